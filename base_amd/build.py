@@ -1,0 +1,67 @@
+"""Builds the native pieces in-tree with hipcc / g++ (no cmake, no JIT cache).
+
+  base_amd/csrc/libbase9hip.so   the HIP kernels + C ABI (gfx950 only)
+  base_amd/host/...              the C++ host programs (added by build_host)
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the dev container; the built
+.so travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HIP_LIB = os.path.join(CSRC, "libbase9hip.so")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target: str, sources: List[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _run(cmd: List[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, f) for f in ("b9_kernels.hip", "b9_capi.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("b9_device.h", "b9_launch.h")] + \
+        [os.path.join(ROOT, "include", "base9_hip.h")]
+    if not force and _newer(HIP_LIB, deps):
+        return HIP_LIB
+    cmd = [HIPCC] + HIP_FLAGS + ["-shared", "-o", HIP_LIB, "-x", "hip"] + srcs
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    _run(cmd)
+    return HIP_LIB
+
+
+def build_all(force: bool = False) -> None:
+    build_hip(force)
+    try:
+        from . import host_build  # noqa: WPS433  (optional until the host programs exist)
+    except ImportError:
+        return
+    host_build.build_host(force)
+
+
+if __name__ == "__main__":
+    build_hip(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    print(HIP_LIB)

@@ -1,0 +1,548 @@
+// b9_capi.cpp -- implementation of the C ABI declared in include/base9_hip.h.
+//
+// Host side of the hot path: validates and stages the model pack and the stars to HBM once,
+// then turns each b9_logpost call into three stream-ordered launches
+// (k_derive_iso -> k_star_like / k_star_marg -> k_finalize).  No CPU fallback exists: without a HIP
+// device b9_ctx_create fails.  See DESIGN.md for the data layout.
+#include "../../include/base9_hip.h"
+#include "b9_device.h"
+#include "b9_launch.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct HostStars {
+    int n = 0, nf = 0;
+    std::vector<double> obs, sigma, mass1, q, prior, fmin, fmax;
+    std::vector<int> stage, wd_type;
+};
+
+}  // namespace
+
+struct b9_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    bool have_pack = false;
+    DevPack pk{};
+    std::vector<void *> pack_allocs;
+
+    bool have_stars = false, stars_dirty = false;
+    HostStars hs;
+    DevStars st{};
+    std::vector<void *> star_allocs;
+
+    DevPriors pr{};
+    b9_options opt{B9_MODE_GIVEN_MASS, 1, 8, 8};
+
+    // per-call work buffers (grown on demand, never shrunk)
+    int cap_walkers = 0, cap_pops = 0;
+    IsoHdr *d_hdr = nullptr;
+    double *d_iso = nullptr;
+    long long iso_stride = 0;
+    int mass_cap = 0;
+    double *d_partial = nullptr;
+    size_t partial_cap = 0;
+    double *d_params = nullptr, *d_logpost = nullptr, *d_perstar = nullptr;
+    size_t perstar_cap = 0;
+
+    // launch plan
+    int tiles_per_block = 0;   // 0 = auto
+    int force_lds = -1;        // -1 auto, 0 never, 1 always (when it fits)
+
+    // timing of the dominant kernel
+    bool timing = false;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t ev_used = 0;
+    double ms_accum = 0.0;
+    int launches = 0;
+};
+
+namespace {
+
+int fail(b9_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ctx, B9_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+template <class T>
+int upload(b9_ctx *ctx, std::vector<void *> &owner, const T *src, size_t count, const T **out)
+{
+    void *d = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIPCHK(ctx, hipMalloc(&d, bytes));
+    owner.push_back(d);
+    if (count) HIPCHK(ctx, hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(d);
+    return B9_OK;
+}
+
+void free_all(std::vector<void *> &v)
+{
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+bool ascending(const double *a, int n)
+{
+    for (int i = 1; i < n; ++i)
+        if (!(a[i] > a[i - 1])) return false;
+    return true;
+}
+
+int padded_filters(int nf) { return nf <= 4 ? 4 : (nf <= 8 ? 8 : 16); }
+
+double Phi(double x) { return 0.5 * std::erfc(-x * M_SQRT1_2); }
+
+// [RECALL] Cluster::setM_wd_up -- normalisation of the log-normal IMF on [0.1 Msun, M_wd_up]
+double log_mass_norm(double m_wd_up)
+{
+    const double mu = -1.02, sg = 0.67729;
+    double zup = (std::log10(m_wd_up) - mu) / sg, zlow = (-1.0 - mu) / sg;
+    double c = 1.0 / (sg * std::sqrt(2.0 * M_PI) * (Phi(zup) - Phi(zlow)));
+    return std::log(c);
+}
+
+double log_prior_mass(double lmn, double m)
+{
+    const double mu = -1.02, sg = 0.67729, ln10 = 2.302585092994045684;
+    double z = (std::log10(m) - mu) / sg;
+    return lmn - 0.5 * z * z - std::log(m) - std::log(ln10);
+}
+
+// (Re)build the device star arrays: sort (singles first, ascending primary mass), SoA, pad.
+int build_stars(b9_ctx *ctx)
+{
+    const HostStars &h = ctx->hs;
+    const int n = h.n, nf = h.nf, nfp = ctx->pk.nfp;
+    if (nf != ctx->pk.nf) return fail(ctx, B9_ERR_INVALID, "stars and pack disagree on n_filt");
+    free_all(ctx->star_allocs);
+    const int n_pad = std::max(64, (n + 63) / 64 * 64);
+    std::vector<int> perm(n);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+        bool ba = h.q[a] > 0.0, bb = h.q[b] > 0.0;
+        if (ba != bb) return !ba;
+        return h.mass1[a] < h.mass1[b];
+    });
+    double log_fs = 0.0;
+    for (int f = 0; f < nf; ++f) log_fs -= std::log(h.fmax[f] - h.fmin[f]);
+
+    std::vector<double> obs((size_t)nfp * n_pad, 0.0), w((size_t)nfp * n_pad, 0.0);
+    std::vector<double> mass1(n_pad, 0.0), q(n_pad, 0.0), c0(n_pad, 0.0), c0m(n_pad, 0.0), la(n_pad, -INFINITY);
+    std::vector<int> flags(n_pad, 0), permp(n_pad, 0);
+    for (int i = 0; i < n; ++i) {
+        const int s = perm[i];
+        double g = 0.0;
+        for (int f = 0; f < nf; ++f) {
+            double sig = h.sigma[(size_t)s * nf + f];
+            obs[(size_t)f * n_pad + i] = h.obs[(size_t)s * nf + f];
+            if (sig > 0.0) {
+                double var = sig * sig;
+                w[(size_t)f * n_pad + i] = 1.0 / var;
+                g -= 0.5 * std::log(2.0 * M_PI * var);
+            }
+        }
+        mass1[i] = h.mass1[s];
+        q[i] = h.q[s];
+        const double pm = h.prior[s];
+        c0m[i] = std::log(pm) + g;
+        c0[i] = std::log(pm) + (log_prior_mass(ctx->pk.log_mass_norm, h.mass1[s]) + g);
+        la[i] = std::log1p(-pm) + log_fs;
+        flags[i] = (h.wd_type[s] > 0 ? 1 : 0) | (h.stage[s] << 8);
+        permp[i] = s;
+    }
+    DevStars st{};
+    st.n = n; st.n_pad = n_pad;
+    int rc;
+    if ((rc = upload(ctx, ctx->star_allocs, obs.data(), obs.size(), &st.obs))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, w.data(), w.size(), &st.w))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, mass1.data(), mass1.size(), &st.mass1))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, q.data(), q.size(), &st.q))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, c0.data(), c0.size(), &st.c0))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, c0m.data(), c0m.size(), &st.c0m))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, la.data(), la.size(), &st.la))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, flags.data(), flags.size(), &st.flags))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, permp.data(), permp.size(), &st.perm))) return rc;
+    ctx->st = st;
+    ctx->stars_dirty = false;
+    return B9_OK;
+}
+
+int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bool want_perstar)
+{
+    if (n_walkers > ctx->cap_walkers || n_pops > ctx->cap_pops || ctx->mass_cap != ((ctx->pk.max_eep + 1) & ~1)) {
+        if (ctx->d_hdr) (void)hipFree(ctx->d_hdr);
+        if (ctx->d_iso) (void)hipFree(ctx->d_iso);
+        if (ctx->d_params) (void)hipFree(ctx->d_params);
+        if (ctx->d_logpost) (void)hipFree(ctx->d_logpost);
+        ctx->d_hdr = nullptr; ctx->d_iso = nullptr; ctx->d_params = nullptr; ctx->d_logpost = nullptr;
+        int cw = std::max(n_walkers, ctx->cap_walkers), cp = std::max(n_pops, ctx->cap_pops);
+        ctx->mass_cap = (ctx->pk.max_eep + 1) & ~1;
+        ctx->iso_stride = (long long)ctx->mass_cap * (ctx->pk.nfp + 1);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_hdr, sizeof(IsoHdr) * cw * cp));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_iso, sizeof(double) * (size_t)ctx->iso_stride * cw * cp));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_params, sizeof(double) * B9_NPARAM * cw));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_logpost, sizeof(double) * cw));
+        ctx->cap_walkers = cw; ctx->cap_pops = cp;
+    }
+    if (n_partial > ctx->partial_cap) {
+        if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+        ctx->d_partial = nullptr;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_partial, sizeof(double) * n_partial));
+        ctx->partial_cap = n_partial;
+    }
+    if (want_perstar) {
+        size_t need = (size_t)n_walkers * ctx->st.n;
+        if (need > ctx->perstar_cap) {
+            if (ctx->d_perstar) (void)hipFree(ctx->d_perstar);
+            ctx->d_perstar = nullptr;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_perstar, sizeof(double) * std::max<size_t>(need, 1)));
+            ctx->perstar_cap = need;
+        }
+    }
+    return B9_OK;
+}
+
+struct Plan { int tiles_per_block, grid_x; bool use_lds; };
+
+Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
+{
+    Plan p;
+    const int n_tiles = (ctx->st.n + 255) / 256;
+    size_t lds = b9k_star_like_lds_bytes(ctx->pk.nfp, n_pops, ctx->pk.max_eep);
+    const bool fits = lds <= 160 * 1024;
+    int tpb = ctx->tiles_per_block;
+    if (tpb <= 0) {
+        // enough workgroups to cover the 256 CUs a few times over, but amortise the per-block
+        // isochrone staging once there is more work than that
+        long long blocks1 = (long long)n_tiles * n_walkers;
+        tpb = (int)std::max<long long>(1, std::min<long long>(8, blocks1 / 2048));
+    }
+    tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
+    p.tiles_per_block = tpb;
+    p.grid_x = (n_tiles + tpb - 1) / tpb;
+    if (ctx->force_lds == 0) p.use_lds = false;
+    else if (ctx->force_lds == 1) p.use_lds = fits;
+    else p.use_lds = fits && tpb >= 2 && lds <= 64 * 1024;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int b9_abi_version(void) { return B9_ABI_VERSION; }
+
+int b9_ctx_create(int device_id, b9_ctx **out)
+{
+    if (!out) return B9_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                         " (the hot path has no CPU fallback)";
+        return B9_ERR_NO_DEVICE;
+    }
+    if (device_id < 0) {
+        if (hipGetDevice(&device_id) != hipSuccess) device_id = 0;
+    }
+    if (device_id >= count) { g_create_error = "device id out of range"; return B9_ERR_INVALID; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return B9_ERR_NO_DEVICE; }
+    b9_ctx *ctx = new b9_ctx();
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx; g_create_error = "hipStreamCreate failed"; return B9_ERR_HIP;
+    }
+    for (int k = 0; k < 12; ++k) { ctx->pr.mean[k] = 0.0; ctx->pr.var[k] = 0.0; }
+    ctx->pr.log_age_min = -INFINITY; ctx->pr.log_age_max = INFINITY;
+    if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
+    if (const char *s = getenv("B9_FORCE_LDS")) ctx->force_lds = atoi(s);
+    *out = ctx;
+    return B9_OK;
+}
+
+void b9_ctx_destroy(b9_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx->pack_allocs);
+    free_all(ctx->star_allocs);
+    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar};
+    for (void *p : bufs) if (p) (void)hipFree(p);
+    for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *b9_last_error(const b9_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int b9_load_pack(b9_ctx *ctx, const b9_pack *p)
+{
+    if (!ctx || !p) return B9_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (p->n_filt < 1 || p->n_filt > B9_MAX_FILT) return fail(ctx, B9_ERR_CAPACITY, "n_filt must be in [1, 16]");
+    if (p->n_feh < 2 || p->n_age < 2 || p->n_y < 1) return fail(ctx, B9_ERR_INVALID, "grid needs >= 2 FeH and >= 2 ages");
+    if (!p->feh || !p->log_age || !p->y || !p->iso_first_eep || !p->iso_n_eep || !p->iso_offset || !p->mass ||
+        !p->mags || !p->abs_coeff)
+        return fail(ctx, B9_ERR_INVALID, "NULL table pointer in pack");
+    if (!ascending(p->feh, p->n_feh) || !ascending(p->log_age, p->n_age) || !ascending(p->y, p->n_y))
+        return fail(ctx, B9_ERR_INVALID, "grid axes must be strictly ascending");
+    const int n_iso = p->n_feh * p->n_y * p->n_age;
+    int max_eep = 0;
+    std::vector<double> tips(n_iso);
+    for (int k = 0; k < n_iso; ++k) {
+        const int n = p->iso_n_eep[k];
+        const long long off = p->iso_offset[k];
+        if (n < 2 || off < 0 || off + n > p->n_points) return fail(ctx, B9_ERR_INVALID, "isochrone index out of range");
+        for (int e = 1; e < n; ++e)
+            if (p->mass[off + e] < p->mass[off + e - 1]) return fail(ctx, B9_ERR_INVALID, "isochrone masses must not descend");
+        max_eep = std::max(max_eep, n);
+        tips[k] = p->mass[off + n - 1];
+    }
+    const bool has_wd = p->n_wc_mass >= 2 && p->n_wc_age >= 2 && p->n_at_teff >= 2 && p->n_at_logg >= 2 && p->n_at_type >= 1;
+    if (has_wd) {
+        if (!p->wc_mass || !p->wc_log_age || !p->wc_log_teff || !p->wc_log_radius || !p->at_logg || !p->at_log_teff || !p->at_mags)
+            return fail(ctx, B9_ERR_INVALID, "NULL WD table pointer in pack");
+        if (!ascending(p->wc_mass, p->n_wc_mass) || !ascending(p->wc_log_age, p->n_wc_age) ||
+            !ascending(p->at_logg, p->n_at_logg) || !ascending(p->at_log_teff, p->n_at_teff) ||
+            (p->n_wc_carb > 1 && !ascending(p->wc_carb, p->n_wc_carb)))
+            return fail(ctx, B9_ERR_INVALID, "WD table axes must be strictly ascending");
+    }
+
+    free_all(ctx->pack_allocs);
+    ctx->have_pack = false;
+    DevPack d{};
+    d.nf = p->n_filt; d.nfp = padded_filters(p->n_filt);
+    d.n_feh = p->n_feh; d.n_y = p->n_y; d.n_age = p->n_age; d.max_eep = max_eep;
+    int rc;
+    auto &A = ctx->pack_allocs;
+    if ((rc = upload(ctx, A, p->feh, p->n_feh, &d.feh))) return rc;
+    if ((rc = upload(ctx, A, p->y, p->n_y, &d.y))) return rc;
+    if ((rc = upload(ctx, A, p->log_age, p->n_age, &d.log_age))) return rc;
+    if ((rc = upload(ctx, A, p->iso_first_eep, n_iso, &d.first))) return rc;
+    if ((rc = upload(ctx, A, p->iso_n_eep, n_iso, &d.cnt))) return rc;
+    std::vector<long long> off(p->iso_offset, p->iso_offset + n_iso);
+    if ((rc = upload(ctx, A, off.data(), off.size(), &d.off))) return rc;
+    if ((rc = upload(ctx, A, p->mass, (size_t)p->n_points, &d.mass))) return rc;
+    {   // pad magnitude rows to nfp
+        std::vector<double> mg((size_t)p->n_points * d.nfp, 0.0);
+        for (long long i = 0; i < p->n_points; ++i)
+            std::memcpy(&mg[(size_t)i * d.nfp], &p->mags[(size_t)i * d.nf], sizeof(double) * d.nf);
+        if ((rc = upload(ctx, A, mg.data(), mg.size(), &d.mags))) return rc;
+    }
+    if ((rc = upload(ctx, A, tips.data(), tips.size(), &d.tips))) return rc;
+    for (int f = 0; f < B9_MAX_FILT; ++f) d.abs_m1[f] = f < d.nf ? p->abs_coeff[f] - 1.0 : 0.0;
+    if (has_wd) {
+        d.n_wc_carb = std::max(1, p->n_wc_carb); d.n_wc_mass = p->n_wc_mass; d.n_wc_age = p->n_wc_age;
+        d.n_at_type = p->n_at_type; d.n_at_logg = p->n_at_logg; d.n_at_teff = p->n_at_teff;
+        const double zero = 0.0;
+        if ((rc = upload(ctx, A, p->n_wc_carb >= 1 ? p->wc_carb : &zero, (size_t)d.n_wc_carb, &d.wc_carb))) return rc;
+        if ((rc = upload(ctx, A, p->wc_mass, p->n_wc_mass, &d.wc_mass))) return rc;
+        if ((rc = upload(ctx, A, p->wc_log_age, p->n_wc_age, &d.wc_log_age))) return rc;
+        size_t nwc = (size_t)d.n_wc_carb * d.n_wc_mass * d.n_wc_age;
+        if ((rc = upload(ctx, A, p->wc_log_teff, nwc, &d.wc_log_teff))) return rc;
+        if ((rc = upload(ctx, A, p->wc_log_radius, nwc, &d.wc_log_radius))) return rc;
+        if ((rc = upload(ctx, A, p->at_logg, p->n_at_logg, &d.at_logg))) return rc;
+        if ((rc = upload(ctx, A, p->at_log_teff, p->n_at_teff, &d.at_log_teff))) return rc;
+        size_t nat = (size_t)d.n_at_type * d.n_at_logg * d.n_at_teff;
+        std::vector<double> at(nat * d.nfp, 0.0);
+        for (size_t i = 0; i < nat; ++i)
+            std::memcpy(&at[i * d.nfp], &p->at_mags[i * d.nf], sizeof(double) * d.nf);
+        if ((rc = upload(ctx, A, at.data(), at.size(), &d.at_mags))) return rc;
+    }
+    d.ifmr_id = p->ifmr_id;
+    d.m_wd_up = p->m_wd_up;
+    d.log_mass_norm = log_mass_norm(p->m_wd_up);
+    ctx->pk = d;
+    ctx->have_pack = true;
+    if (ctx->have_stars) ctx->stars_dirty = true;
+    return B9_OK;
+}
+
+int b9_load_stars(b9_ctx *ctx, const b9_stars *s)
+{
+    if (!ctx || !s) return B9_ERR_INVALID;
+    if (s->n_stars < 1 || s->n_filt < 1 || s->n_filt > B9_MAX_FILT) return fail(ctx, B9_ERR_INVALID, "bad star or filter count");
+    if (!s->obs || !s->sigma || !s->mass1 || !s->mass_ratio || !s->clust_prior || !s->filter_prior_min || !s->filter_prior_max)
+        return fail(ctx, B9_ERR_INVALID, "NULL pointer in stars");
+    HostStars &h = ctx->hs;
+    const size_t n = s->n_stars, nf = s->n_filt;
+    for (size_t f = 0; f < nf; ++f)
+        if (!(s->filter_prior_max[f] > s->filter_prior_min[f])) return fail(ctx, B9_ERR_INVALID, "filter_prior_max must exceed filter_prior_min");
+    for (size_t i = 0; i < n; ++i)
+        if (!(s->clust_prior[i] > 0.0 && s->clust_prior[i] <= 1.0)) return fail(ctx, B9_ERR_INVALID, "clust_prior must be in (0, 1]");
+    h.n = (int)n; h.nf = (int)nf;
+    h.obs.assign(s->obs, s->obs + n * nf);
+    h.sigma.assign(s->sigma, s->sigma + n * nf);
+    h.mass1.assign(s->mass1, s->mass1 + n);
+    h.q.assign(s->mass_ratio, s->mass_ratio + n);
+    h.prior.assign(s->clust_prior, s->clust_prior + n);
+    h.fmin.assign(s->filter_prior_min, s->filter_prior_min + nf);
+    h.fmax.assign(s->filter_prior_max, s->filter_prior_max + nf);
+    if (s->stage) h.stage.assign(s->stage, s->stage + n); else h.stage.assign(n, B9_STAGE_MSRG);
+    if (s->wd_type) h.wd_type.assign(s->wd_type, s->wd_type + n); else h.wd_type.assign(n, 0);
+    ctx->have_stars = true;
+    ctx->stars_dirty = true;
+    return B9_OK;
+}
+
+int b9_set_priors(b9_ctx *ctx, const b9_priors *p)
+{
+    if (!ctx || !p) return B9_ERR_INVALID;
+    for (int k = 0; k < 12; ++k) { ctx->pr.mean[k] = p->mean[k]; ctx->pr.var[k] = p->var[k]; }
+    ctx->pr.log_age_min = p->log_age_min; ctx->pr.log_age_max = p->log_age_max;
+    return B9_OK;
+}
+
+int b9_set_options(b9_ctx *ctx, const b9_options *o)
+{
+    if (!ctx || !o) return B9_ERR_INVALID;
+    if (o->mode != B9_MODE_GIVEN_MASS && o->mode != B9_MODE_MARGINALISED) return fail(ctx, B9_ERR_INVALID, "unknown mode");
+    if (o->n_pops != 1 && o->n_pops != 2) return fail(ctx, B9_ERR_INVALID, "n_pops must be 1 or 2");
+    ctx->opt = *o;
+    return B9_OK;
+}
+
+int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, double *d_logpost,
+                      double *d_perstar, void *stream_v)
+{
+    if (!ctx || !d_params || !d_logpost || n_walkers < 1) return B9_ERR_INVALID;
+    if (!ctx->have_pack || !ctx->have_stars) return fail(ctx, B9_ERR_STATE, "load the pack and the stars first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
+    if (ctx->opt.mode == B9_MODE_MARGINALISED) return fail(ctx, B9_ERR_STATE, "marginalised mode is not built in this revision");
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
+    const int n_pops = ctx->opt.n_pops;
+    const Plan plan = make_plan(ctx, n_walkers, n_pops);
+    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)plan.grid_x * n_walkers, false);
+    if (rc) return rc;
+
+    HIPCHK(ctx, b9k_derive_iso(ctx->pk, d_params, n_walkers, n_pops, ctx->d_hdr, ctx->d_iso, ctx->iso_stride,
+                               ctx->mass_cap, stream));
+    size_t slot = 0;
+    if (ctx->timing) {
+        if (ctx->ev_used == ctx->ev_start.size()) {
+            hipEvent_t a, b;
+            HIPCHK(ctx, hipEventCreate(&a));
+            HIPCHK(ctx, hipEventCreate(&b));
+            ctx->ev_start.push_back(a); ctx->ev_stop.push_back(b);
+        }
+        slot = ctx->ev_used++;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_start[slot], stream));
+    }
+    HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, d_params,
+                              n_walkers, n_pops, plan.use_lds, ctx->d_partial, d_perstar, plan.tiles_per_block,
+                              plan.grid_x, stream));
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
+    HIPCHK(ctx, b9k_finalize(ctx->d_hdr, ctx->d_partial, plan.grid_x, n_pops, d_params, ctx->pr, n_walkers,
+                             d_logpost, stream));
+    return B9_OK;
+}
+
+int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out_logpost, double *out_perstar)
+{
+    if (!ctx || !params || !out_logpost || n_walkers < 1) return B9_ERR_INVALID;
+    if (!ctx->have_pack || !ctx->have_stars) return fail(ctx, B9_ERR_STATE, "load the pack and the stars first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
+    const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
+    int rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)plan.grid_x * n_walkers, out_perstar != nullptr);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
+    rc = b9_logpost_device(ctx, ctx->d_params, n_walkers, ctx->d_logpost, out_perstar ? ctx->d_perstar : nullptr, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_logpost, ctx->d_logpost, sizeof(double) * n_walkers, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_perstar)
+        HIPCHK(ctx, hipMemcpyAsync(out_perstar, ctx->d_perstar, sizeof(double) * (size_t)n_walkers * ctx->st.n,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return B9_OK;
+}
+
+int b9_derive_isochrone(b9_ctx *ctx, const double *param_row, int32_t pop, int32_t cap, double *out_mass,
+                        double *out_mags, int32_t *out_first_eep, int32_t *out_n, double *out_agb_tip)
+{
+    if (!ctx || !param_row || !out_mass || !out_mags || !out_first_eep || !out_n || !out_agb_tip) return B9_ERR_INVALID;
+    if (!ctx->have_pack) return fail(ctx, B9_ERR_STATE, "load the pack first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_capacity(ctx, 1, 1, 1, false);
+    if (rc) return rc;
+    double row[B9_NPARAM];
+    std::memcpy(row, param_row, sizeof row);
+    if (pop) row[B9_P_Y] = row[B9_P_Y2];
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, row, sizeof row, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, b9k_derive_iso(ctx->pk, ctx->d_params, 1, 1, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->stream));
+    IsoHdr h;
+    HIPCHK(ctx, hipMemcpyAsync(&h, ctx->d_hdr, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_n = 0; *out_first_eep = 0; *out_agb_tip = 0.0;
+    if (!h.valid) return B9_OK;
+    if (h.n > cap) return fail(ctx, B9_ERR_CAPACITY, "isochrone longer than the caller's buffers");
+    const int nf = ctx->pk.nf, nfp = ctx->pk.nfp;
+    std::vector<double> buf((size_t)h.n * nfp);
+    HIPCHK(ctx, hipMemcpy(out_mass, ctx->d_iso, sizeof(double) * h.n, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(buf.data(), ctx->d_iso + ctx->mass_cap, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    for (int e = 0; e < h.n; ++e) std::memcpy(&out_mags[(size_t)e * nf], &buf[(size_t)e * nfp], sizeof(double) * nf);
+    *out_n = h.n; *out_first_eep = h.first_eep; *out_agb_tip = h.agb_tip;
+    return B9_OK;
+}
+
+int b9_max_eep(const b9_ctx *ctx) { return (ctx && ctx->have_pack) ? ctx->pk.max_eep : 0; }
+int b9_device_id(const b9_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int b9_bytes_per_star_eval(const b9_ctx *ctx)
+{
+    if (!ctx || !ctx->have_pack) return 0;
+    // obs + 1/sigma^2 per (real) filter, mass1, q, c0, la (8 B each), flags (4 B)
+    return 16 * ctx->pk.nf + 4 * 8 + 4;
+}
+
+int b9_enable_timing(b9_ctx *ctx, int on)
+{
+    if (!ctx) return B9_ERR_INVALID;
+    ctx->timing = on != 0;
+    return B9_OK;
+}
+
+int b9_kernel_time_ms(b9_ctx *ctx, int reset, double *total_ms, int32_t *n_launches)
+{
+    if (!ctx || !total_ms || !n_launches) return B9_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev_stop[i]));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
+        ctx->ms_accum += ms;
+        ctx->launches += 1;
+    }
+    ctx->ev_used = 0;
+    *total_ms = ctx->ms_accum;
+    *n_launches = ctx->launches;
+    if (reset) { ctx->ms_accum = 0.0; ctx->launches = 0; }
+    return B9_OK;
+}
+
+}  // extern "C"

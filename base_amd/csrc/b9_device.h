@@ -1,0 +1,56 @@
+// b9_device.h -- device-side data layout shared by the kernels and the C-ABI host code.
+// gfx950 only.  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define B9_MAX_FILT 16          // padded filter count limit (NFP in {4, 8, 16})
+#define B9_WAVE 64
+
+// Model pack, device view.  Passed to kernels by value (kernarg segment).
+struct DevPack {
+    int nf, nfp;                     // real / padded filter count
+    int n_feh, n_y, n_age;
+    int max_eep;                     // longest isochrone in the pack
+    const double *feh, *y, *log_age;
+    const int *first, *cnt;          // per isochrone
+    const long long *off;
+    const double *mass;              // [n_points]
+    const double *mags;              // [n_points * nfp]  (rows padded with zeros to nfp)
+    const double *tips;              // [n_iso] mass of each isochrone's last point
+    double abs_m1[B9_MAX_FILT];      // abs_coeff[f] - 1   (0 in padded columns)
+    // WD cooling
+    int n_wc_carb, n_wc_mass, n_wc_age;
+    const double *wc_carb, *wc_mass, *wc_log_age, *wc_log_teff, *wc_log_radius;
+    // WD atmospheres, rows padded to nfp
+    int n_at_type, n_at_logg, n_at_teff;
+    const double *at_logg, *at_log_teff, *at_mags;
+    int ifmr_id;
+    double m_wd_up;
+    double log_mass_norm;
+};
+
+// Stars, device view: structure of arrays in the *sorted* order chosen at load time
+// (singles before binaries, each ascending in primary mass), padded to a multiple of 64.
+struct DevStars {
+    int n, n_pad;
+    const double *obs;               // [nfp][n_pad]
+    const double *w;                 // [nfp][n_pad]  1/sigma^2, 0 = filter unused
+    const double *mass1, *q;         // [n_pad]
+    const double *c0;                // [n_pad] log p + logPriorMass(mass1) + sum_f -0.5 log(2 pi sigma_f^2)
+    const double *c0m;               // [n_pad] log p + sum_f -0.5 log(2 pi sigma_f^2)   (marginalised mode)
+    const double *la;                // [n_pad] log((1-p) fsLike)  (-inf when p == 1)
+    const int *flags;                // [n_pad] bit0 = DB atmosphere, bits 8.. = stage
+    const int *perm;                 // [n_pad] original index of sorted star i
+};
+
+// Header of one derived isochrone (one per walker x population).
+struct IsoHdr {
+    int valid, first_eep, n, i_feh, i_y, i_age;
+    double agb_tip, t_feh, t_y, t_age;
+};
+
+struct DevPriors {
+    double mean[12], var[12];
+    double log_age_min, log_age_max;
+};

@@ -1,0 +1,520 @@
+// b9_kernels.hip -- hand-written gfx950 kernels of the BASE-9 per-step log-posterior path.
+//
+//   k_derive_iso   SURVEY 8a row a3   one workgroup per (walker, population): grid bracket,
+//                                     EEP-range intersection, EEP-wise tri-linear interpolation
+//   k_star_like    rows a4-a7, a9     one LANE per star (given-mass mode): LDS- or L1-resident
+//                                     binary search + linear interpolation, binary flux
+//                                     combination, WD branch, Gaussian log-likelihood,
+//                                     population and field-star mixtures; wave-shuffle +
+//                                     LDS block reduction to one partial per workgroup
+//   k_finalize     row a8             fixed-order sum of the partials + cluster prior
+//
+// The reference source is not mounted (/root/reference/README.md:4), so none of this can
+// cite a reference file:line; DESIGN.md "Math" is the normative restatement and
+// oracle/b9_oracle.c the CPU checker.  Floating-point contract: built with
+// -ffp-contract=off; every interpolation is an explicit fma(t, b - a, a), which makes the
+// derived isochrone bit-identical to the oracle's.
+//
+// No MFMA anywhere: there is no dense contraction on this path (BASELINE.json north_star).
+#include "b9_device.h"
+#include "b9_launch.h"
+#include "../../include/base9_hip.h"
+
+#define LOG_G_PLUS_LOG_MSUN 26.12302173752
+#define MF_MU (-1.02)
+#define MF_SIGMA 0.67729
+#define LN10 2.302585092994045684
+#define NEG_INF (-__builtin_inf())
+
+__device__ __forceinline__ double lerp(double a, double b, double t) { return fma(t, b - a, a); }
+
+// largest i in [0, n-2] with ax[i] <= x (clamped); identical to the oracle's bracket()
+__device__ __forceinline__ int bracket(const double *__restrict__ ax, int n, double x)
+{
+    int lo = 0, hi = n - 1;
+    if (n < 2) return 0;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ax[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ double logaddexp(double a, double b)
+{
+    if (a == NEG_INF) return b;
+    if (b == NEG_INF) return a;
+    double hi = a > b ? a : b, lo = a > b ? b : a;
+    return hi + log1p(exp(lo - hi));
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;   // valid in lane 0
+}
+
+// ------------------------------------------------------------------------------------------
+// k_derive_iso
+// ------------------------------------------------------------------------------------------
+struct Corners {
+    long long off[8];      // point offset of EEP `lo` in each corner isochrone
+    int ny;
+    double t_age, t_y, t_feh;
+};
+
+template <bool MASS>
+__device__ __forceinline__ double interp_corner(const DevPack &pk, const Corners &c, int e, int col)
+{
+    double vf[2];
+#pragma unroll
+    for (int df = 0; df < 2; ++df) {
+        double vy[2] = {0.0, 0.0};
+        for (int dy = 0; dy < c.ny; ++dy) {
+            long long p0 = c.off[(df * 2 + dy) * 2 + 0] + e, p1 = c.off[(df * 2 + dy) * 2 + 1] + e;
+            double a = MASS ? pk.mass[p0] : pk.mags[p0 * pk.nfp + col];
+            double b = MASS ? pk.mass[p1] : pk.mags[p1 * pk.nfp + col];
+            vy[dy] = lerp(a, b, c.t_age);
+        }
+        vf[df] = (c.ny == 2) ? lerp(vy[0], vy[1], c.t_y) : vy[0];
+    }
+    return lerp(vf[0], vf[1], c.t_feh);
+}
+
+__global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, const double *__restrict__ params,
+                                                     int n_pops, IsoHdr *__restrict__ hdr,
+                                                     double *__restrict__ iso_data, long long iso_stride,
+                                                     int mass_cap)
+{
+    const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops;
+    const double *par = params + (size_t)w * B9_NPARAM;
+    __shared__ IsoHdr sh;
+    __shared__ Corners sc;
+    if (threadIdx.x == 0) {
+        IsoHdr h;
+        h.valid = 0; h.first_eep = 0; h.n = 0; h.i_feh = h.i_y = h.i_age = 0;
+        h.agb_tip = 0.0; h.t_feh = h.t_y = h.t_age = 0.0;
+        const double log_age = par[B9_P_LOGAGE], feh = par[B9_P_FEH];
+        const double y = pop ? par[B9_P_Y2] : par[B9_P_Y];
+        bool ok = (log_age >= pk.log_age[0] && log_age <= pk.log_age[pk.n_age - 1]) &&
+                  (feh >= pk.feh[0] && feh <= pk.feh[pk.n_feh - 1]) && pk.n_age >= 2 && pk.n_feh >= 2;
+        if (pk.n_y > 1) ok = ok && (y >= pk.y[0] && y <= pk.y[pk.n_y - 1]);
+        if (ok) {
+            h.i_age = bracket(pk.log_age, pk.n_age, log_age);
+            h.t_age = (log_age - pk.log_age[h.i_age]) / (pk.log_age[h.i_age + 1] - pk.log_age[h.i_age]);
+            h.i_feh = bracket(pk.feh, pk.n_feh, feh);
+            h.t_feh = (feh - pk.feh[h.i_feh]) / (pk.feh[h.i_feh + 1] - pk.feh[h.i_feh]);
+            const int ny = pk.n_y > 1 ? 2 : 1;
+            if (ny == 2) {
+                h.i_y = bracket(pk.y, pk.n_y, y);
+                h.t_y = (y - pk.y[h.i_y]) / (pk.y[h.i_y + 1] - pk.y[h.i_y]);
+            }
+            int lo = -2147483647, hi = 2147483647;
+            for (int df = 0; df < 2; ++df) for (int dy = 0; dy < ny; ++dy) for (int da = 0; da < 2; ++da) {
+                int k = ((h.i_feh + df) * pk.n_y + (h.i_y + dy)) * pk.n_age + h.i_age + da;
+                int f0 = pk.first[k], f1 = f0 + pk.cnt[k];
+                lo = f0 > lo ? f0 : lo;
+                hi = f1 < hi ? f1 : hi;
+            }
+            int n = hi - lo;
+            if (n >= 2 && n <= mass_cap) {
+                for (int df = 0; df < 2; ++df) for (int dy = 0; dy < 2; ++dy) for (int da = 0; da < 2; ++da) {
+                    int dyc = dy < ny ? dy : 0;
+                    int k = ((h.i_feh + df) * pk.n_y + (h.i_y + dyc)) * pk.n_age + h.i_age + da;
+                    sc.off[(df * 2 + dy) * 2 + da] = pk.off[k] + (lo - pk.first[k]);
+                }
+                sc.ny = ny; sc.t_age = h.t_age; sc.t_y = h.t_y; sc.t_feh = h.t_feh;
+                h.first_eep = lo; h.n = n; h.valid = 1;
+                h.agb_tip = interp_corner<true>(pk, sc, n - 1, 0);
+            }
+        }
+        sh = h;
+        hdr[wp] = h;
+    }
+    __syncthreads();
+    if (!sh.valid) return;
+    const int n = sh.n, nfp = pk.nfp;
+    double *omass = iso_data + (size_t)wp * iso_stride;
+    double *omags = omass + mass_cap;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) omass[e] = interp_corner<true>(pk, sc, e, 0);
+    for (int idx = threadIdx.x; idx < n * nfp; idx += blockDim.x) {
+        int e = idx / nfp, c = idx - e * nfp;
+        omags[idx] = (c < pk.nf) ? interp_corner<false>(pk, sc, e, c) : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-star evolution (device functions)
+// ------------------------------------------------------------------------------------------
+template <int NFP>
+struct IsoView {
+    const double *mass;   // LDS or global
+    const double *mags;   // rows of NFP doubles
+    int n;
+    double tip;
+    int i_feh, i_y;
+    double t_feh, t_y;
+};
+
+template <int NFP>
+__device__ __forceinline__ void fill(double (&out)[NFP], double v)
+{
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) out[f] = v;
+}
+
+// binary search in the isochrone's mass column + linear interpolation.
+template <int NFP>
+__device__ __forceinline__ void msrgb_mags(const IsoView<NFP> &iso, double m, double (&out)[NFP])
+{
+    if (m < iso.mass[0]) { fill<NFP>(out, B9_MAG_NOFLUX); return; }
+    int lo = 0, hi = iso.n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (iso.mass[mid] <= m) lo = mid; else hi = mid;
+    }
+    const double a = iso.mass[lo], d = iso.mass[lo + 1] - a;
+    const double t = (d > 0.0) ? (m - a) / d : 0.0;
+    const double *r0 = iso.mags + (size_t)lo * NFP;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) out[f] = lerp(r0[f], r0[NFP + f], t);
+}
+
+__device__ __forceinline__ double ifmr(int id, const double *__restrict__ par, double m)
+{
+    switch (id) {
+    case B9_IFMR_WEIDEMANN: {
+        const double mf[7] = {0.55, 0.60, 0.68, 0.79, 0.88, 0.95, 1.02};
+        int i = (int)floor(m) - 1;
+        i = i < 0 ? 0 : (i > 5 ? 5 : i);
+        // same bracket as the oracle: largest i with mi[i] <= m, clamped to [0, 5]
+        double mi = (double)(i + 1);
+        return lerp(mf[i], mf[i + 1], (m - mi) / ((double)(i + 2) - mi));
+    }
+    case B9_IFMR_WILLIAMS:    return 0.339 + 0.129 * m;
+    case B9_IFMR_SALARIS_LIN: return 0.466 + 0.084 * m;
+    case B9_IFMR_SALARIS_PW:  return (m < 4.0) ? 0.134 * m + 0.331 : 0.047 * m + 0.679;
+    case B9_IFMR_LINEAR:      return par[B9_P_IFMR_INTERCEPT] + par[B9_P_IFMR_SLOPE] * (m - 3.0);
+    default: {
+        double d = m - 3.0;
+        return par[B9_P_IFMR_INTERCEPT] + par[B9_P_IFMR_SLOPE] * d + par[B9_P_IFMR_QUAD] * d * d;
+    }
+    }
+}
+
+__device__ inline double prec_log_age_corner(const DevPack &pk, int ifeh, int iy, double m)
+{
+    const int na = pk.n_age;
+    const double *tips = pk.tips + (size_t)(ifeh * pk.n_y + iy) * na;
+    const double tip0 = tips[0];
+    if (m > tip0) return pk.log_age[0] - 2.7 * log10(m / tip0);
+    if (m <= tips[na - 1]) return pk.log_age[na - 1];
+    int lo = 0, hi = na - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (tips[mid] >= m) lo = mid; else hi = mid;
+    }
+    const double a = tips[lo], b = tips[lo + 1];
+    const double t = (b != a) ? (m - a) / (b - a) : 0.0;
+    return lerp(pk.log_age[lo], pk.log_age[lo + 1], t);
+}
+
+// IFMR -> WD cooling model -> atmosphere table.  Tables stay in HBM/L2:
+// only the few per cent of stars above the AGB tip take this branch, and because stars are
+// sorted by mass they sit together in the same waves.
+template <int NFP>
+__device__ __noinline__ void wd_mags(const DevPack &pk, const IsoView<NFP> &iso,
+                                     const double *__restrict__ par, double m, int wd_type,
+                                     double (&out)[NFP])
+{
+    if (pk.n_wc_mass < 2 || pk.n_at_teff < 2) { fill<NFP>(out, B9_MAG_NOFLUX); return; }
+    const int ny = pk.n_y > 1 ? 2 : 1;
+    double vf[2];
+    for (int df = 0; df < 2; ++df) {
+        double vy[2] = {0.0, 0.0};
+        for (int dy = 0; dy < ny; ++dy) vy[dy] = prec_log_age_corner(pk, iso.i_feh + df, iso.i_y + dy, m);
+        vf[df] = (ny == 2) ? lerp(vy[0], vy[1], iso.t_y) : vy[0];
+    }
+    const double prec = lerp(vf[0], vf[1], iso.t_feh);
+    const double log_age = par[B9_P_LOGAGE];
+    if (prec >= log_age) { fill<NFP>(out, -4.0); return; }
+    const double wd_mass = ifmr(pk.ifmr_id, par, m);
+    const double log_cool = log10(pow(10.0, log_age) - pow(10.0, prec));
+
+    const int ia = bracket(pk.wc_log_age, pk.n_wc_age, log_cool);
+    const double ta = (log_cool - pk.wc_log_age[ia]) / (pk.wc_log_age[ia + 1] - pk.wc_log_age[ia]);
+    const int im = bracket(pk.wc_mass, pk.n_wc_mass, wd_mass);
+    const double tm = (wd_mass - pk.wc_mass[im]) / (pk.wc_mass[im + 1] - pk.wc_mass[im]);
+    const int nc = pk.n_wc_carb > 1 ? 2 : 1;
+    int ic = 0; double tc = 0.0;
+    if (nc == 2) {
+        ic = bracket(pk.wc_carb, pk.n_wc_carb, par[B9_P_CARBONICITY]);
+        tc = (par[B9_P_CARBONICITY] - pk.wc_carb[ic]) / (pk.wc_carb[ic + 1] - pk.wc_carb[ic]);
+    }
+    double tr[2];
+    for (int q = 0; q < 2; ++q) {
+        const double *tab = q ? pk.wc_log_radius : pk.wc_log_teff;
+        double vc[2] = {0.0, 0.0};
+        for (int dc = 0; dc < nc; ++dc) {
+            double vm[2];
+            for (int dm = 0; dm < 2; ++dm) {
+                size_t base = ((size_t)(ic + dc) * pk.n_wc_mass + (im + dm)) * pk.n_wc_age + ia;
+                vm[dm] = lerp(tab[base], tab[base + 1], ta);
+            }
+            vc[dc] = lerp(vm[0], vm[1], tm);
+        }
+        tr[q] = (nc == 2) ? lerp(vc[0], vc[1], tc) : vc[0];
+    }
+    const double log_teff = tr[0];
+    const double logg = LOG_G_PLUS_LOG_MSUN + log10(wd_mass) - 2.0 * tr[1];
+    const int ty = (wd_type > 0 && pk.n_at_type > 1) ? 1 : 0;
+    const int it = bracket(pk.at_log_teff, pk.n_at_teff, log_teff);
+    const double tt = (log_teff - pk.at_log_teff[it]) / (pk.at_log_teff[it + 1] - pk.at_log_teff[it]);
+    const int ig = bracket(pk.at_logg, pk.n_at_logg, logg);
+    const double tg = (logg - pk.at_logg[ig]) / (pk.at_logg[ig + 1] - pk.at_logg[ig]);
+    const double *g0 = pk.at_mags + (((size_t)ty * pk.n_at_logg + ig) * pk.n_at_teff + it) * NFP;
+    const double *g1 = g0 + (size_t)pk.n_at_teff * NFP;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) {
+        double v0 = lerp(g0[f], g0[NFP + f], tt);
+        double v1 = lerp(g1[f], g1[NFP + f], tt);
+        out[f] = lerp(v0, v1, tg);
+    }
+}
+
+// which branch a ZAMS mass is on ([RECALL] Star::getStatus)
+template <int NFP>
+__device__ __forceinline__ void star_mags(const DevPack &pk, const IsoView<NFP> &iso,
+                                          const double *__restrict__ par, double m, int wd_type,
+                                          double (&out)[NFP])
+{
+    if (!(m > 0.0))          fill<NFP>(out, B9_MAG_NOFLUX);
+    else if (m <= iso.tip)   msrgb_mags<NFP>(iso, m, out);
+    else if (m <= pk.m_wd_up) wd_mags<NFP>(pk, iso, par, m, wd_type, out);
+    else                     fill<NFP>(out, B9_MAG_NOFLUX);
+}
+
+// SURVEY 8a rows a5 + a6: combined magnitudes -> sum_f w_f (pred_f - obs_f)^2.
+// Flux addition is done as  m1 - 2.5 log10(1 + 10^(-0.4 (m2 - m1)))  : one exp and one log1p
+// per filter instead of two pow and a log10, and no cancellation.
+template <int NFP>
+__device__ __forceinline__ double chi2_system(const DevPack &pk, const IsoView<NFP> &iso,
+                                              const double *__restrict__ par, double m1, double q,
+                                              int wd_type, const double (&obs)[NFP], const double (&w)[NFP])
+{
+    double p1[NFP];
+    star_mags<NFP>(pk, iso, par, m1, wd_type, p1);
+    if (q > 0.0) {
+        double p2[NFP];
+        star_mags<NFP>(pk, iso, par, q * m1, wd_type, p2);
+#pragma unroll
+        for (int f = 0; f < NFP; ++f)
+            p1[f] -= (2.5 / LN10) * log1p(exp((-0.4 * LN10) * (p2[f] - p1[f])));
+    }
+    const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
+    double chi2 = 0.0;
+    bool finite = true;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) {
+        double pred = p1[f] + (mod + pk.abs_m1[f] * av);
+        finite = finite && isfinite(pred);
+        double d = pred - obs[f];
+        chi2 = fma(w[f] * d, d, chi2);
+    }
+    return finite ? chi2 : __builtin_inf();
+}
+
+// ------------------------------------------------------------------------------------------
+// k_star_like  (given-mass mode)
+// ------------------------------------------------------------------------------------------
+template <int NFP, int NPOPS, bool USE_LDS>
+__global__ __launch_bounds__(256) void k_star_like(DevPack pk, DevStars st,
+                                                    const IsoHdr *__restrict__ hdr,
+                                                    const double *__restrict__ iso_data,
+                                                    long long iso_stride, int mass_cap,
+                                                    const double *__restrict__ params,
+                                                    double *__restrict__ partial,
+                                                    double *__restrict__ perstar, int tiles_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // [0..7] reduction scratch, then isochrone(s)
+    const int w = blockIdx.y, tid = threadIdx.x;
+    const double *par = params + (size_t)w * B9_NPARAM;
+
+    IsoView<NFP> iso[NPOPS];
+    bool valid = true;
+#pragma unroll
+    for (int k = 0; k < NPOPS; ++k) {
+        const IsoHdr h = hdr[w * NPOPS + k];
+        valid = valid && h.valid;
+        iso[k].n = h.n; iso[k].tip = h.agb_tip;
+        iso[k].i_feh = h.i_feh; iso[k].i_y = h.i_y; iso[k].t_feh = h.t_feh; iso[k].t_y = h.t_y;
+        const double *g = iso_data + (size_t)(w * NPOPS + k) * iso_stride;
+        iso[k].mass = g; iso[k].mags = g + mass_cap;
+    }
+    const int tile0 = blockIdx.x * tiles_per_block;
+    if (!valid) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
+        if (tid == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = 0.0;
+        if (perstar)
+            for (int t = 0; t < tiles_per_block; ++t) {
+                int i = (tile0 + t) * 256 + tid;
+                if (i < st.n) perstar[(size_t)w * st.n + st.perm[i]] = NEG_INF;
+            }
+        return;
+    }
+    if (USE_LDS) {
+        double *dst = smem + 8;
+#pragma unroll
+        for (int k = 0; k < NPOPS; ++k) {
+            const int n = iso[k].n;
+            const int n_even = (n + 1) & ~1;
+            const double2 *sm = reinterpret_cast<const double2 *>(iso[k].mass);
+            const double2 *sg = reinterpret_cast<const double2 *>(iso[k].mags);
+            double2 *dm = reinterpret_cast<double2 *>(dst);
+            double2 *dg = reinterpret_cast<double2 *>(dst + n_even);
+            for (int j = tid; j < n_even / 2; j += 256) dm[j] = sm[j];
+            for (int j = tid; j < n * NFP / 2; j += 256) dg[j] = sg[j];
+            iso[k].mass = dst; iso[k].mags = dst + n_even;
+            dst += n_even + (size_t)n * NFP;
+        }
+        __syncthreads();
+    }
+
+    const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+    double acc = 0.0;
+    for (int t = 0; t < tiles_per_block; ++t) {
+        const int i = (tile0 + t) * 256 + tid;
+        if ((tile0 + t) * 256 >= st.n) break;
+        double v = 0.0;
+        if (i < st.n) {
+            double obs[NFP], wgt[NFP];
+#pragma unroll
+            for (int f = 0; f < NFP; ++f) {
+                obs[f] = st.obs[(size_t)f * st.n_pad + i];
+                wgt[f] = st.w[(size_t)f * st.n_pad + i];
+            }
+            const double m1 = st.mass1[i], q = st.q[i], c0 = st.c0[i], la = st.la[i];
+            const int wd_type = st.flags[i] & 1;
+            double ll[NPOPS];
+#pragma unroll
+            for (int k = 0; k < NPOPS; ++k)
+                ll[k] = c0 - 0.5 * chi2_system<NFP>(pk, iso[k], par, m1, q, wd_type, obs, wgt);
+            double l = ll[0];
+            if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[NPOPS - 1]);
+            v = logaddexp(la, l);
+            if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
+        }
+        acc += v;
+    }
+    // wave shuffle reduction, then fixed-order LDS sum of the 4 wave partials
+    double s = wave_sum(acc);
+    if ((tid & 63) == 0) smem[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize: per walker, fixed-order sum of the workgroup partials + cluster prior
+// ------------------------------------------------------------------------------------------
+__device__ inline double log_prior_cluster(const DevPriors &pr, const double *__restrict__ par, int n_pops)
+{
+    if (!(par[B9_P_LOGAGE] >= pr.log_age_min && par[B9_P_LOGAGE] <= pr.log_age_max)) return NEG_INF;
+    if (par[B9_P_ABS] < 0.0) return NEG_INF;
+    if (n_pops == 2 && !(par[B9_P_LAMBDA] >= 0.0 && par[B9_P_LAMBDA] <= 1.0)) return NEG_INF;
+    double lp = 0.0;
+    for (int k = 0; k < B9_NPARAM; ++k) {
+        if (k == B9_P_LOGAGE) continue;
+        if (n_pops < 2 && (k == B9_P_Y2 || k == B9_P_LAMBDA)) continue;
+        if (pr.var[k] > 0.0) {
+            double d = par[k] - pr.mean[k];
+            lp -= 0.5 * d * d / pr.var[k];
+        }
+    }
+    return lp;
+}
+
+__global__ __launch_bounds__(64) void k_finalize(const IsoHdr *__restrict__ hdr,
+                                                  const double *__restrict__ partial, int n_partial,
+                                                  int n_pops, const double *__restrict__ params,
+                                                  DevPriors pr, double *__restrict__ logpost)
+{
+    const int w = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int j = tid; j < n_partial; j += 64) s += partial[(size_t)w * n_partial + j];
+    s = wave_sum(s);
+    if (tid == 0) {
+        bool valid = true;
+        for (int k = 0; k < n_pops; ++k) valid = valid && hdr[w * n_pops + k].valid;
+        const double lp = log_prior_cluster(pr, params + (size_t)w * B9_NPARAM, n_pops);
+        logpost[w] = (valid && lp != NEG_INF) ? lp + s : NEG_INF;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+hipError_t b9k_derive_iso(const DevPack &pk, const double *d_params, int n_walkers, int n_pops,
+                          IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap,
+                          hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_derive_iso, dim3(n_walkers * n_pops), dim3(256), 0, stream,
+                       pk, d_params, n_pops, hdr, iso_data, iso_stride, mass_cap);
+    return hipGetLastError();
+}
+
+size_t b9k_star_like_lds_bytes(int nfp, int n_pops, int max_eep)
+{
+    size_t n_even = (size_t)((max_eep + 1) & ~1);
+    return sizeof(double) * (8 + (size_t)n_pops * (n_even + (size_t)max_eep * nfp));
+}
+
+template <int NFP, int NPOPS, bool USE_LDS>
+static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
+                                   const double *iso_data, long long iso_stride, int mass_cap,
+                                   const double *d_params, int n_walkers, double *partial,
+                                   double *perstar, int tiles_per_block, int grid_x, hipStream_t stream)
+{
+    size_t lds = USE_LDS ? b9k_star_like_lds_bytes(NFP, NPOPS, pk.max_eep) : 8 * sizeof(double);
+    auto kern = k_star_like<NFP, NPOPS, USE_LDS>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid_x, n_walkers), dim3(256), lds, stream, pk, st, hdr, iso_data,
+                       iso_stride, mass_cap, d_params, partial, perstar, tiles_per_block);
+    return hipGetLastError();
+}
+
+hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
+                         const double *iso_data, long long iso_stride, int mass_cap,
+                         const double *d_params, int n_walkers, int n_pops, bool use_lds,
+                         double *partial, double *perstar, int tiles_per_block, int grid_x,
+                         hipStream_t stream)
+{
+#define B9_DISPATCH(NFP)                                                                              \
+    if (n_pops == 2) {                                                                                \
+        return use_lds ? launch_star_like<NFP, 2, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, grid_x, stream) \
+                       : launch_star_like<NFP, 2, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, grid_x, stream); \
+    } else {                                                                                          \
+        return use_lds ? launch_star_like<NFP, 1, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, grid_x, stream) \
+                       : launch_star_like<NFP, 1, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, grid_x, stream); \
+    }
+    switch (pk.nfp) {
+    case 4:  B9_DISPATCH(4)
+    case 8:  B9_DISPATCH(8)
+    case 16: B9_DISPATCH(16)
+    default: return hipErrorInvalidValue;
+    }
+#undef B9_DISPATCH
+}
+
+hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial, int n_pops,
+                        const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
+                        hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(n_walkers), dim3(64), 0, stream, hdr, partial, n_partial,
+                       n_pops, d_params, pr, d_logpost);
+    return hipGetLastError();
+}

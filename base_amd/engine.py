@@ -1,0 +1,132 @@
+"""Python front-end over the C ABI (include/base9_hip.h) -- used by tests, bench and the
+walker-parallel driver.  Everything numeric happens in libbase9hip.so on the GPU; this class
+only pins buffers and forwards calls.  It raises if the library or a GPU is missing: the hot
+path has no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import abi
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class B9Error(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"base9_hip error {code}: {msg}")
+        self.code = code
+
+
+class Engine:
+    """One context on one GPU: `Engine(pack, stars, priors, options).logpost(params)`."""
+
+    def __init__(self, pack: Optional[abi.Pinned] = None, stars: Optional[abi.Pinned] = None,
+                 priors: Optional[abi.b9_priors] = None, options: Optional[abi.b9_options] = None,
+                 device: int = -1, lib: Optional[C.CDLL] = None):
+        self.lib = lib or abi.load_hip_library()
+        self._ctx = C.c_void_p()
+        rc = self.lib.b9_ctx_create(int(device), C.byref(self._ctx))
+        if rc != abi.B9_OK:
+            msg = self.lib.b9_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise B9Error(rc, msg)
+        self.n_stars = 0
+        self.n_filt = 0
+        if pack is not None:
+            self.load_pack(pack)
+        if stars is not None:
+            self.load_stars(stars)
+        if priors is not None:
+            self.set_priors(priors)
+        if options is not None:
+            self.set_options(options)
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != abi.B9_OK:
+            raise B9Error(rc, self.lib.b9_last_error(self._ctx).decode())
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self.lib.b9_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- staging --------------------------------------------------------------------------
+    def load_pack(self, pack: abi.Pinned) -> None:
+        self._check(self.lib.b9_load_pack(self._ctx, pack.byref()))
+        self.n_filt = pack.struct.n_filt
+
+    def load_stars(self, stars: abi.Pinned) -> None:
+        self._check(self.lib.b9_load_stars(self._ctx, stars.byref()))
+        self.n_stars = stars.struct.n_stars
+
+    def set_priors(self, priors: abi.b9_priors) -> None:
+        self._check(self.lib.b9_set_priors(self._ctx, C.byref(priors)))
+
+    def set_options(self, options: abi.b9_options) -> None:
+        self._check(self.lib.b9_set_options(self._ctx, C.byref(options)))
+
+    # -- hot path -------------------------------------------------------------------------
+    def logpost(self, params: np.ndarray, perstar: bool = False):
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, abi.B9_NPARAM)
+        nw = params.shape[0]
+        out = np.empty(nw)
+        ps = np.empty((nw, self.n_stars)) if perstar else None
+        self._check(self.lib.b9_logpost(self._ctx, params.ctypes.data_as(_dp), nw, out.ctypes.data_as(_dp),
+                                        ps.ctypes.data_as(_dp) if perstar else None))
+        return (out, ps) if perstar else out
+
+    def logpost_device(self, d_params: int, n_walkers: int, d_logpost: int, d_perstar: int = 0,
+                       stream: int = 0) -> None:
+        """Asynchronous, device pointers (ints, e.g. torch.Tensor.data_ptr())."""
+        self._check(self.lib.b9_logpost_device(self._ctx, C.c_void_p(d_params), int(n_walkers),
+                                               C.c_void_p(d_logpost), C.c_void_p(d_perstar or None),
+                                               C.c_void_p(stream or None)))
+
+    def derive_isochrone(self, param_row: np.ndarray, pop: int = 0, cap: int = 4096) -> Tuple[int, np.ndarray, np.ndarray, float]:
+        row = np.ascontiguousarray(param_row, dtype=np.float64)
+        mass = np.empty(cap)
+        mags = np.empty(cap * self.n_filt)
+        first, n, tip = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        self._check(self.lib.b9_derive_isochrone(self._ctx, row.ctypes.data_as(_dp), pop, cap,
+                                                 mass.ctypes.data_as(_dp), mags.ctypes.data_as(_dp),
+                                                 C.byref(first), C.byref(n), C.byref(tip)))
+        k = n.value
+        return first.value, mass[:k].copy(), mags[:k * self.n_filt].reshape(k, self.n_filt).copy(), tip.value
+
+    # -- introspection --------------------------------------------------------------------
+    def bytes_per_star_eval(self) -> int:
+        return int(self.lib.b9_bytes_per_star_eval(self._ctx))
+
+    def max_eep(self) -> int:
+        return int(self.lib.b9_max_eep(self._ctx))
+
+    def enable_timing(self, on: bool = True) -> None:
+        self._check(self.lib.b9_enable_timing(self._ctx, 1 if on else 0))
+
+    def kernel_time_ms(self, reset: bool = True) -> Tuple[float, int]:
+        ms, n = C.c_double(0), C.c_int32(0)
+        self._check(self.lib.b9_kernel_time_ms(self._ctx, 1 if reset else 0, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def make_problem(pack_dict: Dict, cluster: Dict, n_pops: int = 1, mode: int = abi.MODE_GIVEN_MASS,
+                 marg_iso_increm: int = 8, marg_n_q: int = 8):
+    """Pin a synthetic pack + cluster into ABI structs: (pack, stars, priors, options)."""
+    from . import synth
+    pack = abi.make_pack(pack_dict)
+    stars = abi.make_stars(cluster)
+    priors = synth.default_priors(pack_dict, cluster["truth"], n_pops)
+    options = abi.make_options(mode, n_pops, marg_iso_increm, marg_n_q)
+    return pack, stars, priors, options

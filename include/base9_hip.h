@@ -1,0 +1,214 @@
+/*
+ * base9_hip.h -- C ABI of the MI355X-native BASE-9 per-step log-posterior path.
+ *
+ * This is the drop-in boundary of the hot path.  In the reference
+ * the boundary is an in-process C++ call -- the MCMC driver calls "logPost(proposed cluster)"
+ * once per step, which derives one isochrone from the loaded model pack and loops over the
+ * cluster's stars.  That source is NOT mounted (/root/reference/README.md:4 redirects to
+ * BayesianStellarEvolution/base-cpp), so no entry point below can cite a reference file:line;
+ * each cites instead the SURVEY.md section-8a row it implements and, tagged [RECALL], the
+ * upstream function it is believed to replace.  Parity with BASE-9 is therefore UNPINNED.
+ *
+ * Conventions
+ *  - plain C structs, plain pointers and sizes; no C++/torch types cross this boundary;
+ *  - the caller owns every host buffer passed in; the context owns all device memory;
+ *  - every function returns B9_OK (0) or a negative b9_status; b9_last_error() gives text;
+ *  - proposed parameters outside the model grid are NOT an error: that walker's
+ *    log-posterior is -INFINITY (the reference rejects such a step [RECALL]);
+ *  - one context per GPU, not thread-safe, all work stream-ordered on the context's stream;
+ *  - there is NO CPU fallback: without a HIP device b9_ctx_create fails with B9_ERR_NO_DEVICE.
+ */
+#ifndef BASE9_HIP_H
+#define BASE9_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B9_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------ */
+typedef enum b9_status {
+    B9_OK = 0,
+    B9_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime failure at create            */
+    B9_ERR_INVALID   = -2,   /* bad argument (NULL, negative size, unsorted axis ...)    */
+    B9_ERR_STATE     = -3,   /* call order: pack/stars not loaded yet                    */
+    B9_ERR_HIP       = -4,   /* a HIP call failed; see b9_last_error                     */
+    B9_ERR_CAPACITY  = -5    /* table too large for the kernel's LDS plan                */
+} b9_status;
+
+/* ---- cluster parameter row ([RECALL] Cluster::getParam order) ------ */
+enum {
+    B9_P_LOGAGE = 0,      /* log10(age/yr)                                              */
+    B9_P_Y = 1,           /* helium mass fraction (population A in a two-pop run)        */
+    B9_P_FEH = 2,         /* [Fe/H]                                                      */
+    B9_P_MOD = 3,         /* distance modulus (m-M)_V, includes A_V                      */
+    B9_P_ABS = 4,         /* absorption A_V                                              */
+    B9_P_CARBONICITY = 5, /* WD core carbon fraction                                     */
+    B9_P_IFMR_INTERCEPT = 6,
+    B9_P_IFMR_SLOPE = 7,
+    B9_P_IFMR_QUAD = 8,
+    B9_P_Y2 = 9,          /* helium of population B (two-pop only; [RECALL] multiPopMcmc)*/
+    B9_P_LAMBDA = 10,     /* fraction of stars in population A (two-pop only)            */
+    B9_P_RESERVED = 11,
+    B9_NPARAM = 12        /* row stride, in doubles                                      */
+};
+
+/* ---- star status codes ([RECALL] .phot "stage" column) -------------------------------- */
+enum { B9_STAGE_MSRG = 1, B9_STAGE_WD = 3, B9_STAGE_NSBH = 4, B9_STAGE_BD = 5, B9_STAGE_DNE = 9 };
+
+/* ---- IFMR ids ----------------------------------------------------- */
+enum {
+    B9_IFMR_WEIDEMANN = 0, B9_IFMR_WILLIAMS = 1, B9_IFMR_SALARIS_LIN = 2,
+    B9_IFMR_SALARIS_PW = 3, B9_IFMR_LINEAR = 4, B9_IFMR_QUADRATIC = 5
+};
+
+/* Magnitude assigned to "contributes no flux" ([RECALL] 99.999 sentinel). */
+#define B9_MAG_NOFLUX 99.999
+
+/*
+ * Model pack: the tables a loaded MS/RGB model + WD cooling model + WD atmosphere model +
+ * filter set expose to the hot path ([RECALL] MsRgbModel /
+ * WdCoolingModel / WdAtmosphereModel / Model aggregate).  All axes strictly ascending.
+ *
+ * Isochrone (ifeh, iy, iage) has index  iso = (ifeh * n_y + iy) * n_age + iage,  holds
+ * iso_n_eep[iso] evolutionary points whose EEP ids are iso_first_eep[iso] + 0,1,2,...  and
+ * whose data start at point offset iso_offset[iso] in mass[] / mags[] (mags point-major:
+ * mags[(off + k) * n_filt + f]).  Masses ascend along an isochrone.
+ */
+typedef struct b9_pack {
+    int32_t n_filt;
+    /* MS/RGB grid */
+    int32_t n_feh, n_y, n_age;
+    const double *feh;            /* [n_feh]                                             */
+    const double *y;              /* [n_y]   (n_y == 1: helium is not a grid axis)        */
+    const double *log_age;        /* [n_age]                                             */
+    const int32_t *iso_first_eep; /* [n_feh*n_y*n_age]                                   */
+    const int32_t *iso_n_eep;     /* [n_feh*n_y*n_age]                                   */
+    const int64_t *iso_offset;    /* [n_feh*n_y*n_age]                                   */
+    int64_t n_points;             /* total evolutionary points                            */
+    const double *mass;           /* [n_points]                                          */
+    const double *mags;           /* [n_points*n_filt]                                   */
+    const double *abs_coeff;      /* [n_filt]  A_f / A_V                                  */
+    /* WD cooling model: rectangular [n_wc_carb][n_wc_mass][n_wc_age] (n_wc_mass == 0: no WD models) */
+    int32_t n_wc_carb, n_wc_mass, n_wc_age;
+    const double *wc_carb;        /* [n_wc_carb]                                         */
+    const double *wc_mass;        /* [n_wc_mass] WD mass, Msun                            */
+    const double *wc_log_age;     /* [n_wc_age]  log10 cooling age / yr                   */
+    const double *wc_log_teff;    /* [n_wc_carb*n_wc_mass*n_wc_age]                      */
+    const double *wc_log_radius;  /* same shape, log10 R / cm                             */
+    /* WD atmospheres: [n_at_type][n_at_logg][n_at_teff][n_filt], type 0 = DA, 1 = DB      */
+    int32_t n_at_type, n_at_logg, n_at_teff;
+    const double *at_logg;        /* [n_at_logg]                                         */
+    const double *at_log_teff;    /* [n_at_teff]                                         */
+    const double *at_mags;        /* [n_at_type*n_at_logg*n_at_teff*n_filt]              */
+    /* IFMR + mass limits */
+    int32_t ifmr_id;
+    int32_t reserved0;
+    double m_wd_up;               /* upper ZAMS mass that still makes a WD ([RECALL] M_wd_up) */
+} b9_pack;
+
+/*
+ * Stars: what the photometry file gives per stellar system ([RECALL]
+ * StellarSystem).  obs/sigma are star-major as read from the file: obs[i * n_filt + f].
+ * sigma < 0 (or == 0) marks a filter as unused for that star.
+ */
+typedef struct b9_stars {
+    int32_t n_stars, n_filt;
+    const double *obs;            /* [n_stars*n_filt] observed magnitudes                 */
+    const double *sigma;          /* [n_stars*n_filt] 1-sigma errors, <=0 -> unused       */
+    const double *mass1;          /* [n_stars] primary ZAMS mass, Msun                    */
+    const double *mass_ratio;     /* [n_stars] secondary/primary, 0 -> single             */
+    const double *clust_prior;    /* [n_stars] prior cluster-membership probability       */
+    const int32_t *stage;         /* [n_stars] B9_STAGE_* (used by the marginalised mode) */
+    const int32_t *wd_type;       /* [n_stars] 0 DA, 1 DB; may be NULL (all DA)           */
+    const double *filter_prior_min; /* [n_filt] field-star magnitude range ...           */
+    const double *filter_prior_max; /* [n_filt] ... fsLike = prod_f 1/(max-min)           */
+} b9_stars;
+
+/* Cluster-level priors (SURVEY section 2 "Priors"; scalar per walker, added on device).   */
+typedef struct b9_priors {
+    double mean[B9_NPARAM];       /* Gaussian prior means                                 */
+    double var[B9_NPARAM];        /* variances; <= 0 -> flat (no term)                    */
+    double log_age_min, log_age_max; /* flat prior support in logAge; outside -> -inf      */
+} b9_priors;
+
+/* Evaluation modes */
+enum {
+    B9_MODE_GIVEN_MASS   = 0,  /* BASELINE.json north_star: one interpolation per star at its (mass1, mass_ratio) */
+    B9_MODE_MARGINALISED = 1   /* [RECALL] marg.cpp: integrate each star over primary mass and mass ratio        */
+};
+
+typedef struct b9_options {
+    int32_t mode;             /* B9_MODE_*                                                */
+    int32_t n_pops;           /* 1 (singlePopMcmc) or 2 (multiPopMcmc)                    */
+    int32_t marg_iso_increm;  /* sub-steps per EEP interval in the primary-mass integral  */
+    int32_t marg_n_q;         /* mass-ratio quadrature nodes                              */
+} b9_options;
+
+typedef struct b9_ctx b9_ctx;
+
+/* ---- lifecycle ---------------------------------------------------------------------- */
+int         b9_abi_version(void);
+/* device_id < 0 -> current device.  Fails with B9_ERR_NO_DEVICE when no GPU is present.  */
+int         b9_ctx_create(int device_id, b9_ctx **out);
+void        b9_ctx_destroy(b9_ctx *ctx);
+const char *b9_last_error(const b9_ctx *ctx);   /* ctx may be NULL: last create error      */
+
+/* ---- staging (cold; once per run) ---------------------------------------------------- */
+/* Replaces [RECALL] Model construction: copies the pack's tables to HBM.                   */
+int b9_load_pack(b9_ctx *ctx, const b9_pack *pack);
+/* Replaces [RECALL] reading the .phot into vector<StellarSystem>: SoA + staged to HBM.     */
+int b9_load_stars(b9_ctx *ctx, const b9_stars *stars);
+int b9_set_priors(b9_ctx *ctx, const b9_priors *priors);
+int b9_set_options(b9_ctx *ctx, const b9_options *opt);
+
+/* ---- the hot path -------------------------------------------------------------------- */
+/*
+ * Log-posterior of n_walkers proposed parameter rows ([RECALL]
+ * MpiMcmcApplication::logPostStep).  params: host, [n_walkers * B9_NPARAM].
+ * out_logpost: host, [n_walkers].  out_perstar: host, [n_walkers * n_stars] per-star
+ * log( (1-p) fsLike + p L_i ) in the ORIGINAL star order, or NULL.
+ * Synchronous (returns after the results are on the host).
+ */
+int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers,
+               double *out_logpost, double *out_perstar);
+
+/*
+ * Same, device-resident and asynchronous: d_params / d_logpost (/ d_perstar, nullable) are
+ * DEVICE pointers; launches on `stream` (a hipStream_t passed as void*, NULL = the context's
+ * stream) and returns without synchronising.  This is the entry the walker-parallel driver
+ * uses so that the RCCL all-gather reads log-posteriors straight from HBM.
+ */
+int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers,
+                      double *d_logpost, double *d_perstar, void *stream);
+
+/*
+ * Derive the isochrone for one parameter row ([RECALL]
+ * MsRgbModel::deriveIsochrone; this is all that makeCMD needs).  Outputs, host:
+ * out_mass[cap], out_mags[cap*n_filt] (absolute magnitudes, no modulus/absorption),
+ * *out_first_eep, *out_n (0 when the row is outside the grid).  pop = 0 uses B9_P_Y,
+ * pop = 1 uses B9_P_Y2.
+ */
+int b9_derive_isochrone(b9_ctx *ctx, const double *param_row, int32_t pop, int32_t cap,
+                        double *out_mass, double *out_mags,
+                        int32_t *out_first_eep, int32_t *out_n, double *out_agb_tip);
+
+/* ---- introspection (used by bench/tests; no compute) --------------------------------- */
+int b9_max_eep(const b9_ctx *ctx);           /* longest isochrone in the loaded pack        */
+int b9_device_id(const b9_ctx *ctx);
+/* Algorithmic bytes one star-eval moves in the loaded layout ("bytes per unit"). */
+int b9_bytes_per_star_eval(const b9_ctx *ctx);
+/* Elapsed ms of the dominant (star-likelihood) kernel over the launches since the last call
+ * with reset != 0, measured with HIP events on the launch stream; *n_launches receives the
+ * count.  Timing is only recorded after b9_enable_timing(ctx, 1).                         */
+int b9_enable_timing(b9_ctx *ctx, int on);
+int b9_kernel_time_ms(b9_ctx *ctx, int reset, double *total_ms, int32_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASE9_HIP_H */

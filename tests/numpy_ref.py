@@ -1,0 +1,66 @@
+"""A third, numpy-only statement of the given-mass log-posterior (tests only).
+
+Built on base_amd.synth.forward_mags; shares no code with oracle/b9_oracle.c or the kernels.
+"""
+import numpy as np
+from scipy.special import erfc, logsumexp
+
+from base_amd import abi, synth
+
+MF_MU, MF_SIGMA, LN10 = -1.02, 0.67729, np.log(10.0)
+
+
+def log_mass_norm(m_wd_up):
+    Phi = lambda x: 0.5 * erfc(-x / np.sqrt(2.0))
+    zup, zlow = (np.log10(m_wd_up) - MF_MU) / MF_SIGMA, (-1.0 - MF_MU) / MF_SIGMA
+    return np.log(1.0 / (MF_SIGMA * np.sqrt(2 * np.pi) * (Phi(zup) - Phi(zlow))))
+
+
+def log_prior_mass(m, m_wd_up):
+    z = (np.log10(m) - MF_MU) / MF_SIGMA
+    return log_mass_norm(m_wd_up) - 0.5 * z * z - np.log(m) - np.log(LN10)
+
+
+def log_prior_cluster(priors, par, n_pops):
+    if not (priors.log_age_min <= par[abi.P_LOGAGE] <= priors.log_age_max) or par[abi.P_ABS] < 0:
+        return -np.inf
+    if n_pops == 2 and not (0.0 <= par[abi.P_LAMBDA] <= 1.0):
+        return -np.inf
+    lp = 0.0
+    for k in range(abi.B9_NPARAM):
+        if k == abi.P_LOGAGE or (n_pops < 2 and k in (abi.P_Y2, abi.P_LAMBDA)):
+            continue
+        if priors.var[k] > 0:
+            lp -= 0.5 * (par[k] - priors.mean[k]) ** 2 / priors.var[k]
+    return lp
+
+
+def star_loglike(pack_d, cl, par, pop=0):
+    pred = synth.forward_mags(pack_d, par, cl["mass1"], cl["mass_ratio"], cl["wd_type"], pop=pop)
+    sig = np.asarray(cl["sigma"])
+    used = sig > 0
+    var = np.where(used, sig ** 2, 1.0)
+    term = np.where(used, -0.5 * (np.log(2 * np.pi * var) + (pred - cl["obs"]) ** 2 / var), 0.0)
+    return log_prior_mass(cl["mass1"], pack_d["m_wd_up"]) + term.sum(axis=1)
+
+
+def logpost(pack_d, cl, priors, par, n_pops=1):
+    """(logpost, perstar) for one parameter row; -inf outside the grid."""
+    lp = log_prior_cluster(priors, par, n_pops)
+    n = len(cl["mass1"])
+    if not np.isfinite(lp):
+        return -np.inf, np.full(n, -np.inf)
+    try:
+        ll = star_loglike(pack_d, cl, par, 0)
+        if n_pops == 2:
+            llb = star_loglike(pack_d, cl, par, 1)
+            lam = par[abi.P_LAMBDA]
+            with np.errstate(divide="ignore"):
+                ll = logsumexp(np.stack([np.log(lam) + ll, np.log1p(-lam) + llb]), axis=0)
+    except ValueError:
+        return -np.inf, np.full(n, -np.inf)
+    log_fs = -np.sum(np.log(cl["filter_prior_max"] - cl["filter_prior_min"]))
+    pm = cl["clust_prior"]
+    with np.errstate(divide="ignore"):
+        v = logsumexp(np.stack([np.log1p(-pm) + log_fs, np.log(pm) + ll]), axis=0)
+    return lp + v.sum(), v
