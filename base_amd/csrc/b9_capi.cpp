@@ -173,6 +173,8 @@ int build_stars(b9_ctx *ctx)
     }
     DevStars st{};
     st.n = n; st.n_pad = n_pad;
+    st.n_single = 0;
+    for (int i = 0; i < n; ++i) if (!(h.q[perm[i]] > 0.0)) st.n_single = i + 1;
     int rc;
     if ((rc = upload(ctx, ctx->star_allocs, obs.data(), obs.size(), &st.obs))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, w.data(), w.size(), &st.w))) return rc;
@@ -223,7 +225,7 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
     return B9_OK;
 }
 
-struct Plan { int tiles_per_block, grid_x; bool use_lds; };
+struct Plan { int tiles_per_block, n_groups; bool use_lds; };
 
 Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
 {
@@ -240,7 +242,7 @@ Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
     }
     tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
     p.tiles_per_block = tpb;
-    p.grid_x = (n_tiles + tpb - 1) / tpb;
+    p.n_groups = (n_tiles + tpb - 1) / tpb;
     if (ctx->force_lds == 0) p.use_lds = false;
     else if (ctx->force_lds == 1) p.use_lds = fits;
     else p.use_lds = fits && tpb >= 2 && lds <= 64 * 1024;
@@ -437,7 +439,7 @@ int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, do
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
     const int n_pops = ctx->opt.n_pops;
     const Plan plan = make_plan(ctx, n_walkers, n_pops);
-    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)plan.grid_x * n_walkers, false);
+    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)plan.n_groups * n_walkers, false);
     if (rc) return rc;
 
     HIPCHK(ctx, b9k_derive_iso(ctx->pk, d_params, n_walkers, n_pops, ctx->d_hdr, ctx->d_iso, ctx->iso_stride,
@@ -455,10 +457,10 @@ int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, do
     }
     HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, d_params,
                               n_walkers, n_pops, plan.use_lds, ctx->d_partial, d_perstar, plan.tiles_per_block,
-                              plan.grid_x, stream));
+                              plan.n_groups, stream));
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
-    HIPCHK(ctx, b9k_finalize(ctx->d_hdr, ctx->d_partial, plan.grid_x, n_pops, d_params, ctx->pr, n_walkers,
-                             d_logpost, stream));
+    HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->d_partial,
+                             plan.n_groups, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, stream));
     return B9_OK;
 }
 
@@ -469,7 +471,7 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
     const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
-    int rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)plan.grid_x * n_walkers, out_perstar != nullptr);
+    int rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)plan.n_groups * n_walkers, out_perstar != nullptr);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
     rc = b9_logpost_device(ctx, ctx->d_params, n_walkers, ctx->d_logpost, out_perstar ? ctx->d_perstar : nullptr, ctx->stream);

@@ -34,6 +34,7 @@ struct DevPack {
 // (singles before binaries, each ascending in primary mass), padded to a multiple of 64.
 struct DevStars {
     int n, n_pad;
+    int n_single;                    // stars [0, n_single) are single, [n_single, n) binary
     const double *obs;               // [nfp][n_pad]
     const double *w;                 // [nfp][n_pad]  1/sigma^2, 0 = filter unused
     const double *mass1, *q;         // [n_pad]

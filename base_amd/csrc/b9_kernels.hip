@@ -82,63 +82,91 @@ __device__ __forceinline__ double interp_corner(const DevPack &pk, const Corners
     return lerp(vf[0], vf[1], c.t_feh);
 }
 
+// Largest i in [0, n-2] with ax[i] <= x, found by one wave in one step: lane l loads ax[l]
+// (axes have <= 64 * B9_AXIS_CHUNKS entries) and the bracket is a popcount of the ballot.
+// Equal to the oracle's bracket() for an ascending axis.
+__device__ __forceinline__ int bracket_wave(const double *__restrict__ ax, int n, double x, int lane)
+{
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const bool le = (j < n) && (ax[j] <= x);
+        cnt += __popcll(__ballot(le));
+    }
+    int i = cnt - 1;
+    return i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+}
+
+// grid = (walkers * pops, B9_ISO_SPLIT): every block of a row re-derives the (cheap) header and
+// interpolates its share of the EEPs; block y == 0 publishes the header.
 __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, const double *__restrict__ params,
                                                      int n_pops, IsoHdr *__restrict__ hdr,
                                                      double *__restrict__ iso_data, long long iso_stride,
                                                      int mass_cap)
 {
     const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *par = params + (size_t)w * B9_NPARAM;
     __shared__ IsoHdr sh;
     __shared__ Corners sc;
-    if (threadIdx.x == 0) {
-        IsoHdr h;
-        h.valid = 0; h.first_eep = 0; h.n = 0; h.i_feh = h.i_y = h.i_age = 0;
-        h.agb_tip = 0.0; h.t_feh = h.t_y = h.t_age = 0.0;
-        const double log_age = par[B9_P_LOGAGE], feh = par[B9_P_FEH];
-        const double y = pop ? par[B9_P_Y2] : par[B9_P_Y];
-        bool ok = (log_age >= pk.log_age[0] && log_age <= pk.log_age[pk.n_age - 1]) &&
-                  (feh >= pk.feh[0] && feh <= pk.feh[pk.n_feh - 1]) && pk.n_age >= 2 && pk.n_feh >= 2;
-        if (pk.n_y > 1) ok = ok && (y >= pk.y[0] && y <= pk.y[pk.n_y - 1]);
-        if (ok) {
-            h.i_age = bracket(pk.log_age, pk.n_age, log_age);
-            h.t_age = (log_age - pk.log_age[h.i_age]) / (pk.log_age[h.i_age + 1] - pk.log_age[h.i_age]);
-            h.i_feh = bracket(pk.feh, pk.n_feh, feh);
-            h.t_feh = (feh - pk.feh[h.i_feh]) / (pk.feh[h.i_feh + 1] - pk.feh[h.i_feh]);
-            const int ny = pk.n_y > 1 ? 2 : 1;
-            if (ny == 2) {
-                h.i_y = bracket(pk.y, pk.n_y, y);
-                h.t_y = (y - pk.y[h.i_y]) / (pk.y[h.i_y + 1] - pk.y[h.i_y]);
-            }
-            int lo = -2147483647, hi = 2147483647;
-            for (int df = 0; df < 2; ++df) for (int dy = 0; dy < ny; ++dy) for (int da = 0; da < 2; ++da) {
-                int k = ((h.i_feh + df) * pk.n_y + (h.i_y + dy)) * pk.n_age + h.i_age + da;
-                int f0 = pk.first[k], f1 = f0 + pk.cnt[k];
-                lo = f0 > lo ? f0 : lo;
-                hi = f1 < hi ? f1 : hi;
-            }
-            int n = hi - lo;
-            if (n >= 2 && n <= mass_cap) {
-                for (int df = 0; df < 2; ++df) for (int dy = 0; dy < 2; ++dy) for (int da = 0; da < 2; ++da) {
-                    int dyc = dy < ny ? dy : 0;
-                    int k = ((h.i_feh + df) * pk.n_y + (h.i_y + dyc)) * pk.n_age + h.i_age + da;
-                    sc.off[(df * 2 + dy) * 2 + da] = pk.off[k] + (lo - pk.first[k]);
-                }
-                sc.ny = ny; sc.t_age = h.t_age; sc.t_y = h.t_y; sc.t_feh = h.t_feh;
-                h.first_eep = lo; h.n = n; h.valid = 1;
-                h.agb_tip = interp_corner<true>(pk, sc, n - 1, 0);
-            }
+    __shared__ int s_br[3];
+    const double log_age = par[B9_P_LOGAGE], feh = par[B9_P_FEH];
+    const double y = pop ? par[B9_P_Y2] : par[B9_P_Y];
+    // three waves bracket the three axes concurrently
+    if (wave == 0) { int i = bracket_wave(pk.log_age, pk.n_age, log_age, lane); if (lane == 0) s_br[0] = i; }
+    if (wave == 1) { int i = bracket_wave(pk.feh, pk.n_feh, feh, lane); if (lane == 0) s_br[1] = i; }
+    if (wave == 2) { int i = pk.n_y > 1 ? bracket_wave(pk.y, pk.n_y, y, lane) : 0; if (lane == 0) s_br[2] = i; }
+    __syncthreads();
+    if (wave == 0) {
+        // lanes 0..7: one corner isochrone each
+        const int ny = pk.n_y > 1 ? 2 : 1;
+        const int i_age = s_br[0], i_feh = s_br[1], i_y = s_br[2];
+        const int df = (lane >> 2) & 1, dy = (lane >> 1) & 1, da = lane & 1;
+        const int dyc = dy < ny ? dy : 0;
+        const int k = ((i_feh + df) * pk.n_y + (i_y + dyc)) * pk.n_age + i_age + da;
+        int f0 = -2147483647, f1 = 2147483647;
+        long long off = 0;
+        if (lane < 8) { f0 = pk.first[k]; f1 = f0 + pk.cnt[k]; off = pk.off[k]; }
+        int lo = f0, hi = f1;
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {
+            int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+            lo = l2 > lo ? l2 : lo;
+            hi = h2 < hi ? h2 : hi;
         }
-        sh = h;
-        hdr[wp] = h;
+        if (lane < 8) sc.off[lane] = off + (lo - f0);
+        if (lane == 0) {
+            IsoHdr h;
+            h.valid = 0; h.first_eep = 0; h.n = 0; h.i_feh = i_feh; h.i_y = i_y; h.i_age = i_age;
+            h.agb_tip = 0.0; h.t_feh = h.t_y = h.t_age = 0.0;
+            bool ok = (log_age >= pk.log_age[0] && log_age <= pk.log_age[pk.n_age - 1]) &&
+                      (feh >= pk.feh[0] && feh <= pk.feh[pk.n_feh - 1]) && pk.n_age >= 2 && pk.n_feh >= 2;
+            if (pk.n_y > 1) ok = ok && (y >= pk.y[0] && y <= pk.y[pk.n_y - 1]);
+            const int n = hi - lo;
+            if (ok && n >= 2 && n <= mass_cap) {
+                h.t_age = (log_age - pk.log_age[i_age]) / (pk.log_age[i_age + 1] - pk.log_age[i_age]);
+                h.t_feh = (feh - pk.feh[i_feh]) / (pk.feh[i_feh + 1] - pk.feh[i_feh]);
+                if (ny == 2) h.t_y = (y - pk.y[i_y]) / (pk.y[i_y + 1] - pk.y[i_y]);
+                h.first_eep = lo; h.n = n; h.valid = 1;
+            }
+            sc.ny = ny; sc.t_age = h.t_age; sc.t_y = h.t_y; sc.t_feh = h.t_feh;
+            sh = h;
+        }
     }
     __syncthreads();
-    if (!sh.valid) return;
+    if (!sh.valid) { if (tid == 0 && blockIdx.y == 0) hdr[wp] = sh; return; }
     const int n = sh.n, nfp = pk.nfp;
+    if (tid == 0 && blockIdx.y == 0) {
+        IsoHdr h = sh;
+        h.agb_tip = interp_corner<true>(pk, sc, n - 1, 0);
+        hdr[wp] = h;
+    }
     double *omass = iso_data + (size_t)wp * iso_stride;
     double *omags = omass + mass_cap;
-    for (int e = threadIdx.x; e < n; e += blockDim.x) omass[e] = interp_corner<true>(pk, sc, e, 0);
-    for (int idx = threadIdx.x; idx < n * nfp; idx += blockDim.x) {
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int e0 = blockIdx.y * per, e1 = (e0 + per < n) ? e0 + per : n;
+    for (int e = e0 + tid; e < e1; e += blockDim.x) omass[e] = interp_corner<true>(pk, sc, e, 0);
+    for (int idx = e0 * nfp + tid; idx < e1 * nfp; idx += blockDim.x) {
         int e = idx / nfp, c = idx - e * nfp;
         omags[idx] = (c < pk.nf) ? interp_corner<false>(pk, sc, e, c) : 0.0;
     }
@@ -283,31 +311,32 @@ __device__ __noinline__ void wd_mags(const DevPack &pk, const IsoView<NFP> &iso,
     }
 }
 
-// which branch a ZAMS mass is on ([RECALL] Star::getStatus)
-template <int NFP>
+// which branch a ZAMS mass is on ([RECALL] Star::getStatus).  GENERAL = false is the hot
+// kernel's form: the caller guarantees m <= tip, so only the MS/RGB branch (or "no star") exists.
+template <int NFP, bool GENERAL>
 __device__ __forceinline__ void star_mags(const DevPack &pk, const IsoView<NFP> &iso,
                                           const double *__restrict__ par, double m, int wd_type,
                                           double (&out)[NFP])
 {
-    if (!(m > 0.0))          fill<NFP>(out, B9_MAG_NOFLUX);
-    else if (m <= iso.tip)   msrgb_mags<NFP>(iso, m, out);
-    else if (m <= pk.m_wd_up) wd_mags<NFP>(pk, iso, par, m, wd_type, out);
-    else                     fill<NFP>(out, B9_MAG_NOFLUX);
+    if (!(m > 0.0)) { fill<NFP>(out, B9_MAG_NOFLUX); return; }
+    if (!GENERAL || m <= iso.tip) { msrgb_mags<NFP>(iso, m, out); return; }
+    if (m <= pk.m_wd_up) wd_mags<NFP>(pk, iso, par, m, wd_type, out);
+    else fill<NFP>(out, B9_MAG_NOFLUX);
 }
 
 // SURVEY 8a rows a5 + a6: combined magnitudes -> sum_f w_f (pred_f - obs_f)^2.
 // Flux addition is done as  m1 - 2.5 log10(1 + 10^(-0.4 (m2 - m1)))  : one exp and one log1p
 // per filter instead of two pow and a log10, and no cancellation.
-template <int NFP>
+template <int NFP, bool GENERAL>
 __device__ __forceinline__ double chi2_system(const DevPack &pk, const IsoView<NFP> &iso,
                                               const double *__restrict__ par, double m1, double q,
-                                              int wd_type, const double (&obs)[NFP], const double (&w)[NFP])
+                                              int wd_type, const DevStars &st, int i)
 {
     double p1[NFP];
-    star_mags<NFP>(pk, iso, par, m1, wd_type, p1);
+    star_mags<NFP, GENERAL>(pk, iso, par, m1, wd_type, p1);
     if (q > 0.0) {
         double p2[NFP];
-        star_mags<NFP>(pk, iso, par, q * m1, wd_type, p2);
+        star_mags<NFP, GENERAL>(pk, iso, par, q * m1, wd_type, p2);
 #pragma unroll
         for (int f = 0; f < NFP; ++f)
             p1[f] -= (2.5 / LN10) * log1p(exp((-0.4 * LN10) * (p2[f] - p1[f])));
@@ -319,30 +348,36 @@ __device__ __forceinline__ double chi2_system(const DevPack &pk, const IsoView<N
     for (int f = 0; f < NFP; ++f) {
         double pred = p1[f] + (mod + pk.abs_m1[f] * av);
         finite = finite && isfinite(pred);
-        double d = pred - obs[f];
-        chi2 = fma(w[f] * d, d, chi2);
+        double d = pred - st.obs[(size_t)f * st.n_pad + i];
+        chi2 = fma(st.w[(size_t)f * st.n_pad + i] * d, d, chi2);
     }
     return finite ? chi2 : __builtin_inf();
 }
 
-// ------------------------------------------------------------------------------------------
-// k_star_like  (given-mass mode)
-// ------------------------------------------------------------------------------------------
-template <int NFP, int NPOPS, bool USE_LDS>
-__global__ __launch_bounds__(256) void k_star_like(DevPack pk, DevStars st,
-                                                    const IsoHdr *__restrict__ hdr,
-                                                    const double *__restrict__ iso_data,
-                                                    long long iso_stride, int mass_cap,
-                                                    const double *__restrict__ params,
-                                                    double *__restrict__ partial,
-                                                    double *__restrict__ perstar, int tiles_per_block)
+// one star, all populations, field-star mixture: log( (1-p) fsLike + p L_i )
+template <int NFP, int NPOPS, bool GENERAL>
+__device__ __forceinline__ double star_value(const DevPack &pk, const IsoView<NFP> (&iso)[NPOPS],
+                                             const double *__restrict__ par, const DevStars &st, int i,
+                                             double log_lam, double log_1ml)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];   // [0..7] reduction scratch, then isochrone(s)
-    const int w = blockIdx.y, tid = threadIdx.x;
-    const double *par = params + (size_t)w * B9_NPARAM;
+    const double m1 = st.mass1[i], q = st.q[i], c0 = st.c0[i], la = st.la[i];
+    const int wd_type = st.flags[i] & 1;
+    double ll[NPOPS];
+#pragma unroll
+    for (int k = 0; k < NPOPS; ++k)
+        ll[k] = c0 - 0.5 * chi2_system<NFP, GENERAL>(pk, iso[k], par, m1, q, wd_type, st, i);
+    double l = ll[0];
+    if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[NPOPS - 1]);
+    return logaddexp(la, l);
+}
 
-    IsoView<NFP> iso[NPOPS];
+template <int NFP, int NPOPS>
+__device__ __forceinline__ bool load_iso_views(const IsoHdr *__restrict__ hdr, const double *__restrict__ iso_data,
+                                               long long iso_stride, int mass_cap, int w,
+                                               IsoView<NFP> (&iso)[NPOPS], double &tip_min)
+{
     bool valid = true;
+    tip_min = __builtin_inf();
 #pragma unroll
     for (int k = 0; k < NPOPS; ++k) {
         const IsoHdr h = hdr[w * NPOPS + k];
@@ -351,10 +386,45 @@ __global__ __launch_bounds__(256) void k_star_like(DevPack pk, DevStars st,
         iso[k].i_feh = h.i_feh; iso[k].i_y = h.i_y; iso[k].t_feh = h.t_feh; iso[k].t_y = h.t_y;
         const double *g = iso_data + (size_t)(w * NPOPS + k) * iso_stride;
         iso[k].mass = g; iso[k].mags = g + mass_cap;
+        tip_min = h.agb_tip < tip_min ? h.agb_tip : tip_min;
     }
-    const int tile0 = blockIdx.x * tiles_per_block;
+    return valid;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_star_like  (given-mass mode): the hot kernel.  One lane per star, MS/RGB branch only --
+// stars heavier than the walker's AGB tip (WD / NS-BH branch; two contiguous ranges because
+// stars are sorted by mass) are left to k_finalize so that pow/log10 and the WD tables do not
+// cost this kernel registers.
+//
+// Workgroup -> (star tile, walker) map is XCD-aware: workgroups are dealt round-robin over the 8
+// XCDs, so linear id L runs on XCD L % 8.  All walkers of one star tile are given ids with the
+// same L % 8 and consecutive L / 8: the tile's star data is fetched from HBM once into that
+// XCD's L2 and re-read from L2 by the other walkers.  (Placement affects speed only.)
+// ------------------------------------------------------------------------------------------
+template <int NFP, int NPOPS, bool USE_LDS>
+__global__ __launch_bounds__(256) void k_star_like(DevPack pk, DevStars st,
+                                                    const IsoHdr *__restrict__ hdr,
+                                                    const double *__restrict__ iso_data,
+                                                    long long iso_stride, int mass_cap,
+                                                    const double *__restrict__ params, int n_walkers,
+                                                    double *__restrict__ partial, int n_groups,
+                                                    double *__restrict__ perstar, int tiles_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // [0..7] reduction scratch, then isochrone(s)
+    const int tid = threadIdx.x;
+    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    const int w = s % n_walkers;
+    const int group = (s / n_walkers) * 8 + xcd;        // tile group = tiles_per_block consecutive tiles
+    if (group >= n_groups) return;
+    const double *par = params + (size_t)w * B9_NPARAM;
+
+    IsoView<NFP> iso[NPOPS];
+    double tip_min;
+    const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
+    const int tile0 = group * tiles_per_block;
     if (!valid) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
-        if (tid == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = 0.0;
+        if (tid == 0) partial[(size_t)w * n_groups + group] = 0.0;
         if (perstar)
             for (int t = 0; t < tiles_per_block; ++t) {
                 int i = (tile0 + t) * 256 + tid;
@@ -387,35 +457,25 @@ __global__ __launch_bounds__(256) void k_star_like(DevPack pk, DevStars st,
         const int i = (tile0 + t) * 256 + tid;
         if ((tile0 + t) * 256 >= st.n) break;
         double v = 0.0;
-        if (i < st.n) {
-            double obs[NFP], wgt[NFP];
-#pragma unroll
-            for (int f = 0; f < NFP; ++f) {
-                obs[f] = st.obs[(size_t)f * st.n_pad + i];
-                wgt[f] = st.w[(size_t)f * st.n_pad + i];
-            }
-            const double m1 = st.mass1[i], q = st.q[i], c0 = st.c0[i], la = st.la[i];
-            const int wd_type = st.flags[i] & 1;
-            double ll[NPOPS];
-#pragma unroll
-            for (int k = 0; k < NPOPS; ++k)
-                ll[k] = c0 - 0.5 * chi2_system<NFP>(pk, iso[k], par, m1, q, wd_type, obs, wgt);
-            double l = ll[0];
-            if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[NPOPS - 1]);
-            v = logaddexp(la, l);
+        if (i < st.n && !(st.mass1[i] > tip_min)) {
+            v = star_value<NFP, NPOPS, false>(pk, iso, par, st, i, log_lam, log_1ml);
             if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
         }
         acc += v;
     }
     // wave shuffle reduction, then fixed-order LDS sum of the 4 wave partials
-    double s = wave_sum(acc);
-    if ((tid & 63) == 0) smem[tid >> 6] = s;
+    double sum = wave_sum(acc);
+    if ((tid & 63) == 0) smem[tid >> 6] = sum;
     __syncthreads();
-    if (tid == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    if (tid == 0) partial[(size_t)w * n_groups + group] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_finalize: per walker, fixed-order sum of the workgroup partials + cluster prior
+// k_finalize: one workgroup per walker.
+//   (1) the stars k_star_like skipped -- primary heavier than the AGB tip (SURVEY 8a row a7:
+//       IFMR -> WD cooling -> WD atmosphere, or NS/BH) -- through the general per-star code;
+//   (2) fixed-order sum of the hot kernel's partials (row a8);
+//   (3) cluster prior; -inf for a walker outside the grid.
 // ------------------------------------------------------------------------------------------
 __device__ inline double log_prior_cluster(const DevPriors &pr, const double *__restrict__ par, int n_pops)
 {
@@ -434,20 +494,65 @@ __device__ inline double log_prior_cluster(const DevPriors &pr, const double *__
     return lp;
 }
 
-__global__ __launch_bounds__(64) void k_finalize(const IsoHdr *__restrict__ hdr,
-                                                  const double *__restrict__ partial, int n_partial,
-                                                  int n_pops, const double *__restrict__ params,
-                                                  DevPriors pr, double *__restrict__ logpost)
+// first index in [lo, hi) of the ascending run a[] with a[i] > x
+__device__ __forceinline__ int upper_bound_idx(const double *__restrict__ a, int lo, int hi, double x)
 {
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] > x) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+#define B9_FIN_THREADS 512
+template <int NFP, int NPOPS>
+__global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStars st,
+                                                              const IsoHdr *__restrict__ hdr,
+                                                              const double *__restrict__ iso_data,
+                                                              long long iso_stride, int mass_cap,
+                                                              const double *__restrict__ partial, int n_partial,
+                                                              const double *__restrict__ params, DevPriors pr,
+                                                              double *__restrict__ logpost,
+                                                              double *__restrict__ perstar)
+{
+    __shared__ double s_red[B9_FIN_THREADS / 64];
     const int w = blockIdx.x, tid = threadIdx.x;
-    double s = 0.0;
-    for (int j = tid; j < n_partial; j += 64) s += partial[(size_t)w * n_partial + j];
-    s = wave_sum(s);
+    const double *par = params + (size_t)w * B9_NPARAM;
+    IsoView<NFP> iso[NPOPS];
+    double tip_min;
+    const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
+    const double lp = log_prior_cluster(pr, par, NPOPS);
+    if (!valid || lp == NEG_INF) {
+        if (tid == 0) logpost[w] = NEG_INF;
+        // a finite-grid walker whose prior is -inf still has per-star values from k_star_like;
+        // the oracle reports -inf for them as well
+        if (perstar && valid)
+            for (int i = tid; i < st.n; i += B9_FIN_THREADS) perstar[(size_t)w * st.n + i] = NEG_INF;
+        return;
+    }
+    // (1) heavy stars: [i_s, n_single) and [i_b, n)
+    const int i_s = upper_bound_idx(st.mass1, 0, st.n_single, tip_min);
+    const int i_b = upper_bound_idx(st.mass1, st.n_single, st.n, tip_min);
+    const int n_s = st.n_single - i_s, count = n_s + (st.n - i_b);
+    const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+    double acc = 0.0;
+    for (int j = tid; j < count; j += B9_FIN_THREADS) {
+        const int i = j < n_s ? i_s + j : i_b + (j - n_s);
+        const double v = star_value<NFP, NPOPS, true>(pk, iso, par, st, i, log_lam, log_1ml);
+        if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
+        acc += v;
+    }
+    // (2) partials of the hot kernel, strided over the block in a fixed order
+    for (int j = tid; j < n_partial; j += B9_FIN_THREADS) acc += partial[(size_t)w * n_partial + j];
+    double sum = wave_sum(acc);
+    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+    __syncthreads();
     if (tid == 0) {
-        bool valid = true;
-        for (int k = 0; k < n_pops; ++k) valid = valid && hdr[w * n_pops + k].valid;
-        const double lp = log_prior_cluster(pr, params + (size_t)w * B9_NPARAM, n_pops);
-        logpost[w] = (valid && lp != NEG_INF) ? lp + s : NEG_INF;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < B9_FIN_THREADS / 64; ++k) t += s_red[k];
+        logpost[w] = lp + t;   // (3)
     }
 }
 
@@ -458,7 +563,8 @@ hipError_t b9k_derive_iso(const DevPack &pk, const double *d_params, int n_walke
                           IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap,
                           hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_derive_iso, dim3(n_walkers * n_pops), dim3(256), 0, stream,
+    const int split = pk.max_eep >= 128 ? 4 : 1;
+    hipLaunchKernelGGL(k_derive_iso, dim3(n_walkers * n_pops, split), dim3(256), 0, stream,
                        pk, d_params, n_pops, hdr, iso_data, iso_stride, mass_cap);
     return hipGetLastError();
 }
@@ -473,7 +579,7 @@ template <int NFP, int NPOPS, bool USE_LDS>
 static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                                    const double *iso_data, long long iso_stride, int mass_cap,
                                    const double *d_params, int n_walkers, double *partial,
-                                   double *perstar, int tiles_per_block, int grid_x, hipStream_t stream)
+                                   double *perstar, int tiles_per_block, int n_groups, hipStream_t stream)
 {
     size_t lds = USE_LDS ? b9k_star_like_lds_bytes(NFP, NPOPS, pk.max_eep) : 8 * sizeof(double);
     auto kern = k_star_like<NFP, NPOPS, USE_LDS>;
@@ -482,39 +588,57 @@ static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid_x, n_walkers), dim3(256), lds, stream, pk, st, hdr, iso_data,
-                       iso_stride, mass_cap, d_params, partial, perstar, tiles_per_block);
+    const int blocks = 8 * ((n_groups + 7) / 8) * n_walkers;     // padded so every XCD sees whole walker sets
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, pk, st, hdr, iso_data,
+                       iso_stride, mass_cap, d_params, n_walkers, partial, n_groups, perstar, tiles_per_block);
     return hipGetLastError();
 }
+
+template <int NFP, int NPOPS>
+static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
+                                  const double *iso_data, long long iso_stride, int mass_cap,
+                                  const double *partial, int n_partial, const double *d_params,
+                                  const DevPriors &pr, int n_walkers, double *d_logpost, double *perstar,
+                                  hipStream_t stream)
+{
+    hipLaunchKernelGGL((k_finalize<NFP, NPOPS>), dim3(n_walkers), dim3(B9_FIN_THREADS), 0, stream, pk, st, hdr,
+                       iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, d_logpost, perstar);
+    return hipGetLastError();
+}
+
+#define B9_SWITCH_NFP(CALL2, CALL1)                 \
+    switch (pk.nfp) {                               \
+    case 4:  if (n_pops == 2) { return CALL2(4); } else { return CALL1(4); }   \
+    case 8:  if (n_pops == 2) { return CALL2(8); } else { return CALL1(8); }   \
+    case 16: if (n_pops == 2) { return CALL2(16); } else { return CALL1(16); } \
+    default: return hipErrorInvalidValue;           \
+    }
 
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
                          const double *d_params, int n_walkers, int n_pops, bool use_lds,
-                         double *partial, double *perstar, int tiles_per_block, int grid_x,
+                         double *partial, double *perstar, int tiles_per_block, int n_groups,
                          hipStream_t stream)
 {
-#define B9_DISPATCH(NFP)                                                                              \
-    if (n_pops == 2) {                                                                                \
-        return use_lds ? launch_star_like<NFP, 2, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, grid_x, stream) \
-                       : launch_star_like<NFP, 2, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, grid_x, stream); \
-    } else {                                                                                          \
-        return use_lds ? launch_star_like<NFP, 1, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, grid_x, stream) \
-                       : launch_star_like<NFP, 1, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, grid_x, stream); \
-    }
-    switch (pk.nfp) {
-    case 4:  B9_DISPATCH(4)
-    case 8:  B9_DISPATCH(8)
-    case 16: B9_DISPATCH(16)
-    default: return hipErrorInvalidValue;
-    }
-#undef B9_DISPATCH
+#define SL_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, n_groups, stream
+#define SL2(NFP) (use_lds ? launch_star_like<NFP, 2, true>(SL_ARGS) : launch_star_like<NFP, 2, false>(SL_ARGS))
+#define SL1(NFP) (use_lds ? launch_star_like<NFP, 1, true>(SL_ARGS) : launch_star_like<NFP, 1, false>(SL_ARGS))
+    B9_SWITCH_NFP(SL2, SL1)
+#undef SL1
+#undef SL2
+#undef SL_ARGS
 }
 
-hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial, int n_pops,
+hipError_t b9k_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
+                        long long iso_stride, int mass_cap, const double *partial, int n_partial, int n_pops,
                         const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        hipStream_t stream)
+                        double *perstar, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(n_walkers), dim3(64), 0, stream, hdr, partial, n_partial,
-                       n_pops, d_params, pr, d_logpost);
-    return hipGetLastError();
+#define FN_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, n_walkers, d_logpost, perstar, stream
+#define FN2(NFP) launch_finalize<NFP, 2>(FN_ARGS)
+#define FN1(NFP) launch_finalize<NFP, 1>(FN_ARGS)
+    B9_SWITCH_NFP(FN2, FN1)
+#undef FN1
+#undef FN2
+#undef FN_ARGS
 }

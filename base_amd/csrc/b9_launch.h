@@ -11,9 +11,10 @@ size_t b9k_star_like_lds_bytes(int nfp, int n_pops, int max_eep);
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
                          const double *d_params, int n_walkers, int n_pops, bool use_lds,
-                         double *partial, double *perstar, int tiles_per_block, int grid_x,
+                         double *partial, double *perstar, int tiles_per_block, int n_groups,
                          hipStream_t stream);
 
-hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial, int n_pops,
+hipError_t b9k_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
+                        long long iso_stride, int mass_cap, const double *partial, int n_partial, int n_pops,
                         const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        hipStream_t stream);
+                        double *perstar, hipStream_t stream);

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- star-likelihood evals/sec of the MI355X-native BASE-9 log-posterior path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric: "star-likelihood evals/sec ... on synthetic 50k-star x 8-filter
+clusters at 1 GPU, with 1/2/4/8-GPU walker-parallel throughput"; configs[2] sharded 8 ways):
+50 000 stars x 8 filters, PARSEC-shaped synthetic pack, 8 walkers per GPU (weak scaling: 64
+walkers at 8 GPUs).  One "step" is one adaptive-Metropolis step of every walker: propose ->
+log-posterior of the rank's walkers on its GPU (three HIP launches behind the C ABI) -> one
+RCCL all-gather of the log-posteriors -> accept/reject + adaptation.  Star data and model
+tables are resident in HBM before the timed region starts.
+
+value     = n_stars x total walkers x K / max-over-ranks wall time   (whole job, all GPUs)
+roofline  = the dominant kernel (k_star_like): algorithmic bytes per launch / its mean launch
+            duration, measured with HIP events on the launch stream inside this run
+cpu_baseline = the CPU oracle ("port"; the reference itself is not mounted)
+            timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+N_STARS, N_FILT, WALKERS_PER_GPU = 50000, 8, 8
+
+
+def cpu_baseline(pack_d, cl, truth, budget_s: float = 12.0):
+    """Time the CPU oracle on a bounded sample of the same workload (rank 0 only)."""
+    import oracle
+    from base_amd import abi, synth
+    try:
+        oracle.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
+    priors, options = synth.default_priors(pack_d, truth), abi.make_options()
+    orc = oracle.Oracle(pack, stars, priors, options, native=native)
+    params = synth.walker_params(truth, WALKERS_PER_GPU)
+    orc.logpost(params[:1])                       # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.logpost(params)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or reps >= 200:
+            break
+    evals = reps * N_STARS * WALKERS_PER_GPU
+    return {"value": evals / dt, "unit": "star-likelihood evals/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x logpost of {WALKERS_PER_GPU} walkers x {N_STARS} stars x {N_FILT} filters "
+                      f"({dt:.1f} s, oracle/b9_oracle.c -O3 -march=native, 1 thread; "
+                      f"BASE-9 itself is not mounted: build's CPU oracle, parity unpinned)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from base_amd import abi, engine, mcmc, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic inputs (identical on every rank: fixed seeds) -----------------------------
+    pack_d = synth.make_pack("parsec", N_FILT)
+    truth = synth.default_params(pack_d)
+    cl = synth.make_cluster(pack_d, N_STARS, seed=9003, truth=truth)
+    pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
+    priors, options = synth.default_priors(pack_d, truth), abi.make_options()
+    eng = engine.Engine(pack, stars, priors, options, device=local_rank)
+    n_walkers = WALKERS_PER_GPU * world
+    start = synth.walker_params(truth, n_walkers, seed=42)
+    sampler = mcmc.make_device_sampler(eng, start, rank, world, seed=2024)
+    sampler.initialise()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sampler.step()
+    eng.enable_timing(True)
+    eng.kernel_time_ms(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sampler.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    k_ms, k_n = eng.kernel_time_ms(reset=True)
+    eng.enable_timing(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        evals = float(N_STARS) * n_walkers * args.steps
+        bytes_eval = eng.bytes_per_star_eval()
+        bytes_launch = float(bytes_eval) * N_STARS * WALKERS_PER_GPU
+        k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
+        achieved = bytes_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        out = {
+            "metric": "star-likelihood evals/sec", "value": evals / dt, "unit": "star-likelihood evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "mcmc_steps_per_s": args.steps / dt,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3: 50k-star x 8-filter synthetic cluster, PARSEC-shaped synthetic pack "
+                                   "(10 FeH x 60 ages x 400 EEPs), given-mass mode, 8 walkers per GPU",
+                       "n_stars": N_STARS, "n_filters": N_FILT, "walkers_per_gpu": WALKERS_PER_GPU,
+                       "walkers_total": n_walkers, "parallelism": f"walkers{world}",
+                       "collective": "all_gather(logpost) per step" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_star_like", "launches": k_n, "avg_launch_us": 1e6 * k_avg_s,
+                         "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_star_eval": bytes_eval},
+            "accept_rate": sampler.ens.accepted / float(n_walkers * (args.steps + args.warmup)),
+            "parity": "vs this repo's CPU oracle (BASE-9 parity unpinned: reference source not mounted)",
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pack_d, cl, truth)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
