@@ -162,7 +162,7 @@ ABI_SYMBOLS = [
 
 def load_hip_library(path: Optional[str] = None) -> C.CDLL:
     """dlopen libbase9hip.so and declare its prototypes.  Raises if it is not built."""
-    path = path or HIP_LIB_PATH
+    path = path or os.environ.get("B9_HIP_LIB") or HIP_LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

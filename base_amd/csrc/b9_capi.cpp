@@ -59,7 +59,6 @@ struct b9_ctx {
 
     // launch plan
     int tiles_per_block = 0;   // 0 = auto
-    int force_lds = -1;        // -1 auto, 0 never, 1 always (when it fits)
 
     // timing of the dominant kernel
     bool timing = false;
@@ -129,29 +128,54 @@ double log_prior_mass(double lmn, double m)
     return lmn - 0.5 * z * z - std::log(m) - std::log(ln10);
 }
 
-// (Re)build the device star arrays: sort (singles first, ascending primary mass), SoA, pad.
+// (Re)build the device star arrays.  Layout (DESIGN.md "Data layout"): singles and binaries are
+// each sorted by primary mass and cut into 64-star chunks (one wave each, so a wave never mixes
+// the two kinds and neighbouring lanes search neighbouring isochrone rows); the chunks of the two
+// kinds are then interleaved in proportion, so every 256-star workgroup carries the same mix of
+// cheap (single) and expensive (binary) waves.  Unused slots of a partial chunk and the tail
+// padding hold mass1 = +inf (skipped by the hot kernel) and perm = -1.
 int build_stars(b9_ctx *ctx)
 {
     const HostStars &h = ctx->hs;
     const int n = h.n, nf = h.nf, nfp = ctx->pk.nfp;
     if (nf != ctx->pk.nf) return fail(ctx, B9_ERR_INVALID, "stars and pack disagree on n_filt");
     free_all(ctx->star_allocs);
-    const int n_pad = std::max(64, (n + 63) / 64 * 64);
-    std::vector<int> perm(n);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         bool ba = h.q[a] > 0.0, bb = h.q[b] > 0.0;
         if (ba != bb) return !ba;
         return h.mass1[a] < h.mass1[b];
     });
+    int n_single = 0;
+    for (int i = 0; i < n; ++i) if (!(h.q[order[i]] > 0.0)) n_single = i + 1;
+    const int cs = (n_single + 63) / 64, cb = (n - n_single + 63) / 64, ct = cs + cb;
+    const int n_pad = std::max(256, (ct * 64 + 255) / 256 * 256);
+    // slot -> star (or -1): proportional interleave of the two chunk kinds
+    std::vector<int> slot(n_pad, -1);
+    {
+        int us = 0, ub = 0;
+        for (int c = 0; c < ct; ++c) {
+            // binary chunk when the binaries are behind their share (expensive chunks lead)
+            bool take_b = (ub < cb) && ((long long)(ub) * ct <= (long long)c * cb || us >= cs);
+            if (take_b) {
+                for (int j = 0; j < 64; ++j) { int k = n_single + ub * 64 + j; if (k < n) slot[c * 64 + j] = order[k]; }
+                ++ub;
+            } else {
+                for (int j = 0; j < 64; ++j) { int k = us * 64 + j; if (k < n_single) slot[c * 64 + j] = order[k]; }
+                ++us;
+            }
+        }
+    }
     double log_fs = 0.0;
     for (int f = 0; f < nf; ++f) log_fs -= std::log(h.fmax[f] - h.fmin[f]);
 
     std::vector<double> obs((size_t)nfp * n_pad, 0.0), w((size_t)nfp * n_pad, 0.0);
-    std::vector<double> mass1(n_pad, 0.0), q(n_pad, 0.0), c0(n_pad, 0.0), c0m(n_pad, 0.0), la(n_pad, -INFINITY);
-    std::vector<int> flags(n_pad, 0), permp(n_pad, 0);
-    for (int i = 0; i < n; ++i) {
-        const int s = perm[i];
+    std::vector<double> mass1(n_pad, INFINITY), q(n_pad, 0.0), c0(n_pad, 0.0), c0m(n_pad, 0.0), la(n_pad, -INFINITY);
+    std::vector<int> flags(n_pad, 0), permp(n_pad, -1);
+    for (int i = 0; i < n_pad; ++i) {
+        const int s = slot[i];
+        if (s < 0) continue;
         double g = 0.0;
         for (int f = 0; f < nf; ++f) {
             double sig = h.sigma[(size_t)s * nf + f];
@@ -171,10 +195,17 @@ int build_stars(b9_ctx *ctx)
         flags[i] = (h.wd_type[s] > 0 ? 1 : 0) | (h.stage[s] << 8);
         permp[i] = s;
     }
+    // slots in descending order of primary mass: k_finalize takes the leading run of stars
+    // heavier than a walker's AGB tip (the WD / NS-BH branch) from this list
+    std::vector<int> heavy_slot;
+    heavy_slot.reserve(n);
+    for (int i = 0; i < n_pad; ++i) if (slot[i] >= 0) heavy_slot.push_back(i);
+    std::stable_sort(heavy_slot.begin(), heavy_slot.end(), [&](int a, int b) { return mass1[a] > mass1[b]; });
+    std::vector<double> heavy_mass(std::max(n, 1), 0.0);
+    for (int k = 0; k < n; ++k) heavy_mass[k] = mass1[heavy_slot[k]];
+
     DevStars st{};
     st.n = n; st.n_pad = n_pad;
-    st.n_single = 0;
-    for (int i = 0; i < n; ++i) if (!(h.q[perm[i]] > 0.0)) st.n_single = i + 1;
     int rc;
     if ((rc = upload(ctx, ctx->star_allocs, obs.data(), obs.size(), &st.obs))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, w.data(), w.size(), &st.w))) return rc;
@@ -185,6 +216,8 @@ int build_stars(b9_ctx *ctx)
     if ((rc = upload(ctx, ctx->star_allocs, la.data(), la.size(), &st.la))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, flags.data(), flags.size(), &st.flags))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, permp.data(), permp.size(), &st.perm))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, heavy_mass.data(), heavy_mass.size(), &st.heavy_mass))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, heavy_slot.data(), heavy_slot.size(), &st.heavy_slot))) return rc;
     ctx->st = st;
     ctx->stars_dirty = false;
     return B9_OK;
@@ -225,27 +258,23 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
     return B9_OK;
 }
 
-struct Plan { int tiles_per_block, n_groups; bool use_lds; };
+struct Plan { int tiles_per_block, n_groups; };
 
 Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
 {
     Plan p;
-    const int n_tiles = (ctx->st.n + 255) / 256;
-    size_t lds = b9k_star_like_lds_bytes(ctx->pk.nfp, n_pops, ctx->pk.max_eep);
-    const bool fits = lds <= 160 * 1024;
+    const int n_tiles = ctx->st.n_pad / 256;
+    (void)n_pops;
     int tpb = ctx->tiles_per_block;
     if (tpb <= 0) {
-        // enough workgroups to cover the 256 CUs a few times over, but amortise the per-block
-        // isochrone staging once there is more work than that
+        // one tile per workgroup until there are more workgroups than ~8 per CU; beyond that
+        // amortise the per-workgroup mass-column staging over several tiles
         long long blocks1 = (long long)n_tiles * n_walkers;
-        tpb = (int)std::max<long long>(1, std::min<long long>(8, blocks1 / 2048));
+        tpb = (int)std::max<long long>(1, std::min<long long>(8, blocks1 / 4096));
     }
     tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
     p.tiles_per_block = tpb;
     p.n_groups = (n_tiles + tpb - 1) / tpb;
-    if (ctx->force_lds == 0) p.use_lds = false;
-    else if (ctx->force_lds == 1) p.use_lds = fits;
-    else p.use_lds = fits && tpb >= 2 && lds <= 64 * 1024;
     return p;
 }
 
@@ -279,7 +308,6 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     for (int k = 0; k < 12; ++k) { ctx->pr.mean[k] = 0.0; ctx->pr.var[k] = 0.0; }
     ctx->pr.log_age_min = -INFINITY; ctx->pr.log_age_max = INFINITY;
     if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
-    if (const char *s = getenv("B9_FORCE_LDS")) ctx->force_lds = atoi(s);
     *out = ctx;
     return B9_OK;
 }
@@ -456,7 +484,7 @@ int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, do
         HIPCHK(ctx, hipEventRecord(ctx->ev_start[slot], stream));
     }
     HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, d_params,
-                              n_walkers, n_pops, plan.use_lds, ctx->d_partial, d_perstar, plan.tiles_per_block,
+                              n_walkers, n_pops, ctx->d_partial, d_perstar, plan.tiles_per_block,
                               plan.n_groups, stream));
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
     HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->d_partial,

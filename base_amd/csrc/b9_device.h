@@ -30,11 +30,11 @@ struct DevPack {
     double log_mass_norm;
 };
 
-// Stars, device view: structure of arrays in the *sorted* order chosen at load time
-// (singles before binaries, each ascending in primary mass), padded to a multiple of 64.
+// Stars, device view: structure of arrays in the slot order chosen at load time (64-star
+// chunks of mass-sorted singles and of mass-sorted binaries, interleaved; see build_stars),
+// padded to whole 256-star tiles.  Empty slots have mass1 = +inf and perm = -1.
 struct DevStars {
-    int n, n_pad;
-    int n_single;                    // stars [0, n_single) are single, [n_single, n) binary
+    int n, n_pad;                    // real stars / slots
     const double *obs;               // [nfp][n_pad]
     const double *w;                 // [nfp][n_pad]  1/sigma^2, 0 = filter unused
     const double *mass1, *q;         // [n_pad]
@@ -42,7 +42,9 @@ struct DevStars {
     const double *c0m;               // [n_pad] log p + sum_f -0.5 log(2 pi sigma_f^2)   (marginalised mode)
     const double *la;                // [n_pad] log((1-p) fsLike)  (-inf when p == 1)
     const int *flags;                // [n_pad] bit0 = DB atmosphere, bits 8.. = stage
-    const int *perm;                 // [n_pad] original index of sorted star i
+    const int *perm;                 // [n_pad] original index of the star in slot i, -1 = empty
+    const double *heavy_mass;        // [n] primary masses in descending order ...
+    const int *heavy_slot;           // [n] ... and the slots that hold them
 };
 
 // Header of one derived isochrone (one per walker x population).

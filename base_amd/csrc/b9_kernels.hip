@@ -2,12 +2,13 @@
 //
 //   k_derive_iso   SURVEY 8a row a3   one workgroup per (walker, population): grid bracket,
 //                                     EEP-range intersection, EEP-wise tri-linear interpolation
-//   k_star_like    rows a4-a7, a9     one LANE per star (given-mass mode): LDS- or L1-resident
-//                                     binary search + linear interpolation, binary flux
-//                                     combination, WD branch, Gaussian log-likelihood,
+//   k_star_like    rows a4-a6, a9     one LANE per star (given-mass mode): binary search in the
+//                                     LDS-staged mass column + linear interpolation, binary flux
+//                                     combination, Gaussian log-likelihood,
 //                                     population and field-star mixtures; wave-shuffle +
 //                                     LDS block reduction to one partial per workgroup
-//   k_finalize     row a8             fixed-order sum of the partials + cluster prior
+//   k_finalize     rows a7, a8        WD-branch stars (IFMR, cooling, atmospheres), fixed-order sum
+//                                     of the partials + cluster prior
 //
 // The reference source is not mounted (/root/reference/README.md:4), so none of this can
 // cite a reference file:line; DESIGN.md "Math" is the normative restatement and
@@ -26,6 +27,24 @@
 #define LN10 2.302585092994045684
 #define NEG_INF (-__builtin_inf())
 
+// Diagnostic build only (-DB9_STAMPS): per-wave s_memtime stamps of the hot kernel's phases,
+// written to a buffer of their own that no kernel reads.  Never defined in the shipped library.
+#ifdef B9_STAMPS
+#define B9_NSTAMP 12
+__device__ unsigned long long g_stamps[8192 * B9_NSTAMP];
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        const unsigned wv_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                  \
+        if ((threadIdx.x & 63) == 0 && wv_ < 8192) g_stamps[wv_ * B9_NSTAMP + (k)] = t_;           \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ double lerp(double a, double b, double t) { return fma(t, b - a, a); }
 
 // largest i in [0, n-2] with ax[i] <= x (clamped); identical to the oracle's bracket()
@@ -40,12 +59,49 @@ __device__ __forceinline__ int bracket(const double *__restrict__ ax, int n, dou
     return lo;
 }
 
+// log(x) for x >= 1 (also +inf / NaN in, NaN out).  The hot kernel only ever needs log(1 + r)
+// with r >= 0, to an ABSOLUTE accuracy of a few 1e-16 -- so the argument reduction and
+// polynomial of fdlibm's e_log.c (error < 1 ulp) are enough and the double-double arithmetic,
+// subnormal and sign handling of the library log/log1p (98 / 135 VALU instructions each, and 9
+// inlined copies per binary star) are not.  ~35 instructions; the one division is a v_rcp_f64
+// seed plus two Newton steps and a residual correction.
+__device__ __forceinline__ double log_ge1(double x)
+{
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    int k = __builtin_amdgcn_frexp_exp(x);          // x = m * 2^k, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool lt = m < 0.70710678118654752440;
+    m = lt ? m + m : m;                             // m in [sqrt(1/2), sqrt(2))
+    k = lt ? k - 1 : k;
+    const double f = m - 1.0;
+    const double y = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(y);
+    r = fma(fma(-y, r, 1.0), r, r);
+    r = fma(fma(-y, r, 1.0), r, r);
+    double sq = f * r;
+    sq = fma(fma(-y, sq, f), r, sq);                // s = f / (2 + f)
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return fma(dk, ln2_hi, -((hfsq - fma(sq, hfsq + R, dk * ln2_lo)) - f));
+}
+
+// log(1 + exp(x)), any x (x = -inf gives 0)
+__device__ __forceinline__ double log1pexp(double x) { return log_ge1(1.0 + exp(x)); }
+
 __device__ __forceinline__ double logaddexp(double a, double b)
 {
     if (a == NEG_INF) return b;
     if (b == NEG_INF) return a;
     double hi = a > b ? a : b, lo = a > b ? b : a;
-    return hi + log1p(exp(lo - hi));
+    return hi + log1pexp(lo - hi);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -339,19 +395,19 @@ __device__ __forceinline__ double chi2_system(const DevPack &pk, const IsoView<N
         star_mags<NFP, GENERAL>(pk, iso, par, q * m1, wd_type, p2);
 #pragma unroll
         for (int f = 0; f < NFP; ++f)
-            p1[f] -= (2.5 / LN10) * log1p(exp((-0.4 * LN10) * (p2[f] - p1[f])));
+            p1[f] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (p2[f] - p1[f]));
     }
     const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
     double chi2 = 0.0;
-    bool finite = true;
 #pragma unroll
     for (int f = 0; f < NFP; ++f) {
-        double pred = p1[f] + (mod + pk.abs_m1[f] * av);
-        finite = finite && isfinite(pred);
-        double d = pred - st.obs[(size_t)f * st.n_pad + i];
+        const double pred = p1[f] + (mod + pk.abs_m1[f] * av);
+        const double d = pred - st.obs[(size_t)f * st.n_pad + i];
         chi2 = fma(st.w[(size_t)f * st.n_pad + i] * d, d, chi2);
     }
-    return finite ? chi2 : __builtin_inf();
+    // a non-finite predicted magnitude (NaN or inf, also under a zero weight: 0 * inf = NaN)
+    // leaves chi2 non-finite: the star is impossible under this isochrone
+    return isfinite(chi2) ? chi2 : __builtin_inf();
 }
 
 // one star, all populations, field-star mixture: log( (1-p) fsLike + p L_i )
@@ -402,8 +458,96 @@ __device__ __forceinline__ bool load_iso_views(const IsoHdr *__restrict__ hdr, c
 // same L % 8 and consecutive L / 8: the tile's star data is fetched from HBM once into that
 // XCD's L2 and re-read from L2 by the other walkers.  (Placement affects speed only.)
 // ------------------------------------------------------------------------------------------
-template <int NFP, int NPOPS, bool USE_LDS>
-__global__ __launch_bounds__(256) void k_star_like(DevPack pk, DevStars st,
+#ifndef B9_K1_MIN_WAVES
+#define B9_K1_MIN_WAVES 3
+#endif
+
+// Bracket of mass m in an LDS-resident mass column (same rule as msrgb_mags / the oracle).
+__device__ __forceinline__ void find_bracket(const double *mass, int n, double m, int &lo_out, double &t_out)
+{
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (mass[mid] <= m) lo = mid; else hi = mid;
+    }
+    const double a = mass[lo], d = mass[lo + 1] - a;
+    t_out = (d > 0.0) ? (m - a) / d : 0.0;
+    lo_out = lo;
+}
+
+// The hot kernel's per-star body, written so that dependent memory round trips are minimal:
+// star data is already in registers (loaded at kernel entry, in flight while the mass column
+// is staged); both binary searches (primary, secondary) run in LDS BEFORE any magnitude row
+// is requested, then the rows of both components are requested together (one L2 round trip).
+template <int NFP, int NPOPS>
+__device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP> (&iso)[NPOPS],
+                                           const double *__restrict__ par, double m1, double q,
+                                           double c0, double la, const double (&obs)[NFP],
+                                           const double (&wgt)[NFP], double log_lam, double log_1ml)
+{
+    const bool binary = q > 0.0;
+    const double m2 = q * m1;
+    double ll[NPOPS];
+#pragma unroll
+    for (int k = 0; k < NPOPS; ++k) {
+        int lo1, lo2 = 0;
+        double t1, t2 = 0.0;
+        const bool dark1 = !(m1 > 0.0) || m1 < iso[k].mass[0];
+        const bool dark2 = !(m2 > 0.0) || m2 < iso[k].mass[0];
+        find_bracket(iso[k].mass, iso[k].n, m1, lo1, t1);
+        if (binary) find_bracket(iso[k].mass, iso[k].n, m2, lo2, t2);
+        STAMP(4);
+        // two consecutive rows = 2*NFP contiguous doubles
+        const double2 *r1 = reinterpret_cast<const double2 *>(iso[k].mags + (size_t)lo1 * NFP);
+        const double2 *r2 = reinterpret_cast<const double2 *>(iso[k].mags + (size_t)lo2 * NFP);
+        double2 a1[NFP], a2[NFP];
+#pragma unroll
+        for (int j = 0; j < NFP; ++j) a1[j] = r1[j];
+        if (binary) {
+#pragma unroll
+            for (int j = 0; j < NFP; ++j) a2[j] = r2[j];
+        }
+        double p[NFP];
+#pragma unroll
+        for (int j = 0; j < NFP / 2; ++j) {
+            p[2 * j] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].x, a1[NFP / 2 + j].x, t1);
+            p[2 * j + 1] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].y, a1[NFP / 2 + j].y, t1);
+        }
+        STAMP(5);
+#ifndef B9_ABL_NOBIN
+        if (binary) {
+#pragma unroll
+            for (int j = 0; j < NFP / 2; ++j) {
+                const double s0 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].x, a2[NFP / 2 + j].x, t2);
+                const double s1 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].y, a2[NFP / 2 + j].y, t2);
+                p[2 * j] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s0 - p[2 * j]));
+                p[2 * j + 1] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s1 - p[2 * j + 1]));
+            }
+        }
+#else
+        if (binary) { for (int j = 0; j < NFP / 2; ++j) { p[2 * j] += a2[j].x * t2; p[2 * j + 1] += a2[NFP / 2 + j].y; } }
+#endif
+        STAMP(6);
+        const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
+        double chi2 = 0.0;
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            const double d = (p[f] + (mod + pk.abs_m1[f] * av)) - obs[f];
+            chi2 = fma(wgt[f] * d, d, chi2);
+        }
+        ll[k] = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
+    }
+    double l = ll[0];
+    if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[NPOPS - 1]);
+#ifdef B9_ABL_NOMIX
+    return la + l;
+#else
+    return logaddexp(la, l);
+#endif
+}
+
+template <int NFP, int NPOPS>
+__global__ __launch_bounds__(256, B9_K1_MIN_WAVES) void k_star_like(DevPack pk, DevStars st,
                                                     const IsoHdr *__restrict__ hdr,
                                                     const double *__restrict__ iso_data,
                                                     long long iso_stride, int mass_cap,
@@ -411,64 +555,111 @@ __global__ __launch_bounds__(256) void k_star_like(DevPack pk, DevStars st,
                                                     double *__restrict__ partial, int n_groups,
                                                     double *__restrict__ perstar, int tiles_per_block)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];   // [0..7] reduction scratch, then isochrone(s)
+    // LDS: [0..7] reduction scratch, then the mass column of each population's isochrone -- the
+    // binary search runs in LDS (dependent ds_reads instead of dependent L2 round trips); the
+    // magnitude rows a star needs are then read from L2 (coalesced: stars are sorted by mass,
+    // so neighbouring lanes hit the same or adjacent rows).
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
+    STAMP(0);
     const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
     const int w = s % n_walkers;
     const int group = (s / n_walkers) * 8 + xcd;        // tile group = tiles_per_block consecutive tiles
     if (group >= n_groups) return;
     const double *par = params + (size_t)w * B9_NPARAM;
-
-    IsoView<NFP> iso[NPOPS];
-    double tip_min;
-    const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
     const int tile0 = group * tiles_per_block;
+
+    // ---- first round trip: everything that depends only on the kernel arguments ------------
+    // (1) this lane's star of the first tile
+    int i = tile0 * 256 + tid;
+    double obs[NFP], wgt[NFP], m1, q, c0, la;
+    {
+        const int il = i < st.n_pad ? i : st.n_pad - 1;     // stay inside the padded arrays
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            obs[f] = st.obs[(size_t)f * st.n_pad + il];
+            wgt[f] = st.w[(size_t)f * st.n_pad + il];
+        }
+        m1 = st.mass1[il]; q = st.q[il]; c0 = st.c0[il]; la = st.la[il];
+    }
+    // (2) the mass column(s): the source address needs no header field, and copying the full
+    //     capacity instead of hdr.n entries costs nothing (the tail is never searched)
+    IsoView<NFP> iso[NPOPS];
+#pragma unroll
+    for (int k = 0; k < NPOPS; ++k) {
+        const double *g = iso_data + (size_t)(w * NPOPS + k) * iso_stride;
+        double *dst = smem + 8 + (size_t)k * mass_cap;
+        const double2 *sm = reinterpret_cast<const double2 *>(g);
+        double2 *dm = reinterpret_cast<double2 *>(dst);
+        for (int j = tid; j < mass_cap / 2; j += 256) dm[j] = sm[j];
+        iso[k].mass = dst; iso[k].mags = g + mass_cap;
+    }
+    // (3) the header(s)
+    bool valid = true;
+    double tip_min = __builtin_inf();
+#pragma unroll
+    for (int k = 0; k < NPOPS; ++k) {
+        const IsoHdr h = hdr[w * NPOPS + k];
+        valid = valid && h.valid;
+        iso[k].n = h.n; iso[k].tip = h.agb_tip;
+        iso[k].i_feh = h.i_feh; iso[k].i_y = h.i_y; iso[k].t_feh = h.t_feh; iso[k].t_y = h.t_y;
+        tip_min = h.agb_tip < tip_min ? h.agb_tip : tip_min;
+    }
+    const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
     if (!valid) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
         if (tid == 0) partial[(size_t)w * n_groups + group] = 0.0;
         if (perstar)
             for (int t = 0; t < tiles_per_block; ++t) {
-                int i = (tile0 + t) * 256 + tid;
-                if (i < st.n) perstar[(size_t)w * st.n + st.perm[i]] = NEG_INF;
+                int ii = (tile0 + t) * 256 + tid;
+                if (ii < st.n_pad && st.perm[ii] >= 0) perstar[(size_t)w * st.n + st.perm[ii]] = NEG_INF;
             }
         return;
     }
-    if (USE_LDS) {
-        double *dst = smem + 8;
-#pragma unroll
-        for (int k = 0; k < NPOPS; ++k) {
-            const int n = iso[k].n;
-            const int n_even = (n + 1) & ~1;
-            const double2 *sm = reinterpret_cast<const double2 *>(iso[k].mass);
-            const double2 *sg = reinterpret_cast<const double2 *>(iso[k].mags);
-            double2 *dm = reinterpret_cast<double2 *>(dst);
-            double2 *dg = reinterpret_cast<double2 *>(dst + n_even);
-            for (int j = tid; j < n_even / 2; j += 256) dm[j] = sm[j];
-            for (int j = tid; j < n * NFP / 2; j += 256) dg[j] = sg[j];
-            iso[k].mass = dst; iso[k].mags = dst + n_even;
-            dst += n_even + (size_t)n * NFP;
-        }
-        __syncthreads();
-    }
-
-    const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
     const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
     double acc = 0.0;
     for (int t = 0; t < tiles_per_block; ++t) {
-        const int i = (tile0 + t) * 256 + tid;
-        if ((tile0 + t) * 256 >= st.n) break;
+        if ((tile0 + t) * 256 >= st.n_pad) break;
+        if (t > 0) {
+            i = (tile0 + t) * 256 + tid;
+            const int il = i < st.n_pad ? i : st.n_pad - 1;
+#pragma unroll
+            for (int f = 0; f < NFP; ++f) {
+                obs[f] = st.obs[(size_t)f * st.n_pad + il];
+                wgt[f] = st.w[(size_t)f * st.n_pad + il];
+            }
+            m1 = st.mass1[il]; q = st.q[il]; c0 = st.c0[il]; la = st.la[il];
+        }
+        STAMP(3);
         double v = 0.0;
-        if (i < st.n && !(st.mass1[i] > tip_min)) {
-            v = star_value<NFP, NPOPS, false>(pk, iso, par, st, i, log_lam, log_1ml);
+        if (i < st.n_pad && !(m1 > tip_min)) {     // empty slots hold m1 = +inf
+#ifdef B9_ABL_LOADONLY
+            v = m1 + q + c0 + la + iso[0].mass[tid & 127];
+            for (int f = 0; f < NFP; ++f) v += obs[f] * wgt[f];
+#else
+            v = hot_star<NFP, NPOPS>(pk, iso, par, m1, q, c0, la, obs, wgt, log_lam, log_1ml);
+#endif
             if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
         }
         acc += v;
     }
+    STAMP(7);
     // wave shuffle reduction, then fixed-order LDS sum of the 4 wave partials
     double sum = wave_sum(acc);
     if ((tid & 63) == 0) smem[tid >> 6] = sum;
     __syncthreads();
     if (tid == 0) partial[(size_t)w * n_groups + group] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    STAMP(8);
 }
+
+#ifdef B9_STAMPS
+extern "C" int b9_debug_read_stamps(unsigned long long *out, int n_waves)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * B9_NSTAMP * n_waves);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_finalize: one workgroup per walker.
@@ -492,16 +683,6 @@ __device__ inline double log_prior_cluster(const DevPriors &pr, const double *__
         }
     }
     return lp;
-}
-
-// first index in [lo, hi) of the ascending run a[] with a[i] > x
-__device__ __forceinline__ int upper_bound_idx(const double *__restrict__ a, int lo, int hi, double x)
-{
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (a[mid] > x) hi = mid; else lo = mid + 1;
-    }
-    return lo;
 }
 
 #define B9_FIN_THREADS 512
@@ -530,15 +711,21 @@ __global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStar
             for (int i = tid; i < st.n; i += B9_FIN_THREADS) perstar[(size_t)w * st.n + i] = NEG_INF;
         return;
     }
-    // (1) heavy stars: [i_s, n_single) and [i_b, n)
-    const int i_s = upper_bound_idx(st.mass1, 0, st.n_single, tip_min);
-    const int i_b = upper_bound_idx(st.mass1, st.n_single, st.n, tip_min);
-    const int n_s = st.n_single - i_s, count = n_s + (st.n - i_b);
+    // (1) heavy stars: the leading run of the descending-mass list with mass > tip_min
+    int count;
+    {
+        int lo = 0, hi = st.n;                     // first k with heavy_mass[k] <= tip_min
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (st.heavy_mass[mid] > tip_min) lo = mid + 1; else hi = mid;
+        }
+        count = lo;
+    }
     const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
     const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
     double acc = 0.0;
     for (int j = tid; j < count; j += B9_FIN_THREADS) {
-        const int i = j < n_s ? i_s + j : i_b + (j - n_s);
+        const int i = st.heavy_slot[j];
         const double v = star_value<NFP, NPOPS, true>(pk, iso, par, st, i, log_lam, log_1ml);
         if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
         acc += v;
@@ -569,20 +756,19 @@ hipError_t b9k_derive_iso(const DevPack &pk, const double *d_params, int n_walke
     return hipGetLastError();
 }
 
-size_t b9k_star_like_lds_bytes(int nfp, int n_pops, int max_eep)
+size_t b9k_star_like_lds_bytes(int n_pops, int mass_cap)
 {
-    size_t n_even = (size_t)((max_eep + 1) & ~1);
-    return sizeof(double) * (8 + (size_t)n_pops * (n_even + (size_t)max_eep * nfp));
+    return sizeof(double) * (8 + (size_t)n_pops * mass_cap);
 }
 
-template <int NFP, int NPOPS, bool USE_LDS>
+template <int NFP, int NPOPS>
 static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                                    const double *iso_data, long long iso_stride, int mass_cap,
                                    const double *d_params, int n_walkers, double *partial,
                                    double *perstar, int tiles_per_block, int n_groups, hipStream_t stream)
 {
-    size_t lds = USE_LDS ? b9k_star_like_lds_bytes(NFP, NPOPS, pk.max_eep) : 8 * sizeof(double);
-    auto kern = k_star_like<NFP, NPOPS, USE_LDS>;
+    const size_t lds = b9k_star_like_lds_bytes(NPOPS, mass_cap);
+    auto kern = k_star_like<NFP, NPOPS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -616,13 +802,13 @@ static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const I
 
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
-                         const double *d_params, int n_walkers, int n_pops, bool use_lds,
+                         const double *d_params, int n_walkers, int n_pops,
                          double *partial, double *perstar, int tiles_per_block, int n_groups,
                          hipStream_t stream)
 {
 #define SL_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, n_groups, stream
-#define SL2(NFP) (use_lds ? launch_star_like<NFP, 2, true>(SL_ARGS) : launch_star_like<NFP, 2, false>(SL_ARGS))
-#define SL1(NFP) (use_lds ? launch_star_like<NFP, 1, true>(SL_ARGS) : launch_star_like<NFP, 1, false>(SL_ARGS))
+#define SL2(NFP) launch_star_like<NFP, 2>(SL_ARGS)
+#define SL1(NFP) launch_star_like<NFP, 1>(SL_ARGS)
     B9_SWITCH_NFP(SL2, SL1)
 #undef SL1
 #undef SL2

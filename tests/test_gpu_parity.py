@@ -75,12 +75,10 @@ CASES = [
 
 
 @pytest.mark.parametrize("name,n_filt,n_stars,wd_frac,n_y,n_pops,small", CASES)
-@pytest.mark.parametrize("plan", ["auto", "lds", "global"])
+@pytest.mark.parametrize("plan", ["auto", "tpb3", "tpb8"])
 def test_logpost_matches_oracle(hip, monkeypatch, name, n_filt, n_stars, wd_frac, n_y, n_pops, small, plan):
-    if plan == "lds":
-        monkeypatch.setenv("B9_FORCE_LDS", "1"); monkeypatch.setenv("B9_TILES_PER_BLOCK", "3")
-    elif plan == "global":
-        monkeypatch.setenv("B9_FORCE_LDS", "0"); monkeypatch.setenv("B9_TILES_PER_BLOCK", "1")
+    if plan != "auto":
+        monkeypatch.setenv("B9_TILES_PER_BLOCK", plan[3:])
     pack_d, cl, pack, stars, priors, options = build_problem(name, n_filt, n_stars=n_stars, wd_frac=wd_frac,
                                                              n_y=n_y, n_pops=n_pops, small=small)
     eng = hip.Engine(pack, stars, priors, options)

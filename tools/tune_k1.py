@@ -15,10 +15,10 @@ truth = synth.default_params(pack_d)
 cl = synth.make_cluster(pack_d, n_stars, seed=9003, truth=truth, wd_frac=wd_frac)
 pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
 priors, options = synth.default_priors(pack_d, truth), abi.make_options()
-params = synth.walker_params(truth, n_walkers, seed=42, scale=0.05)
+params = synth.walker_params(truth, n_walkers, seed=42, scale=float(os.environ.get("TUNE_SCALE", "0.05")))
 d_params = torch.tensor(params, device="cuda")
 d_out = torch.empty(n_walkers, dtype=torch.float64, device="cuda")
-plans = [("auto", None, None)] + [(f"tpb{t}-lds{l}", t, l) for l in (0, 1) for t in (1, 2, 4, 8)]
+plans = [("auto", None, None)] + ([] if os.environ.get("TUNE_AUTO_ONLY") else [(f"tpb{t}", t, None) for t in (1, 2, 4)])
 for name, tpb, lds in plans:
     for k, v in (("B9_TILES_PER_BLOCK", tpb), ("B9_FORCE_LDS", lds)):
         if v is None: os.environ.pop(k, None)
