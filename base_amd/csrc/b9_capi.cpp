@@ -56,12 +56,15 @@ struct b9_ctx {
     size_t partial_cap = 0;
     double *d_params = nullptr, *d_logpost = nullptr, *d_perstar = nullptr;
     size_t perstar_cap = 0;
+    void *d_mcmc = nullptr;          // device state of b9_mcmc_run_block
+    size_t mcmc_cap = 0;
 
     // launch plan
     int tiles_per_block = 0;   // 0 = auto
 
     // timing of the dominant kernel
-    bool timing = false;
+    int timing = 0;            // 0 off, n > 0: bracket every n-th launch of the dominant kernel with events
+    unsigned long long launch_no = 0;
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used = 0;
     double ms_accum = 0.0;
@@ -319,7 +322,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx->pack_allocs);
     free_all(ctx->star_allocs);
-    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar};
+    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_mcmc};
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
@@ -456,24 +459,21 @@ int b9_set_options(b9_ctx *ctx, const b9_options *o)
     return B9_OK;
 }
 
-int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, double *d_logpost,
-                      double *d_perstar, void *stream_v)
+// The three stream-ordered launches of one log-posterior evaluation.  With mc.enabled the first
+// kernel also draws the Metropolis proposal (and writes it to d_params) and the last one accepts
+// or rejects it: a whole MCMC step without the host.
+static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, double *d_logpost,
+                          double *d_perstar, const McmcDev &mc, hipStream_t stream)
 {
-    if (!ctx || !d_params || !d_logpost || n_walkers < 1) return B9_ERR_INVALID;
-    if (!ctx->have_pack || !ctx->have_stars) return fail(ctx, B9_ERR_STATE, "load the pack and the stars first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
-    if (ctx->opt.mode == B9_MODE_MARGINALISED) return fail(ctx, B9_ERR_STATE, "marginalised mode is not built in this revision");
-    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
     const int n_pops = ctx->opt.n_pops;
     const Plan plan = make_plan(ctx, n_walkers, n_pops);
     int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)plan.n_groups * n_walkers, false);
     if (rc) return rc;
-
     HIPCHK(ctx, b9k_derive_iso(ctx->pk, d_params, n_walkers, n_pops, ctx->d_hdr, ctx->d_iso, ctx->iso_stride,
-                               ctx->mass_cap, stream));
+                               ctx->mass_cap, mc, stream));
     size_t slot = 0;
-    if (ctx->timing) {
+    const bool timed = ctx->timing > 0 && (ctx->launch_no++ % (unsigned)ctx->timing) == 0;
+    if (timed) {
         if (ctx->ev_used == ctx->ev_start.size()) {
             hipEvent_t a, b;
             HIPCHK(ctx, hipEventCreate(&a));
@@ -486,20 +486,102 @@ int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, do
     HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, d_params,
                               n_walkers, n_pops, ctx->d_partial, d_perstar, plan.tiles_per_block,
                               plan.n_groups, stream));
-    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
     HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->d_partial,
-                             plan.n_groups, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, stream));
+                             plan.n_groups, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, stream));
+    return B9_OK;
+}
+
+static int check_ready(b9_ctx *ctx)
+{
+    if (!ctx->have_pack || !ctx->have_stars) return fail(ctx, B9_ERR_STATE, "load the pack and the stars first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
+    if (ctx->opt.mode == B9_MODE_MARGINALISED) return fail(ctx, B9_ERR_STATE, "marginalised mode is not built in this revision");
+    return B9_OK;
+}
+
+int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, double *d_logpost,
+                      double *d_perstar, void *stream_v)
+{
+    if (!ctx || !d_params || !d_logpost || n_walkers < 1) return B9_ERR_INVALID;
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
+    McmcDev mc{};
+    return launch_logpost(ctx, const_cast<double *>(d_params), n_walkers, d_logpost, d_perstar, mc, stream);
+}
+
+/* Device-resident Metropolis block (the caller of the hot path). */
+int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
+{
+    if (!ctx || !blk || blk->n_walkers < 1 || blk->n_steps < 0 || blk->n_free < 1 || blk->n_free > 11 ||
+        !blk->free_idx || !blk->chol || !blk->walker_ids || !blk->params || !blk->logpost)
+        return B9_ERR_INVALID;
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps;
+    for (int i = 0; i < d; ++i)
+        if (blk->free_idx[i] < 0 || blk->free_idx[i] >= B9_NPARAM) return fail(ctx, B9_ERR_INVALID, "free_idx out of range");
+    {   // make sure the shared work buffers exist before taking pointers into them
+        const Plan plan = make_plan(ctx, W, ctx->opt.n_pops);
+        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)plan.n_groups * W, false);
+        if (rc) return rc;
+    }
+    // one device allocation for the block's state
+    const size_t n_cur = (size_t)W * B9_NPARAM, n_samp = blk->samples ? (size_t)S * W * d : 0,
+                 n_lps = blk->lps ? (size_t)S * W : 0;
+    const size_t doubles = n_cur + W + (size_t)d * d + n_samp + n_lps + 1;
+    const size_t bytes = doubles * sizeof(double) + (size_t)(d + W) * sizeof(int);
+    if (bytes > ctx->mcmc_cap) {
+        if (ctx->d_mcmc) (void)hipFree(ctx->d_mcmc);
+        ctx->d_mcmc = nullptr; ctx->mcmc_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_mcmc, bytes));
+        ctx->mcmc_cap = bytes;
+    }
+    double *p = static_cast<double *>(ctx->d_mcmc);
+    McmcDev mc{};
+    mc.enabled = 1; mc.d = d;
+    mc.cur = p; p += n_cur;
+    mc.lp_cur = p; p += W;
+    double *d_chol = p; p += (size_t)d * d;
+    mc.samples = n_samp ? p : nullptr; p += n_samp;
+    mc.lps = n_lps ? p : nullptr; p += n_lps;
+    mc.n_acc = reinterpret_cast<unsigned long long *>(p); p += 1;
+    int *d_free = reinterpret_cast<int *>(p), *d_ids = d_free + d;
+    mc.chol = d_chol; mc.free_idx = d_free; mc.walker_ids = d_ids;
+    mc.k0 = (unsigned)(blk->seed & 0xFFFFFFFFull); mc.k1 = (unsigned)(blk->seed >> 32);
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(mc.cur, blk->params, n_cur * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(mc.lp_cur, blk->logpost, W * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(d_chol, blk->chol, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(d_free, blk->free_idx, d * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(d_ids, blk->walker_ids, W * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemsetAsync(mc.n_acc, 0, sizeof(unsigned long long), s));
+    for (int k = 0; k < S; ++k) {
+        mc.step = (unsigned long long)(blk->step0 + k);
+        mc.row = k;
+        rc = launch_logpost(ctx, ctx->d_params, W, ctx->d_logpost, nullptr, mc, s);
+        if (rc) return rc;
+    }
+    unsigned long long n_acc = 0;
+    HIPCHK(ctx, hipMemcpyAsync(blk->params, mc.cur, n_cur * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(blk->logpost, mc.lp_cur, W * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (n_samp) HIPCHK(ctx, hipMemcpyAsync(blk->samples, mc.samples, n_samp * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (n_lps) HIPCHK(ctx, hipMemcpyAsync(blk->lps, mc.lps, n_lps * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(&n_acc, mc.n_acc, sizeof n_acc, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    blk->n_accept = (int64_t)n_acc;
     return B9_OK;
 }
 
 int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out_logpost, double *out_perstar)
 {
     if (!ctx || !params || !out_logpost || n_walkers < 1) return B9_ERR_INVALID;
-    if (!ctx->have_pack || !ctx->have_stars) return fail(ctx, B9_ERR_STATE, "load the pack and the stars first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
+    int rc = check_ready(ctx);
+    if (rc) return rc;
     const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
-    int rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)plan.n_groups * n_walkers, out_perstar != nullptr);
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)plan.n_groups * n_walkers, out_perstar != nullptr);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
     rc = b9_logpost_device(ctx, ctx->d_params, n_walkers, ctx->d_logpost, out_perstar ? ctx->d_perstar : nullptr, ctx->stream);
@@ -524,7 +606,7 @@ int b9_derive_isochrone(b9_ctx *ctx, const double *param_row, int32_t pop, int32
     std::memcpy(row, param_row, sizeof row);
     if (pop) row[B9_P_Y] = row[B9_P_Y2];
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, row, sizeof row, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, b9k_derive_iso(ctx->pk, ctx->d_params, 1, 1, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->stream));
+    HIPCHK(ctx, b9k_derive_iso(ctx->pk, ctx->d_params, 1, 1, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, McmcDev{}, ctx->stream));
     IsoHdr h;
     HIPCHK(ctx, hipMemcpyAsync(&h, ctx->d_hdr, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -553,7 +635,8 @@ int b9_bytes_per_star_eval(const b9_ctx *ctx)
 int b9_enable_timing(b9_ctx *ctx, int on)
 {
     if (!ctx) return B9_ERR_INVALID;
-    ctx->timing = on != 0;
+    ctx->timing = on > 0 ? on : 0;
+    ctx->launch_no = 0;
     return B9_OK;
 }
 

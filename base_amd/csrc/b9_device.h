@@ -57,3 +57,20 @@ struct DevPriors {
     double mean[12], var[12];
     double log_age_min, log_age_max;
 };
+
+// Device-resident Metropolis state of the local walkers (b9_mcmc_run_block).  Passed by value;
+// enabled == 0 makes the kernels behave as the plain log-posterior path.
+struct McmcDev {
+    int enabled, d;                  // d = number of free parameters (<= 11)
+    double *cur;                     // [W][12] current positions
+    double *lp_cur;                  // [W]
+    const double *chol;              // [d][d] row-major proposal factor
+    const int *free_idx;             // [d]
+    const int *walker_ids;           // [W] global walker ids (RNG streams)
+    unsigned k0, k1;                 // Philox key (seed)
+    unsigned long long step;         // global step number of this launch
+    double *samples;                 // [n_steps][W][d] or null
+    double *lps;                     // [n_steps][W] or null
+    unsigned long long *n_acc;       // accepted proposals
+    int row;                         // step index inside the block
+};

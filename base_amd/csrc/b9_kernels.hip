@@ -112,7 +112,34 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ------------------------------------------------------------------------------------------
+// Counter-based random numbers for the device-resident sampler: Philox4x32-10 (Salmon et al.
+// 2011), counter = (step lo, step hi, walker, draw), key = seed.  base_amd/mcmc.py holds the
+// numpy twin; tests/test_mcmc.py checks it against the Random123 known-answer vectors.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                           unsigned k0, unsigned k1, unsigned (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)c0 * 0xD2511F53ull;
+        const unsigned long long p1 = (unsigned long long)c2 * 0xCD9E8D57ull;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u01(unsigned hi, unsigned lo)
+{
+    const unsigned long long x = ((unsigned long long)(hi >> 5) << 26) + (unsigned long long)(lo >> 6);
+    return ((double)x + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------------------------------
 // k_derive_iso
+// ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 struct Corners {
     long long off[8];      // point offset of EEP `lo` in each corner isochrone
@@ -153,12 +180,14 @@ __device__ __forceinline__ int bracket_wave(const double *__restrict__ ax, int n
     return i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
 }
 
-// grid = (walkers * pops, B9_ISO_SPLIT): every block of a row re-derives the (cheap) header and
-// interpolates its share of the EEPs; block y == 0 publishes the header.
-__global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, const double *__restrict__ params,
+// grid = (walkers * pops, ceil(mass_cap * (nfp + 1) / 256)): every block re-derives the (cheap)
+// header -- three dependent round trips: {parameters, axes} -> corner index rows -> table
+// values -- and then each THREAD produces exactly one output value, so the table reads of one
+// isochrone are a single round trip spread over ~15 workgroups.  Block y == 0 publishes the header.
+__global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restrict__ params,
                                                      int n_pops, IsoHdr *__restrict__ hdr,
                                                      double *__restrict__ iso_data, long long iso_stride,
-                                                     int mass_cap)
+                                                     int mass_cap, McmcDev mc)
 {
     const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,6 +195,30 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, const double *__
     __shared__ IsoHdr sh;
     __shared__ Corners sc;
     __shared__ int s_br[3];
+    __shared__ double s_par[B9_NPARAM], s_z[12];
+    if (mc.enabled) {
+        // Metropolis proposal of walker w, recomputed identically by every block of the row:
+        //   prop = cur;  prop[free[i]] += sum_j chol[i][j] z_j,   z from Philox + Box-Muller.
+        // Block (y == 0, pop == 0) publishes the row to `params` for the two kernels that follow.
+        const int d = mc.d, n_pairs = (d + 1) >> 1;
+        if (tid < B9_NPARAM) s_par[tid] = mc.cur[(size_t)w * B9_NPARAM + tid];
+        if (tid < n_pairs) {
+            unsigned r[4];
+            philox4x32((unsigned)mc.step, (unsigned)(mc.step >> 32), (unsigned)mc.walker_ids[w], (unsigned)tid, mc.k0, mc.k1, r);
+            const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+            const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+            s_z[2 * tid] = rad * cos(ang);
+            s_z[2 * tid + 1] = rad * sin(ang);
+        }
+        __syncthreads();
+        double delta = 0.0;
+        if (tid < d) for (int j = 0; j < d; ++j) delta = delta + mc.chol[tid * d + j] * s_z[j];
+        __syncthreads();
+        if (tid < d) s_par[mc.free_idx[tid]] += delta;
+        __syncthreads();
+        if (blockIdx.y == 0 && pop == 0 && tid < B9_NPARAM) params[(size_t)w * B9_NPARAM + tid] = s_par[tid];
+        par = s_par;
+    }
     const double log_age = par[B9_P_LOGAGE], feh = par[B9_P_FEH];
     const double y = pop ? par[B9_P_Y2] : par[B9_P_Y];
     // three waves bracket the three axes concurrently
@@ -179,10 +232,19 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, const double *__
         const int i_age = s_br[0], i_feh = s_br[1], i_y = s_br[2];
         const int df = (lane >> 2) & 1, dy = (lane >> 1) & 1, da = lane & 1;
         const int dyc = dy < ny ? dy : 0;
-        const int k = ((i_feh + df) * pk.n_y + (i_y + dyc)) * pk.n_age + i_age + da;
+        const int kk = ((i_feh + df) * pk.n_y + (i_y + dyc)) * pk.n_age + i_age + da;
         int f0 = -2147483647, f1 = 2147483647;
         long long off = 0;
-        if (lane < 8) { f0 = pk.first[k]; f1 = f0 + pk.cnt[k]; off = pk.off[k]; }
+        double ax0 = 0.0, ax1 = 1.0;
+        if (lane < 8) { f0 = pk.first[kk]; f1 = f0 + pk.cnt[kk]; off = pk.off[kk]; }
+        // lanes 8..13 fetch the axis values the interpolation weights need (same round trip)
+        if (lane == 8)  ax0 = pk.log_age[i_age];
+        if (lane == 9)  ax0 = pk.log_age[i_age + 1];
+        if (lane == 10) ax0 = pk.feh[i_feh];
+        if (lane == 11) ax0 = pk.feh[i_feh + 1];
+        if (lane == 12) ax0 = pk.y[i_y];
+        if (lane == 13) ax0 = pk.y[ny == 2 ? i_y + 1 : i_y];
+        (void)ax1;
         int lo = f0, hi = f1;
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) {
@@ -190,19 +252,26 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, const double *__
             lo = l2 > lo ? l2 : lo;
             hi = h2 < hi ? h2 : hi;
         }
+        lo = __shfl(lo, 0, 64); hi = __shfl(hi, 0, 64);
+        const double a_lo = __shfl(ax0, 8, 64), a_hi = __shfl(ax0, 9, 64);
+        const double f_lo = __shfl(ax0, 10, 64), f_hi = __shfl(ax0, 11, 64);
+        const double y_lo = __shfl(ax0, 12, 64), y_hi = __shfl(ax0, 13, 64);
+        const double a_min = pk.log_age[0], a_max = pk.log_age[pk.n_age - 1];
+        const double f_min = pk.feh[0], f_max = pk.feh[pk.n_feh - 1];
+        const double y_min = pk.y[0], y_max = pk.y[pk.n_y - 1];
         if (lane < 8) sc.off[lane] = off + (lo - f0);
         if (lane == 0) {
             IsoHdr h;
             h.valid = 0; h.first_eep = 0; h.n = 0; h.i_feh = i_feh; h.i_y = i_y; h.i_age = i_age;
             h.agb_tip = 0.0; h.t_feh = h.t_y = h.t_age = 0.0;
-            bool ok = (log_age >= pk.log_age[0] && log_age <= pk.log_age[pk.n_age - 1]) &&
-                      (feh >= pk.feh[0] && feh <= pk.feh[pk.n_feh - 1]) && pk.n_age >= 2 && pk.n_feh >= 2;
-            if (pk.n_y > 1) ok = ok && (y >= pk.y[0] && y <= pk.y[pk.n_y - 1]);
+            bool ok = (log_age >= a_min && log_age <= a_max) && (feh >= f_min && feh <= f_max) &&
+                      pk.n_age >= 2 && pk.n_feh >= 2;
+            if (pk.n_y > 1) ok = ok && (y >= y_min && y <= y_max);
             const int n = hi - lo;
             if (ok && n >= 2 && n <= mass_cap) {
-                h.t_age = (log_age - pk.log_age[i_age]) / (pk.log_age[i_age + 1] - pk.log_age[i_age]);
-                h.t_feh = (feh - pk.feh[i_feh]) / (pk.feh[i_feh + 1] - pk.feh[i_feh]);
-                if (ny == 2) h.t_y = (y - pk.y[i_y]) / (pk.y[i_y + 1] - pk.y[i_y]);
+                h.t_age = (log_age - a_lo) / (a_hi - a_lo);
+                h.t_feh = (feh - f_lo) / (f_hi - f_lo);
+                if (ny == 2) h.t_y = (y - y_lo) / (y_hi - y_lo);
                 h.first_eep = lo; h.n = n; h.valid = 1;
             }
             sc.ny = ny; sc.t_age = h.t_age; sc.t_y = h.t_y; sc.t_feh = h.t_feh;
@@ -212,19 +281,23 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, const double *__
     __syncthreads();
     if (!sh.valid) { if (tid == 0 && blockIdx.y == 0) hdr[wp] = sh; return; }
     const int n = sh.n, nfp = pk.nfp;
-    if (tid == 0 && blockIdx.y == 0) {
+    double *omass = iso_data + (size_t)wp * iso_stride;
+    double *omags = omass + mass_cap;
+    const int idx = blockIdx.y * 256 + tid;
+    const int e = idx / (nfp + 1), c = idx - e * (nfp + 1);
+    double v = 0.0;
+    if (e < n) {
+        if (c == nfp) v = interp_corner<true>(pk, sc, e, 0);
+        else if (c < pk.nf) v = interp_corner<false>(pk, sc, e, c);
+    }
+    // the thread that owns the last point's mass also knows the AGB-tip mass: it publishes the header
+    if (blockIdx.y == 0 && tid == 0) {
         IsoHdr h = sh;
         h.agb_tip = interp_corner<true>(pk, sc, n - 1, 0);
         hdr[wp] = h;
     }
-    double *omass = iso_data + (size_t)wp * iso_stride;
-    double *omags = omass + mass_cap;
-    const int per = (n + gridDim.y - 1) / gridDim.y;
-    const int e0 = blockIdx.y * per, e1 = (e0 + per < n) ? e0 + per : n;
-    for (int e = e0 + tid; e < e1; e += blockDim.x) omass[e] = interp_corner<true>(pk, sc, e, 0);
-    for (int idx = e0 * nfp + tid; idx < e1 * nfp; idx += blockDim.x) {
-        int e = idx / nfp, c = idx - e * nfp;
-        omags[idx] = (c < pk.nf) ? interp_corner<false>(pk, sc, e, c) : 0.0;
+    if (e < n) {
+        if (c == nfp) omass[e] = v; else omags[(size_t)e * nfp + c] = v;
     }
 }
 
@@ -287,13 +360,22 @@ __device__ __forceinline__ double ifmr(int id, const double *__restrict__ par, d
     }
 }
 
-__device__ inline double prec_log_age_corner(const DevPack &pk, int ifeh, int iy, double m)
+// Axes the WD branch searches, staged in LDS by k_finalize (a dozen dependent bracket steps per
+// star: ~64-cycle ds_reads instead of L2/HBM round trips).  Pointers fall back to global memory
+// when the axes do not fit.
+struct WdAxes {
+    const double *log_age;        // [n_age]
+    const double *tips[4];        // [(df*2+dy)][n_age] AGB-tip mass of the corner (FeH, Y) columns
+    const double *wc_log_age, *wc_mass, *wc_carb, *at_log_teff, *at_logg;
+};
+
+__device__ inline double prec_log_age_corner(const DevPack &pk, const WdAxes &ax, int corner, double m)
 {
     const int na = pk.n_age;
-    const double *tips = pk.tips + (size_t)(ifeh * pk.n_y + iy) * na;
+    const double *tips = ax.tips[corner];
     const double tip0 = tips[0];
-    if (m > tip0) return pk.log_age[0] - 2.7 * log10(m / tip0);
-    if (m <= tips[na - 1]) return pk.log_age[na - 1];
+    if (m > tip0) return ax.log_age[0] - 2.7 * log10(m / tip0);
+    if (m <= tips[na - 1]) return ax.log_age[na - 1];
     int lo = 0, hi = na - 1;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -301,14 +383,13 @@ __device__ inline double prec_log_age_corner(const DevPack &pk, int ifeh, int iy
     }
     const double a = tips[lo], b = tips[lo + 1];
     const double t = (b != a) ? (m - a) / (b - a) : 0.0;
-    return lerp(pk.log_age[lo], pk.log_age[lo + 1], t);
+    return lerp(ax.log_age[lo], ax.log_age[lo + 1], t);
 }
 
-// IFMR -> WD cooling model -> atmosphere table.  Tables stay in HBM/L2:
-// only the few per cent of stars above the AGB tip take this branch, and because stars are
-// sorted by mass they sit together in the same waves.
+// IFMR -> WD cooling model -> atmosphere table.  Only the stars above the AGB
+// tip take this branch; k_finalize runs it (the hot kernel never does).
 template <int NFP>
-__device__ __noinline__ void wd_mags(const DevPack &pk, const IsoView<NFP> &iso,
+__device__ __forceinline__ void wd_mags(const DevPack &pk, const WdAxes &ax, const IsoView<NFP> &iso,
                                      const double *__restrict__ par, double m, int wd_type,
                                      double (&out)[NFP])
 {
@@ -317,24 +398,24 @@ __device__ __noinline__ void wd_mags(const DevPack &pk, const IsoView<NFP> &iso,
     double vf[2];
     for (int df = 0; df < 2; ++df) {
         double vy[2] = {0.0, 0.0};
-        for (int dy = 0; dy < ny; ++dy) vy[dy] = prec_log_age_corner(pk, iso.i_feh + df, iso.i_y + dy, m);
+        for (int dy = 0; dy < ny; ++dy) vy[dy] = prec_log_age_corner(pk, ax, df * 2 + dy, m);
         vf[df] = (ny == 2) ? lerp(vy[0], vy[1], iso.t_y) : vy[0];
     }
     const double prec = lerp(vf[0], vf[1], iso.t_feh);
     const double log_age = par[B9_P_LOGAGE];
     if (prec >= log_age) { fill<NFP>(out, -4.0); return; }
     const double wd_mass = ifmr(pk.ifmr_id, par, m);
-    const double log_cool = log10(pow(10.0, log_age) - pow(10.0, prec));
+    const double log_cool = log10(exp10(log_age) - exp10(prec));
 
-    const int ia = bracket(pk.wc_log_age, pk.n_wc_age, log_cool);
-    const double ta = (log_cool - pk.wc_log_age[ia]) / (pk.wc_log_age[ia + 1] - pk.wc_log_age[ia]);
-    const int im = bracket(pk.wc_mass, pk.n_wc_mass, wd_mass);
-    const double tm = (wd_mass - pk.wc_mass[im]) / (pk.wc_mass[im + 1] - pk.wc_mass[im]);
+    const int ia = bracket(ax.wc_log_age, pk.n_wc_age, log_cool);
+    const double ta = (log_cool - ax.wc_log_age[ia]) / (ax.wc_log_age[ia + 1] - ax.wc_log_age[ia]);
+    const int im = bracket(ax.wc_mass, pk.n_wc_mass, wd_mass);
+    const double tm = (wd_mass - ax.wc_mass[im]) / (ax.wc_mass[im + 1] - ax.wc_mass[im]);
     const int nc = pk.n_wc_carb > 1 ? 2 : 1;
     int ic = 0; double tc = 0.0;
     if (nc == 2) {
-        ic = bracket(pk.wc_carb, pk.n_wc_carb, par[B9_P_CARBONICITY]);
-        tc = (par[B9_P_CARBONICITY] - pk.wc_carb[ic]) / (pk.wc_carb[ic + 1] - pk.wc_carb[ic]);
+        ic = bracket(ax.wc_carb, pk.n_wc_carb, par[B9_P_CARBONICITY]);
+        tc = (par[B9_P_CARBONICITY] - ax.wc_carb[ic]) / (ax.wc_carb[ic + 1] - ax.wc_carb[ic]);
     }
     double tr[2];
     for (int q = 0; q < 2; ++q) {
@@ -353,10 +434,10 @@ __device__ __noinline__ void wd_mags(const DevPack &pk, const IsoView<NFP> &iso,
     const double log_teff = tr[0];
     const double logg = LOG_G_PLUS_LOG_MSUN + log10(wd_mass) - 2.0 * tr[1];
     const int ty = (wd_type > 0 && pk.n_at_type > 1) ? 1 : 0;
-    const int it = bracket(pk.at_log_teff, pk.n_at_teff, log_teff);
-    const double tt = (log_teff - pk.at_log_teff[it]) / (pk.at_log_teff[it + 1] - pk.at_log_teff[it]);
-    const int ig = bracket(pk.at_logg, pk.n_at_logg, logg);
-    const double tg = (logg - pk.at_logg[ig]) / (pk.at_logg[ig + 1] - pk.at_logg[ig]);
+    const int it = bracket(ax.at_log_teff, pk.n_at_teff, log_teff);
+    const double tt = (log_teff - ax.at_log_teff[it]) / (ax.at_log_teff[it + 1] - ax.at_log_teff[it]);
+    const int ig = bracket(ax.at_logg, pk.n_at_logg, logg);
+    const double tg = (logg - ax.at_logg[ig]) / (ax.at_logg[ig + 1] - ax.at_logg[ig]);
     const double *g0 = pk.at_mags + (((size_t)ty * pk.n_at_logg + ig) * pk.n_at_teff + it) * NFP;
     const double *g1 = g0 + (size_t)pk.n_at_teff * NFP;
 #pragma unroll
@@ -367,32 +448,32 @@ __device__ __noinline__ void wd_mags(const DevPack &pk, const IsoView<NFP> &iso,
     }
 }
 
-// which branch a ZAMS mass is on ([RECALL] Star::getStatus).  GENERAL = false is the hot
-// kernel's form: the caller guarantees m <= tip, so only the MS/RGB branch (or "no star") exists.
-template <int NFP, bool GENERAL>
-__device__ __forceinline__ void star_mags(const DevPack &pk, const IsoView<NFP> &iso,
+// which branch a ZAMS mass is on ([RECALL] Star::getStatus) -- the general form, used by k_finalize
+// for the stars the hot kernel skips (hot_star below is the MS/RGB-only form).
+template <int NFP>
+__device__ __forceinline__ void star_mags(const DevPack &pk, const WdAxes &ax, const IsoView<NFP> &iso,
                                           const double *__restrict__ par, double m, int wd_type,
                                           double (&out)[NFP])
 {
     if (!(m > 0.0)) { fill<NFP>(out, B9_MAG_NOFLUX); return; }
-    if (!GENERAL || m <= iso.tip) { msrgb_mags<NFP>(iso, m, out); return; }
-    if (m <= pk.m_wd_up) wd_mags<NFP>(pk, iso, par, m, wd_type, out);
+    if (m <= iso.tip) { msrgb_mags<NFP>(iso, m, out); return; }
+    if (m <= pk.m_wd_up) wd_mags<NFP>(pk, ax, iso, par, m, wd_type, out);
     else fill<NFP>(out, B9_MAG_NOFLUX);
 }
 
 // SURVEY 8a rows a5 + a6: combined magnitudes -> sum_f w_f (pred_f - obs_f)^2.
 // Flux addition is done as  m1 - 2.5 log10(1 + 10^(-0.4 (m2 - m1)))  : one exp and one log1p
 // per filter instead of two pow and a log10, and no cancellation.
-template <int NFP, bool GENERAL>
-__device__ __forceinline__ double chi2_system(const DevPack &pk, const IsoView<NFP> &iso,
+template <int NFP>
+__device__ __forceinline__ double chi2_system(const DevPack &pk, const WdAxes &ax, const IsoView<NFP> &iso,
                                               const double *__restrict__ par, double m1, double q,
                                               int wd_type, const DevStars &st, int i)
 {
     double p1[NFP];
-    star_mags<NFP, GENERAL>(pk, iso, par, m1, wd_type, p1);
+    star_mags<NFP>(pk, ax, iso, par, m1, wd_type, p1);
     if (q > 0.0) {
         double p2[NFP];
-        star_mags<NFP, GENERAL>(pk, iso, par, q * m1, wd_type, p2);
+        star_mags<NFP>(pk, ax, iso, par, q * m1, wd_type, p2);
 #pragma unroll
         for (int f = 0; f < NFP; ++f)
             p1[f] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (p2[f] - p1[f]));
@@ -411,8 +492,8 @@ __device__ __forceinline__ double chi2_system(const DevPack &pk, const IsoView<N
 }
 
 // one star, all populations, field-star mixture: log( (1-p) fsLike + p L_i )
-template <int NFP, int NPOPS, bool GENERAL>
-__device__ __forceinline__ double star_value(const DevPack &pk, const IsoView<NFP> (&iso)[NPOPS],
+template <int NFP, int NPOPS>
+__device__ __forceinline__ double star_value(const DevPack &pk, const WdAxes (&ax)[NPOPS], const IsoView<NFP> (&iso)[NPOPS],
                                              const double *__restrict__ par, const DevStars &st, int i,
                                              double log_lam, double log_1ml)
 {
@@ -421,7 +502,7 @@ __device__ __forceinline__ double star_value(const DevPack &pk, const IsoView<NF
     double ll[NPOPS];
 #pragma unroll
     for (int k = 0; k < NPOPS; ++k)
-        ll[k] = c0 - 0.5 * chi2_system<NFP, GENERAL>(pk, iso[k], par, m1, q, wd_type, st, i);
+        ll[k] = c0 - 0.5 * chi2_system<NFP>(pk, ax[k], iso[k], par, m1, q, wd_type, st, i);
     double l = ll[0];
     if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[NPOPS - 1]);
     return logaddexp(la, l);
@@ -686,6 +767,43 @@ __device__ inline double log_prior_cluster(const DevPriors &pr, const double *__
 }
 
 #define B9_FIN_THREADS 512
+#define B9_FIN_WAVES (B9_FIN_THREADS / 64)
+
+// Metropolis accept/reject of walker w's proposal (one thread; device-resident sampler only):
+// accept when log u < lp_prop - lp_cur, u from the walker's Philox stream (draw index n_pairs).
+__device__ inline void metropolis_accept(const McmcDev &mc, const double *__restrict__ params, int w, double lp_prop)
+{
+    unsigned r[4];
+    philox4x32((unsigned)mc.step, (unsigned)(mc.step >> 32), (unsigned)mc.walker_ids[w], (unsigned)((mc.d + 1) >> 1),
+               mc.k0, mc.k1, r);
+    const double u = u01(r[0], r[1]);
+    const double lp_cur = mc.lp_cur[w];
+    const bool ok = isfinite(lp_prop) && (log(u) < lp_prop - lp_cur);
+    double *cur = mc.cur + (size_t)w * B9_NPARAM;
+    if (ok) {
+        for (int k = 0; k < B9_NPARAM; ++k) cur[k] = params[(size_t)w * B9_NPARAM + k];
+        mc.lp_cur[w] = lp_prop;
+        atomicAdd(mc.n_acc, 1ull);
+    }
+    const int W = gridDim.x;
+    if (mc.samples) for (int i = 0; i < mc.d; ++i) mc.samples[((size_t)mc.row * W + w) * mc.d + i] = cur[mc.free_idx[i]];
+    if (mc.lps) mc.lps[(size_t)mc.row * W + w] = ok ? lp_prop : lp_cur;
+}
+
+// block-wide sum of one int per thread (all threads get the result)
+__device__ __forceinline__ int block_count(bool pred, int *s_cnt)
+{
+    const int tid = threadIdx.x;
+    const int c = __popcll(__ballot(pred));
+    __syncthreads();                       // s_cnt may still be read from the previous round
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int k = 0; k < B9_FIN_WAVES; ++k) t += s_cnt[k];
+    return t;
+}
+
 template <int NFP, int NPOPS>
 __global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStars st,
                                                               const IsoHdr *__restrict__ hdr,
@@ -694,65 +812,108 @@ __global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStar
                                                               const double *__restrict__ partial, int n_partial,
                                                               const double *__restrict__ params, DevPriors pr,
                                                               double *__restrict__ logpost,
-                                                              double *__restrict__ perstar)
+                                                              double *__restrict__ perstar, int axes_in_lds, McmcDev mc)
 {
-    __shared__ double s_red[B9_FIN_THREADS / 64];
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // WD axes (when axes_in_lds)
+    __shared__ double s_red[B9_FIN_WAVES];
+    __shared__ int s_cnt[B9_FIN_WAVES];
     const int w = blockIdx.x, tid = threadIdx.x;
     const double *par = params + (size_t)w * B9_NPARAM;
     IsoView<NFP> iso[NPOPS];
     double tip_min;
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
     const double lp = log_prior_cluster(pr, par, NPOPS);
+    // this walker's partials from the hot kernel: requested now, consumed at the end
+    double acc = 0.0;
+    for (int j = tid; j < n_partial; j += B9_FIN_THREADS) acc += partial[(size_t)w * n_partial + j];
     if (!valid || lp == NEG_INF) {
-        if (tid == 0) logpost[w] = NEG_INF;
-        // a finite-grid walker whose prior is -inf still has per-star values from k_star_like;
-        // the oracle reports -inf for them as well
+        if (tid == 0) { logpost[w] = NEG_INF; if (mc.enabled) metropolis_accept(mc, params, w, NEG_INF); }
+        // a walker inside the grid whose prior is -inf still has per-star values from the hot
+        // kernel; the oracle reports -inf for them as well
         if (perstar && valid)
             for (int i = tid; i < st.n; i += B9_FIN_THREADS) perstar[(size_t)w * st.n + i] = NEG_INF;
         return;
     }
-    // (1) heavy stars: the leading run of the descending-mass list with mass > tip_min
-    int count;
-    {
-        int lo = 0, hi = st.n;                     // first k with heavy_mass[k] <= tip_min
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (st.heavy_mass[mid] > tip_min) lo = mid + 1; else hi = mid;
+    // (1) heavy stars: count = first k with heavy_mass[k] <= tip_min, by a 512-ary search in
+    //     which every thread probes one point per round (two rounds for 50k stars)
+    int lo = 0, hi = st.n;
+    while (lo < hi) {
+        const int span = hi - lo, step = (span + B9_FIN_THREADS - 1) / B9_FIN_THREADS;
+        const int p = lo + tid * step;
+        const bool above = (p < hi) && (st.heavy_mass[p] > tip_min);
+        const int c = block_count(above, s_cnt);
+        if (c == 0) { hi = lo; }
+        else { const int nlo = lo + (c - 1) * step + 1, nhi = lo + c * step; lo = nlo; hi = nhi < hi ? nhi : hi; }
+    }
+    const int count = lo;
+    if (count > 0) {
+        WdAxes ax[NPOPS];
+        const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1;
+        const double *tip_src[NPOPS][4];     // each population brackets (FeH, Y) on its own
+        for (int k = 0; k < NPOPS; ++k)
+            for (int df = 0; df < 2; ++df) for (int dy = 0; dy < 2; ++dy)
+                tip_src[k][df * 2 + dy] = pk.tips + (size_t)((iso[k].i_feh + df) * pk.n_y + (iso[k].i_y + (dy < ny ? dy : 0))) * na;
+        if (axes_in_lds) {
+            double *d = smem;
+            const double *src[6] = {pk.log_age, pk.wc_log_age, pk.wc_mass, pk.wc_carb, pk.at_log_teff, pk.at_logg};
+            const int len[6] = {na, pk.n_wc_age, pk.n_wc_mass, pk.n_wc_carb, pk.n_at_teff, pk.n_at_logg};
+            const double *dst[6];
+            for (int a = 0; a < 6; ++a) {
+                dst[a] = d;
+                for (int j = tid; j < len[a]; j += B9_FIN_THREADS) d[j] = src[a][j];
+                d += len[a];
+            }
+            for (int k = 0; k < NPOPS; ++k)
+                for (int c = 0; c < 4; ++c) {
+                    for (int j = tid; j < na; j += B9_FIN_THREADS) d[j] = tip_src[k][c][j];
+                    ax[k].tips[c] = d;
+                    d += na;
+                }
+            __syncthreads();
+            for (int k = 0; k < NPOPS; ++k) {
+                ax[k].log_age = dst[0]; ax[k].wc_log_age = dst[1]; ax[k].wc_mass = dst[2]; ax[k].wc_carb = dst[3];
+                ax[k].at_log_teff = dst[4]; ax[k].at_logg = dst[5];
+            }
+        } else {
+            for (int k = 0; k < NPOPS; ++k) {
+                ax[k].log_age = pk.log_age;
+                for (int c = 0; c < 4; ++c) ax[k].tips[c] = tip_src[k][c];
+                ax[k].wc_log_age = pk.wc_log_age; ax[k].wc_mass = pk.wc_mass; ax[k].wc_carb = pk.wc_carb;
+                ax[k].at_log_teff = pk.at_log_teff; ax[k].at_logg = pk.at_logg;
+            }
         }
-        count = lo;
+        const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+        const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+        for (int j = tid; j < count; j += B9_FIN_THREADS) {
+            const int i = st.heavy_slot[j];
+            const double v = star_value<NFP, NPOPS>(pk, ax, iso, par, st, i, log_lam, log_1ml);
+            if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
+            acc += v;
+        }
     }
-    const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
-    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
-    double acc = 0.0;
-    for (int j = tid; j < count; j += B9_FIN_THREADS) {
-        const int i = st.heavy_slot[j];
-        const double v = star_value<NFP, NPOPS, true>(pk, iso, par, st, i, log_lam, log_1ml);
-        if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
-        acc += v;
-    }
-    // (2) partials of the hot kernel, strided over the block in a fixed order
-    for (int j = tid; j < n_partial; j += B9_FIN_THREADS) acc += partial[(size_t)w * n_partial + j];
+    // (2) fixed-order block sum of {hot-kernel partials, heavy stars}
     double sum = wave_sum(acc);
     if ((tid & 63) == 0) s_red[tid >> 6] = sum;
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < B9_FIN_THREADS / 64; ++k) t += s_red[k];
+        for (int k = 0; k < B9_FIN_WAVES; ++k) t += s_red[k];
         logpost[w] = lp + t;   // (3)
+        if (mc.enabled) metropolis_accept(mc, params, w, lp + t);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-hipError_t b9k_derive_iso(const DevPack &pk, const double *d_params, int n_walkers, int n_pops,
+hipError_t b9k_derive_iso(const DevPack &pk, double *d_params, int n_walkers, int n_pops,
                           IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap,
-                          hipStream_t stream)
+                          const McmcDev &mc, hipStream_t stream)
 {
-    const int split = pk.max_eep >= 128 ? 4 : 1;
-    hipLaunchKernelGGL(k_derive_iso, dim3(n_walkers * n_pops, split), dim3(256), 0, stream,
-                       pk, d_params, n_pops, hdr, iso_data, iso_stride, mass_cap);
+    const int gy = (mass_cap * (pk.nfp + 1) + 255) / 256;
+    hipLaunchKernelGGL(k_derive_iso, dim3(n_walkers * n_pops, gy), dim3(256), 0, stream,
+                       pk, d_params, n_pops, hdr, iso_data, iso_stride, mass_cap, mc);
     return hipGetLastError();
 }
 
@@ -785,10 +946,15 @@ static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const I
                                   const double *iso_data, long long iso_stride, int mass_cap,
                                   const double *partial, int n_partial, const double *d_params,
                                   const DevPriors &pr, int n_walkers, double *d_logpost, double *perstar,
-                                  hipStream_t stream)
+                                  const McmcDev &mc, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_finalize<NFP, NPOPS>), dim3(n_walkers), dim3(B9_FIN_THREADS), 0, stream, pk, st, hdr,
-                       iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, d_logpost, perstar);
+    const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
+    size_t lds = has_wd ? sizeof(double) * ((size_t)(1 + 4 * NPOPS) * pk.n_age + pk.n_wc_age + pk.n_wc_mass + pk.n_wc_carb +
+                                            pk.n_at_teff + pk.n_at_logg) : 0;
+    const int in_lds = has_wd && lds <= 48 * 1024;
+    if (!in_lds) lds = 0;
+    hipLaunchKernelGGL((k_finalize<NFP, NPOPS>), dim3(n_walkers), dim3(B9_FIN_THREADS), lds, stream, pk, st, hdr,
+                       iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, d_logpost, perstar, in_lds, mc);
     return hipGetLastError();
 }
 
@@ -818,9 +984,9 @@ hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 hipError_t b9k_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                         long long iso_stride, int mass_cap, const double *partial, int n_partial, int n_pops,
                         const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        double *perstar, hipStream_t stream)
+                        double *perstar, const McmcDev &mc, hipStream_t stream)
 {
-#define FN_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, n_walkers, d_logpost, perstar, stream
+#define FN_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, n_walkers, d_logpost, perstar, mc, stream
 #define FN2(NFP) launch_finalize<NFP, 2>(FN_ARGS)
 #define FN1(NFP) launch_finalize<NFP, 1>(FN_ARGS)
     B9_SWITCH_NFP(FN2, FN1)

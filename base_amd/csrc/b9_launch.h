@@ -2,9 +2,9 @@
 #pragma once
 #include "b9_device.h"
 
-hipError_t b9k_derive_iso(const DevPack &pk, const double *d_params, int n_walkers, int n_pops,
+hipError_t b9k_derive_iso(const DevPack &pk, double *d_params, int n_walkers, int n_pops,
                           IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap,
-                          hipStream_t stream);
+                          const McmcDev &mc, hipStream_t stream);
 
 size_t b9k_star_like_lds_bytes(int n_pops, int mass_cap);
 
@@ -17,4 +17,4 @@ hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 hipError_t b9k_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                         long long iso_stride, int mass_cap, const double *partial, int n_partial, int n_pops,
                         const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        double *perstar, hipStream_t stream);
+                        double *perstar, const McmcDev &mc, hipStream_t stream);

@@ -94,6 +94,30 @@ class Engine:
                                                C.c_void_p(d_logpost), C.c_void_p(d_perstar or None),
                                                C.c_void_p(stream or None)))
 
+    def mcmc_run_block(self, params, logpost, walker_ids, free, chol, seed, step0, n_steps, record=True):
+        """Device-resident Metropolis block (b9_mcmc_run_block).  Same contract as
+        mcmc.HostBlockRunner.run: returns (params, logpost, samples, lps, n_accept)."""
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, abi.B9_NPARAM).copy()
+        W, d = params.shape[0], len(free)
+        logpost = np.ascontiguousarray(logpost, dtype=np.float64).copy()
+        free_a = np.ascontiguousarray(free, dtype=np.int32)
+        ids = np.ascontiguousarray(walker_ids, dtype=np.int32)
+        chol_a = np.ascontiguousarray(chol, dtype=np.float64)
+        samples = np.empty((n_steps, W, d)) if record else None
+        lps = np.empty((n_steps, W)) if record else None
+        blk = abi.b9_mcmc_block()
+        blk.n_walkers, blk.n_free = W, d
+        blk.free_idx = free_a.ctypes.data_as(_ip)
+        blk.chol = chol_a.ctypes.data_as(_dp)
+        blk.walker_ids = ids.ctypes.data_as(_ip)
+        blk.seed, blk.step0, blk.n_steps = int(seed), int(step0), int(n_steps)
+        blk.params = params.ctypes.data_as(_dp)
+        blk.logpost = logpost.ctypes.data_as(_dp)
+        blk.samples = samples.ctypes.data_as(_dp) if record else None
+        blk.lps = lps.ctypes.data_as(_dp) if record else None
+        self._check(self.lib.b9_mcmc_run_block(self._ctx, C.byref(blk)))
+        return params, logpost, samples, lps, int(blk.n_accept)
+
     def derive_isochrone(self, param_row: np.ndarray, pop: int = 0, cap: int = 4096) -> Tuple[int, np.ndarray, np.ndarray, float]:
         row = np.ascontiguousarray(param_row, dtype=np.float64)
         mass = np.empty(cap)
@@ -112,8 +136,9 @@ class Engine:
     def max_eep(self) -> int:
         return int(self.lib.b9_max_eep(self._ctx))
 
-    def enable_timing(self, on: bool = True) -> None:
-        self._check(self.lib.b9_enable_timing(self._ctx, 1 if on else 0))
+    def enable_timing(self, every: int = 1) -> None:
+        """0/False: off; n: bracket every n-th launch of the dominant kernel with HIP events."""
+        self._check(self.lib.b9_enable_timing(self._ctx, int(every)))
 
     def kernel_time_ms(self, reset: bool = True) -> Tuple[float, int]:
         ms, n = C.c_double(0), C.c_int32(0)

@@ -1,21 +1,25 @@
 """Walker-parallel adaptive Metropolis over the HIP log-posterior (BASELINE.json north_star:
 "partition independent walkers/chains across the GPUs of one node with an RCCL all-gather of
-log-posteriors for the adaptive proposal step").
+log-posteriors over xGMI for the adaptive proposal step").
 
 Design (there is no reference counterpart -- the reference runs one chain on CPU
-threads [RECALL], "walkers" are a construct of the build contract):
+threads [RECALL]; "walkers" are a construct of the build contract):
 
   * W independent Metropolis chains ("walkers"); walker w lives on rank  w // (W / world).
-  * Every rank holds the full ensemble state (W x B9_NPARAM doubles -- a few KB) and draws ALL
-    walkers' proposals from counter-based per-walker Philox streams, so proposals are identical
-    on every rank and independent of the number of GPUs.
-  * Each rank evaluates only its own walkers' log-posteriors on its GPU (b9_logpost_device,
-    device-resident), then ONE collective per step -- an all-gather of the W log-posteriors
-    (RCCL over xGMI on GPUs; gloo in the CPU tests) -- gives every rank all of them.
-  * Accept/reject and the adaptive step (pooled proposal covariance over all walkers, as in
-    the reference's staged burn-in adaptation [RECALL]) are then replicated on every rank.
+  * Between adaptation points a walker needs nothing from any other walker: every rank advances
+    its own walkers for `block` steps with no communication at all (on a GPU the whole block is
+    device-resident: see DeviceBlockRunner).
+  * At the adaptive-proposal step -- once per block -- every rank contributes one row per local
+    walker, [log-posterior, position, block moments], to ONE all-gather (RCCL over xGMI on
+    GPUs, gloo in the CPU tests).  Every rank then pools the rows in walker order and derives the
+    same proposal covariance (adaptive Metropolis, 2.38^2/d scaling), as the reference's staged
+    burn-in adaptation does for its single chain [RECALL].
+  * Random numbers are counter-based (Philox4x32-10, key = seed, counter = (step, walker, draw)):
+    a walker's chain is the same whatever the number of ranks, and the device runner reproduces
+    the host reference draw for draw.
 
-The only data-path traffic between GPUs is that 8*W-byte all-gather; it is latency-bound.
+The all-gather moves (15 + 2d + d^2) doubles per walker per block -- a few hundred bytes; it is
+latency-bound, and amortised over `block` steps.
 """
 from __future__ import annotations
 
@@ -26,151 +30,218 @@ import numpy as np
 from . import abi
 
 DEFAULT_FREE = (abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS)
-DEFAULT_STEP = {abi.P_LOGAGE: 0.005, abi.P_Y: 0.003, abi.P_FEH: 0.01, abi.P_MOD: 0.005, abi.P_ABS: 0.003,
-                abi.P_CARBONICITY: 0.01, abi.P_IFMR_INTERCEPT: 0.005, abi.P_IFMR_SLOPE: 0.005,
-                abi.P_IFMR_QUAD: 0.002, abi.P_Y2: 0.003, abi.P_LAMBDA: 0.01}
+DEFAULT_STEP = {abi.P_LOGAGE: 5e-4, abi.P_Y: 3e-4, abi.P_FEH: 1e-3, abi.P_MOD: 5e-4, abi.P_ABS: 3e-4,
+                abi.P_CARBONICITY: 1e-3, abi.P_IFMR_INTERCEPT: 5e-4, abi.P_IFMR_SLOPE: 5e-4,
+                abi.P_IFMR_QUAD: 2e-4, abi.P_Y2: 3e-4, abi.P_LAMBDA: 1e-3}
+
+# ------------------------------------------------------------------------------------------
+# Philox4x32-10 (Salmon et al. 2011), vectorised; the device runner implements the same function
+# ------------------------------------------------------------------------------------------
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
 
 
-class Ensemble:
-    """Replicated ensemble state + proposal machinery (pure numpy; identical on every rank)."""
+def philox4x32(c0, c1, c2, c3, k0, k1):
+    """10 rounds; all arguments uint32 arrays (broadcastable).  Returns four uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint32) for x in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint32(k0); k1 = np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = c0.astype(np.uint64) * _M0
+            p1 = c2.astype(np.uint64) * _M1
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & _MASK).astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & _MASK).astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32(k0 + _W0); k1 = np.uint32(k1 + _W1)
+    return c0, c1, c2, c3
 
-    def __init__(self, start: np.ndarray, free: Sequence[int] = DEFAULT_FREE, seed: int = 1234,
-                 adapt_start: int = 200, adapt_every: int = 100, step_sizes: Optional[dict] = None):
-        self.params = np.ascontiguousarray(start, dtype=np.float64).reshape(-1, abi.B9_NPARAM).copy()
-        self.n_walkers = self.params.shape[0]
+
+def _u01(hi, lo):
+    """(0,1) double from two uint32: 53 random bits, never 0 or 1."""
+    x = (hi.astype(np.uint64) >> np.uint64(5)) * np.uint64(1 << 26) + (lo.astype(np.uint64) >> np.uint64(6))
+    return (x.astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def draws(seed: int, step: int, walkers: np.ndarray, d: int):
+    """Standard normals z[len(walkers), d] and uniforms u[len(walkers)] for one step."""
+    walkers = np.asarray(walkers, dtype=np.uint32)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    s_lo, s_hi = np.uint32(step & 0xFFFFFFFF), np.uint32((step >> 32) & 0xFFFFFFFF)
+    z = np.empty((len(walkers), d))
+    n_pairs = (d + 1) // 2
+    for j in range(n_pairs):                         # Box-Muller, one Philox call per pair
+        r = philox4x32(s_lo, s_hi, walkers, np.uint32(j), k0, k1)
+        u1, u2 = _u01(r[0], r[1]), _u01(r[2], r[3])
+        rad = np.sqrt(-2.0 * np.log(u1))
+        z[:, 2 * j] = rad * np.cos(2.0 * np.pi * u2)
+        if 2 * j + 1 < d:
+            z[:, 2 * j + 1] = rad * np.sin(2.0 * np.pi * u2)
+    r = philox4x32(s_lo, s_hi, walkers, np.uint32(n_pairs), k0, k1)
+    return z, _u01(r[0], r[1])
+
+
+# ------------------------------------------------------------------------------------------
+# block runners: advance the LOCAL walkers `n_steps` steps with a fixed proposal factor
+# ------------------------------------------------------------------------------------------
+class HostBlockRunner:
+    """Reference runner: proposals and accept/reject in numpy, log-posteriors from `evaluate`
+    (the CPU oracle in tests, or the GPU engine's synchronous logpost)."""
+
+    def __init__(self, evaluate: Callable[[np.ndarray], np.ndarray]):
+        self.evaluate = evaluate
+
+    def run(self, params, logpost, walker_ids, free, chol, seed, step0, n_steps):
+        """Returns (params, logpost, samples[n_steps, Wl, d], lps[n_steps, Wl], n_accept)."""
+        params, logpost = params.copy(), logpost.copy()
+        d = len(free)
+        samples = np.empty((n_steps, len(walker_ids), d))
+        lps = np.empty((n_steps, len(walker_ids)))
+        n_acc = 0
+        for s in range(n_steps):
+            z, u = draws(seed, step0 + s, walker_ids, d)
+            prop = params.copy()
+            delta = np.zeros_like(z)                 # delta_i = sum_j chol[i, j] z_j, j ascending,
+            for j in range(d):                       # plain multiply-add: the device does the same
+                delta = delta + chol[None, :, j] * z[:, j:j + 1]
+            prop[:, free] += delta
+            lp = np.asarray(self.evaluate(prop), dtype=np.float64)
+            with np.errstate(invalid="ignore"):
+                ok = (np.log(u) < lp - logpost) & np.isfinite(lp)
+            params[ok] = prop[ok]
+            logpost[ok] = lp[ok]
+            n_acc += int(ok.sum())
+            samples[s] = params[:, free]
+            lps[s] = logpost
+        return params, logpost, samples, lps, n_acc
+
+
+class DeviceBlockRunner:
+    """The whole block on the GPU (b9_mcmc_run_block): per step three launches -- proposal +
+    isochrone, star likelihood, finalize + accept -- and no host round trip until the block ends."""
+
+    def __init__(self, engine, record: bool = True):
+        self.engine, self.record = engine, record
+
+    def run(self, params, logpost, walker_ids, free, chol, seed, step0, n_steps):
+        return self.engine.mcmc_run_block(params, logpost, walker_ids, free, chol, seed, step0, n_steps, self.record)
+
+
+class WalkerSampler:
+    """W walkers sharded over `world` ranks; one all-gather per adaptation block."""
+
+    def __init__(self, start: np.ndarray, runner, rank: int = 0, world: int = 1,
+                 all_gather: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+                 free: Sequence[int] = DEFAULT_FREE, seed: int = 1234, block: int = 50,
+                 step_sizes: Optional[dict] = None, adapt: bool = True):
+        start = np.ascontiguousarray(start, dtype=np.float64).reshape(-1, abi.B9_NPARAM)
+        self.n_walkers = start.shape[0]
+        if self.n_walkers % world:
+            raise ValueError("the number of walkers must be a multiple of the number of ranks")
+        self.rank, self.world, self.runner = rank, world, runner
+        self.per = self.n_walkers // world
+        self.ids = np.arange(rank * self.per, (rank + 1) * self.per)
         self.free = np.array(list(free), dtype=np.int64)
         self.d = len(self.free)
-        self.logpost = np.full(self.n_walkers, -np.inf)
-        self.step = 0
+        self.seed, self.block, self.adapt = seed, block, adapt
         ss = dict(DEFAULT_STEP)
         if step_sizes:
             ss.update(step_sizes)
-        self.chol = np.diag([ss[int(k)] for k in self.free])
-        self.adapt_start, self.adapt_every = adapt_start, adapt_every
-        # one counter-based stream per walker: the same draws whatever the rank layout
-        self.rng = [np.random.Generator(np.random.Philox(key=[seed, w])) for w in range(self.n_walkers)]
-        # running pooled moments of the accepted states (for the adaptive covariance)
-        self.n_mom = 0
-        self.mean = np.zeros(self.d)
-        self.m2 = np.zeros((self.d, self.d))
+        self.chol = np.diag([ss[int(k)] for k in self.free]).astype(np.float64)
+        self.scale = 1.0                              # global step scale, steered by the pooled acceptance
+        self.params = start[self.ids].copy()          # local walkers only
+        self.logpost = np.full(self.per, -np.inf)
+        self.all_params = start.copy()                # refreshed at every gather
+        self.all_logpost = np.full(self.n_walkers, -np.inf)
+        self.step = 0
         self.accepted = 0
-        self._prop = self.params.copy()
-        self._u = np.zeros(self.n_walkers)
+        self._gather = all_gather
+        # pooled running moments over all walkers and all blocks (Chan et al. pairwise update)
+        self.n_mom, self.mean, self.m2 = 0, np.zeros(self.d), np.zeros((self.d, self.d))
 
-    def propose(self) -> np.ndarray:
-        z = np.empty((self.n_walkers, self.d))
-        for w, g in enumerate(self.rng):
-            z[w] = g.standard_normal(self.d)
-            self._u[w] = g.random()
-        self._prop[:] = self.params
-        self._prop[:, self.free] += z @ self.chol.T
-        return self._prop
+    # -- collectives ------------------------------------------------------------------------
+    def gather_rows(self, rows: np.ndarray) -> np.ndarray:
+        """rows[per, k] on every rank -> [n_walkers, k] in walker order."""
+        if self.world == 1:
+            return rows.copy()
+        return self._gather(rows)
 
-    def accept(self, logpost_prop: np.ndarray) -> np.ndarray:
-        with np.errstate(invalid="ignore"):
-            ok = np.log(self._u) < (logpost_prop - self.logpost)
-        ok &= np.isfinite(logpost_prop)
-        self.params[ok] = self._prop[ok]
-        self.logpost[ok] = logpost_prop[ok]
-        self.accepted += int(ok.sum())
-        self.step += 1
-        # pooled running covariance (Welford, one update per walker per step)
-        x = self.params[:, self.free]
-        for w in range(self.n_walkers):
-            self.n_mom += 1
-            dlt = x[w] - self.mean
-            self.mean += dlt / self.n_mom
-            self.m2 += np.outer(dlt, x[w] - self.mean)
-        if self.step >= self.adapt_start and self.step % self.adapt_every == 0 and self.n_mom > 10 * self.d:
-            cov = self.m2 / (self.n_mom - 1)
-            cov = cov * (2.38 ** 2 / self.d) + 1e-12 * np.eye(self.d)
+    # -- driver -----------------------------------------------------------------------------
+    def initialise(self, evaluate: Callable[[np.ndarray], np.ndarray]) -> None:
+        self.logpost = np.asarray(evaluate(self.params), dtype=np.float64).copy()
+        rows = self.gather_rows(np.concatenate([self.logpost[:, None], self.params], axis=1))
+        self.all_logpost, self.all_params = rows[:, 0].copy(), rows[:, 1:].copy()
+
+    def run_block(self, n_steps: Optional[int] = None):
+        n = self.block if n_steps is None else n_steps
+        self.params, self.logpost, samples, lps, n_acc = self.runner.run(
+            self.params, self.logpost, self.ids, self.free, self.scale * self.chol, self.seed, self.step, n)
+        self.step += n
+        self.accepted += n_acc
+        # one row per local walker: [lp, full position, #moves, n, sum x, sum x x^T] over the block
+        x = samples                                               # [n, per, d]
+        moved = (np.abs(np.diff(np.concatenate([x[:1] * np.nan, x]), axis=0)).sum(axis=2) > 0)[1:].sum(axis=0)
+        row = np.concatenate([self.logpost[:, None], self.params, moved[:, None].astype(np.float64),
+                              np.full((self.per, 1), float(n)), x.sum(axis=0),
+                              np.einsum("swi,swj->wij", x, x).reshape(self.per, -1)], axis=1)
+        rows = self.gather_rows(row)                              # THE collective of the block
+        self.all_logpost = rows[:, 0].copy()
+        self.all_params = rows[:, 1:1 + abi.B9_NPARAM].copy()
+        if self.adapt:
+            # pooled fraction of steps (after the block's first) on which a walker moved
+            rate = rows[:, 1 + abi.B9_NPARAM].sum() / max(1.0, self.n_walkers * (n - 1.0))
+            if n > 4:
+                self.scale *= 0.5 if rate < 0.10 else (0.8 if rate < 0.20 else (1.5 if rate > 0.50 else (1.2 if rate > 0.35 else 1.0)))
+            self._adapt(rows[:, 2 + abi.B9_NPARAM:])
+        return samples, lps
+
+    def _adapt(self, mom: np.ndarray) -> None:
+        d = self.d
+        for w in range(self.n_walkers):                           # fixed walker order on every rank
+            n_b, s1, s2 = mom[w, 0], mom[w, 1:1 + d], mom[w, 1 + d:].reshape(d, d)
+            mean_b = s1 / n_b
+            m2_b = s2 - n_b * np.outer(mean_b, mean_b)
+            tot = self.n_mom + n_b
+            dlt = mean_b - self.mean
+            self.m2 += m2_b + np.outer(dlt, dlt) * (self.n_mom * n_b / tot)
+            self.mean += dlt * (n_b / tot)
+            self.n_mom = tot
+        if self.n_mom > 20 * d:
+            cov = self.m2 / (self.n_mom - 1) * (2.38 ** 2 / d)
+            scale = np.sqrt(np.maximum(np.diag(cov), 1e-300))
+            cov = cov + np.diag((1e-6 * scale) ** 2)              # keep it positive definite
             try:
                 self.chol = np.linalg.cholesky(cov)
             except np.linalg.LinAlgError:
                 pass
-        return ok
-
-
-class WalkerSampler:
-    """Drives an Ensemble with a log-posterior evaluator sharded over torch.distributed ranks.
-
-    `evaluate_local(params_local) -> logpost_local` is either the GPU path (DeviceEvaluator) or,
-    in the gloo CPU tests, any callable on numpy arrays.
-    """
-
-    def __init__(self, ensemble: Ensemble, evaluate_local: Callable, rank: int = 0, world: int = 1,
-                 gather: Optional[Callable] = None):
-        if ensemble.n_walkers % world:
-            raise ValueError("the number of walkers must be a multiple of the number of ranks")
-        self.ens, self.rank, self.world = ensemble, rank, world
-        self.per = ensemble.n_walkers // world
-        self.lo, self.hi = rank * self.per, (rank + 1) * self.per
-        self.evaluate_local = evaluate_local
-        self.gather = gather
-
-    def initialise(self) -> None:
-        self.ens.logpost[:] = self._eval(self.ens.params)
-
-    def _eval(self, params_all: np.ndarray) -> np.ndarray:
-        local = self.evaluate_local(params_all[self.lo:self.hi])
-        if self.world == 1:
-            return np.asarray(local, dtype=np.float64).copy()
-        return self.gather(local)
-
-    def step(self) -> np.ndarray:
-        prop = self.ens.propose()
-        lp = self._eval(prop)
-        return self.ens.accept(lp)
 
     def run(self, n_steps: int, record: Optional[List] = None) -> None:
-        for _ in range(n_steps):
-            self.step()
+        done = 0
+        while done < n_steps:
+            n = min(self.block, n_steps - done)
+            samples, lps = self.run_block(n)
             if record is not None:
-                record.append((self.ens.params.copy(), self.ens.logpost.copy()))
+                record.append((samples, lps))
+            done += n
 
 
-class DeviceEvaluator:
-    """GPU evaluation of the local walkers + RCCL all-gather, all on torch's current stream.
+# ------------------------------------------------------------------------------------------
+# torch.distributed plumbing
+# ------------------------------------------------------------------------------------------
+def torch_all_gather(device: Optional[str] = None) -> Callable[[np.ndarray], np.ndarray]:
+    """all-gather of equally shaped float64 rows through torch.distributed (nccl = RCCL on a
+    GPU build, gloo on CPU).  With `device` the rows travel through a device tensor."""
+    import torch
+    import torch.distributed as dist
 
-    torch is plumbing here: it owns the device buffers and the process group; the numbers come
-    from b9_logpost_device (hand-written HIP behind the C ABI).
-    """
+    def gather(rows: np.ndarray) -> np.ndarray:
+        world = dist.get_world_size()
+        t = torch.from_numpy(np.ascontiguousarray(rows))
+        if device:
+            t = t.to(device)
+        out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy()
 
-    def __init__(self, engine, n_local: int, world: int = 1, device: Optional[int] = None):
-        import torch
-        self.torch = torch
-        self.engine = engine
-        self.world = world
-        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        self.h_params = torch.empty((n_local, abi.B9_NPARAM), dtype=torch.float64).pin_memory()
-        self.d_params = torch.empty((n_local, abi.B9_NPARAM), dtype=torch.float64, device=dev)
-        self.d_local = torch.empty(n_local, dtype=torch.float64, device=dev)
-        self.d_all = torch.empty(n_local * world, dtype=torch.float64, device=dev)
-        self.h_all = torch.empty(n_local * world, dtype=torch.float64).pin_memory()
-        self.n_local = n_local
-
-    def evaluate_and_gather(self, params_local: np.ndarray) -> np.ndarray:
-        torch = self.torch
-        self.h_params.numpy()[:] = params_local
-        self.d_params.copy_(self.h_params, non_blocking=True)
-        stream = torch.cuda.current_stream().cuda_stream
-        self.engine.logpost_device(self.d_params.data_ptr(), self.n_local, self.d_local.data_ptr(), 0, stream)
-        if self.world > 1:
-            torch.distributed.all_gather_into_tensor(self.d_all, self.d_local)
-            src = self.d_all
-        else:
-            src = self.d_local
-        self.h_all.copy_(src, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        return self.h_all.numpy().copy()
-
-
-def make_device_sampler(engine, start: np.ndarray, rank: int, world: int, **ens_kw) -> WalkerSampler:
-    ens = Ensemble(start, **ens_kw)
-    per = ens.n_walkers // world
-    ev = DeviceEvaluator(engine, per, world)
-    s = WalkerSampler(ens, ev.evaluate_and_gather, rank, world, gather=lambda x: x)
-    # evaluate_and_gather already returns the gathered vector; bypass the second gather
-    s._eval = lambda params_all: ev.evaluate_and_gather(params_all[s.lo:s.hi])   # noqa: E731
-    s.evaluator = ev
-    return s
+    return gather

@@ -7,9 +7,10 @@ Workload (BASELINE.json metric: "star-likelihood evals/sec ... on synthetic 50k-
 clusters at 1 GPU, with 1/2/4/8-GPU walker-parallel throughput"; configs[2] sharded 8 ways):
 50 000 stars x 8 filters, PARSEC-shaped synthetic pack, 8 walkers per GPU (weak scaling: 64
 walkers at 8 GPUs).  One "step" is one adaptive-Metropolis step of every walker: propose ->
-log-posterior of the rank's walkers on its GPU (three HIP launches behind the C ABI) -> one
-RCCL all-gather of the log-posteriors -> accept/reject + adaptation.  Star data and model
-tables are resident in HBM before the timed region starts.
+log-posterior of the rank's walkers -> accept/reject, all on the GPU (three HIP launches behind
+the C ABI, b9_mcmc_run_block); every 50 steps the ranks exchange one RCCL all-gather of
+per-walker rows and re-derive the pooled proposal covariance.  Star data and model tables are
+resident in HBM before the timed region starts.
 
 value     = n_stars x total walkers x K / max-over-ranks wall time   (whole job, all GPUs)
 roofline  = the dominant kernel (k_star_like): algorithmic bytes per launch / its mean launch
@@ -33,6 +34,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 N_STARS, N_FILT, WALKERS_PER_GPU = 50000, 8, 8
+TIMING_EVERY = 8        # HIP-event bracket on every 8th launch of the dominant kernel in the timed region
 
 
 def cpu_baseline(pack_d, cl, truth, budget_s: float = 12.0):
@@ -67,9 +69,10 @@ def cpu_baseline(pack_d, cl, truth, budget_s: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the HIP-event bracketing of k_star_like")
     args = ap.parse_args()
 
     import torch
@@ -94,27 +97,29 @@ def main():
     priors, options = synth.default_priors(pack_d, truth), abi.make_options()
     eng = engine.Engine(pack, stars, priors, options, device=local_rank)
     n_walkers = WALKERS_PER_GPU * world
-    start = synth.walker_params(truth, n_walkers, seed=42)
-    sampler = mcmc.make_device_sampler(eng, start, rank, world, seed=2024)
-    sampler.initialise()
+    start = synth.walker_params(truth, n_walkers, seed=42, scale=0.02)
+    gather = mcmc.torch_all_gather("cuda") if world > 1 else None
+    block = 50
+    sampler = mcmc.WalkerSampler(start, mcmc.DeviceBlockRunner(eng, record=True), rank, world, gather,
+                                 seed=2024, block=block)
+    sampler.initialise(eng.logpost)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sampler.step()
-    eng.enable_timing(True)
+    sampler.run(args.warmup)
+    acc0 = sampler.accepted
+    eng.enable_timing(0 if args.no_kernel_timing else TIMING_EVERY)
     eng.kernel_time_ms(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sampler.step()
+    sampler.run(args.steps)             # exactly K steps, in device-resident blocks of <= 50
     barrier()
     dt = time.perf_counter() - t0
     k_ms, k_n = eng.kernel_time_ms(reset=True)
-    eng.enable_timing(False)
+    eng.enable_timing(0)
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -137,12 +142,14 @@ def main():
                                    "(10 FeH x 60 ages x 400 EEPs), given-mass mode, 8 walkers per GPU",
                        "n_stars": N_STARS, "n_filters": N_FILT, "walkers_per_gpu": WALKERS_PER_GPU,
                        "walkers_total": n_walkers, "parallelism": f"walkers{world}",
-                       "collective": "all_gather(logpost) per step" if world > 1 else "none"},
+                       "mcmc_block": block,
+                       "collective": "one all_gather of [logpost, position, moments] rows per 50-step block" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_star_like", "launches": k_n, "avg_launch_us": 1e6 * k_avg_s,
+                         "kernel": "k_star_like", "launches_timed": k_n, "timed_every": TIMING_EVERY,
+                         "avg_launch_us": 1e6 * k_avg_s,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_star_eval": bytes_eval},
-            "accept_rate": sampler.ens.accepted / float(n_walkers * (args.steps + args.warmup)),
+            "accept_rate": (sampler.accepted - acc0) / float(WALKERS_PER_GPU * args.steps),
             "parity": "vs this repo's CPU oracle (BASE-9 parity unpinned: reference source not mounted)",
         }
         if world == 1 and not args.no_cpu_baseline:

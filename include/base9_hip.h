@@ -187,6 +187,33 @@ int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers,
                       double *d_logpost, double *d_perstar, void *stream);
 
 /*
+ * Device-resident Metropolis block: advances the n_walkers local chains n_steps steps without
+ * returning to the host between steps (SURVEY 8f row 1 -- the per-step caller of the hot path;
+ * [RECALL] the body of MpiMcmcApplication's sampling loop: propose from the adapted covariance,
+ * logPost, accept/reject).  Per step and walker w: z ~ N(0, I_d) and u ~ U(0,1) from the
+ * counter-based stream Philox4x32-10(key = seed, counter = (step, walker_ids[w], draw));
+ * proposal = current, proposal[free_idx[i]] += sum_j chol[i*d+j] z_j; accepted when
+ * log u < logpost(proposal) - logpost(current).  All pointers are HOST pointers; params and
+ * logpost are updated in place; samples ([n_steps][n_walkers][n_free]) and lps
+ * ([n_steps][n_walkers]) receive the chain and may be NULL.  Synchronous.
+ */
+typedef struct b9_mcmc_block {
+    int32_t n_walkers, n_free;
+    const int32_t *free_idx;     /* [n_free] parameter indices being sampled                  */
+    const double *chol;          /* [n_free*n_free] row-major proposal factor                 */
+    const int32_t *walker_ids;   /* [n_walkers] global walker ids (random-number streams)     */
+    uint64_t seed;
+    int64_t step0;               /* global number of the block's first step                   */
+    int32_t n_steps, reserved;
+    double *params;              /* [n_walkers*B9_NPARAM] in/out                              */
+    double *logpost;             /* [n_walkers] in/out                                        */
+    double *samples;             /* out, nullable                                             */
+    double *lps;                 /* out, nullable                                             */
+    int64_t n_accept;            /* out                                                       */
+} b9_mcmc_block;
+int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk);
+
+/*
  * Derive the isochrone for one parameter row ([RECALL]
  * MsRgbModel::deriveIsochrone; this is all that makeCMD needs).  Outputs, host:
  * out_mass[cap], out_mags[cap*n_filt] (absolute magnitudes, no modulus/absorption),
@@ -202,9 +229,10 @@ int b9_max_eep(const b9_ctx *ctx);           /* longest isochrone in the loaded 
 int b9_device_id(const b9_ctx *ctx);
 /* Algorithmic bytes one star-eval moves in the loaded layout ("bytes per unit"). */
 int b9_bytes_per_star_eval(const b9_ctx *ctx);
-/* Elapsed ms of the dominant (star-likelihood) kernel over the launches since the last call
- * with reset != 0, measured with HIP events on the launch stream; *n_launches receives the
- * count.  Timing is only recorded after b9_enable_timing(ctx, 1).                         */
+/* Elapsed ms of the dominant (star-likelihood) kernel over the TIMED launches since the last
+ * call with reset != 0, measured with HIP events on the launch stream; *n_launches receives
+ * their count.  b9_enable_timing(ctx, n): n = 0 off, n > 0 brackets every n-th launch
+ * (n = 1: all of them; each bracket costs the host two hipEventRecord calls).              */
 int b9_enable_timing(b9_ctx *ctx, int on);
 int b9_kernel_time_ms(b9_ctx *ctx, int reset, double *total_ms, int32_t *n_launches);
 

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz -- small input/output vectors for the hot path.
+
+PROVENANCE: the reference (BASE-9) source is not mounted (/root/reference holds only a redirect
+README), so these vectors are NOT reference outputs.  They are produced by this repo's CPU oracle
+(oracle/b9_oracle.c) after it has been cross-checked against the independent numpy statement in
+tests/numpy_ref.py, and they pin both the oracle and the HIP path against regressions.
+"BASE-9 parity unpinned" applies to them as to everything else.
+
+    python tests/golden/make_golden.py        # rewrites the fixtures
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import oracle  # noqa: E402
+from base_amd import abi, synth  # noqa: E402
+
+CASES = {
+    # name: (pack, n_filt, n_stars, wd_frac, n_y, n_pops, pack kwargs)
+    "c0_girardi_3f_200": ("girardi", 3, 200, 0.0, 1, 1, dict(n_feh=4, n_age=8, n_eep=60)),
+    "c1_dsed_8f_300": ("dsed", 8, 300, 0.0, 1, 1, dict(n_feh=4, n_age=8, n_eep=60)),
+    "c3_parsec_8f_wd_300": ("parsec", 8, 300, 0.1, 1, 1, dict(n_feh=4, n_age=8, n_eep=60)),
+    "c4_parsec_8f_2pop_300": ("parsec", 8, 300, 0.05, 3, 2, dict(n_feh=3, n_age=6, n_eep=50)),
+}
+PACK_KEYS = ["feh", "y", "log_age", "iso_first_eep", "iso_n_eep", "iso_offset", "mass", "mags", "abs_coeff",
+             "wc_carb", "wc_mass", "wc_log_age", "wc_log_teff", "wc_log_radius", "at_logg", "at_log_teff", "at_mags"]
+STAR_KEYS = ["obs", "sigma", "mass1", "mass_ratio", "clust_prior", "stage", "wd_type", "filter_prior_min", "filter_prior_max"]
+
+
+def main():
+    for name, (pk, nf, ns, wd, ny, npops, kw) in CASES.items():
+        pack_d = synth.make_pack(pk, n_filt=nf, n_y=ny, **kw)
+        truth = synth.default_params(pack_d)
+        cl = synth.make_cluster(pack_d, ns, seed=9001, truth=truth, wd_frac=wd, n_pops=npops)
+        pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
+        priors = synth.default_priors(pack_d, truth, npops)
+        options = abi.make_options(n_pops=npops)
+        params = synth.walker_params(truth, 4, n_pops=npops)
+        params[3, abi.P_FEH] = pack_d["feh"][-1] + 0.5     # one row outside the grid
+        lp, ps = oracle.Oracle(pack, stars, priors, options).logpost(params, perstar=True)
+        iso = oracle.derive_isochrone(oracle.load(), pack, params[0])
+        out = {f"pack_{k}": np.asarray(pack_d[k]) for k in PACK_KEYS}
+        out.update({f"star_{k}": np.asarray(cl[k]) for k in STAR_KEYS})
+        out.update(pack_n_filt=nf, pack_ifmr_id=pack_d["ifmr_id"], pack_m_wd_up=pack_d["m_wd_up"], pack_n_at_type=2,
+                   n_pops=npops, prior_mean=np.array(list(priors.mean)), prior_var=np.array(list(priors.var)),
+                   prior_age=np.array([priors.log_age_min, priors.log_age_max]),
+                   params=params, logpost=lp, perstar=ps,
+                   iso_first=iso[0], iso_mass=iso[1], iso_mags=iso[2], iso_tip=iso[3])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, lp)
+
+
+if __name__ == "__main__":
+    main()

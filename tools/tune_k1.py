@@ -28,7 +28,7 @@ for name, tpb, lds in plans:
     for _ in range(20):
         eng.logpost_device(d_params.data_ptr(), n_walkers, d_out.data_ptr(), 0, stream)
     torch.cuda.synchronize()
-    eng.enable_timing(True); eng.kernel_time_ms(True)
+    eng.enable_timing(1); eng.kernel_time_ms(True)
     t0 = time.perf_counter()
     for _ in range(200):
         eng.logpost_device(d_params.data_ptr(), n_walkers, d_out.data_ptr(), 0, stream)
