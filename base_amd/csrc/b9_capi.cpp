@@ -61,6 +61,7 @@ struct b9_ctx {
 
     // launch plan
     int tiles_per_block = 0;   // 0 = auto
+    int walkers_per_lane = 1;  // WB template parameter of k_star_like (1 or 2)
 
     // timing of the dominant kernel
     int timing = 0;            // 0 off, n > 0: bracket every n-th launch of the dominant kernel with events
@@ -133,10 +134,9 @@ double log_prior_mass(double lmn, double m)
 
 // (Re)build the device star arrays.  Layout (DESIGN.md "Data layout"): singles and binaries are
 // each sorted by primary mass and cut into 64-star chunks (one wave each, so a wave never mixes
-// the two kinds and neighbouring lanes search neighbouring isochrone rows); the chunks of the two
-// kinds are then interleaved in proportion, so every 256-star workgroup carries the same mix of
-// cheap (single) and expensive (binary) waves.  Unused slots of a partial chunk and the tail
-// padding hold mass1 = +inf (skipped by the hot kernel) and perm = -1.
+// the two kinds and neighbouring lanes search neighbouring isochrone rows); binary chunks come
+// first.  Unused slots of a partial chunk and the tail padding hold mass1 = +inf (skipped by the
+// hot kernel) and perm = -1.
 int build_stars(b9_ctx *ctx)
 {
     const HostStars &h = ctx->hs;
@@ -154,27 +154,20 @@ int build_stars(b9_ctx *ctx)
     for (int i = 0; i < n; ++i) if (!(h.q[order[i]] > 0.0)) n_single = i + 1;
     const int cs = (n_single + 63) / 64, cb = (n - n_single + 63) / 64, ct = cs + cb;
     const int n_pad = std::max(256, (ct * 64 + 255) / 256 * 256);
-    // slot -> star (or -1): proportional interleave of the two chunk kinds
+    // slot -> star (or -1): all binary chunks, then all single chunks.  Workgroups are dispatched
+    // in slot order, so the expensive binary waves start first and the kernel's tail consists of
+    // cheap single-star waves.
     std::vector<int> slot(n_pad, -1);
-    {
-        int us = 0, ub = 0;
-        for (int c = 0; c < ct; ++c) {
-            // binary chunk when the binaries are behind their share (expensive chunks lead)
-            bool take_b = (ub < cb) && ((long long)(ub) * ct <= (long long)c * cb || us >= cs);
-            if (take_b) {
-                for (int j = 0; j < 64; ++j) { int k = n_single + ub * 64 + j; if (k < n) slot[c * 64 + j] = order[k]; }
-                ++ub;
-            } else {
-                for (int j = 0; j < 64; ++j) { int k = us * 64 + j; if (k < n_single) slot[c * 64 + j] = order[k]; }
-                ++us;
-            }
-        }
-    }
+    for (int cb_i = 0; cb_i < cb; ++cb_i)
+        for (int j = 0; j < 64; ++j) { int k = n_single + cb_i * 64 + j; if (k < n) slot[cb_i * 64 + j] = order[k]; }
+    for (int cs_i = 0; cs_i < cs; ++cs_i)
+        for (int j = 0; j < 64; ++j) { int k = cs_i * 64 + j; if (k < n_single) slot[(cb + cs_i) * 64 + j] = order[k]; }
+    (void)ct;
     double log_fs = 0.0;
     for (int f = 0; f < nf; ++f) log_fs -= std::log(h.fmax[f] - h.fmin[f]);
 
     std::vector<double> obs((size_t)nfp * n_pad, 0.0), w((size_t)nfp * n_pad, 0.0);
-    std::vector<double> mass1(n_pad, INFINITY), q(n_pad, 0.0), c0(n_pad, 0.0), c0m(n_pad, 0.0), la(n_pad, -INFINITY);
+    std::vector<double> mass1(n_pad, INFINITY), q(n_pad, 0.0), c0(n_pad, 0.0), c0m(n_pad, 0.0), la(n_pad, -INFINITY), ea(n_pad, 0.0);
     std::vector<int> flags(n_pad, 0), permp(n_pad, -1);
     for (int i = 0; i < n_pad; ++i) {
         const int s = slot[i];
@@ -195,6 +188,7 @@ int build_stars(b9_ctx *ctx)
         c0m[i] = std::log(pm) + g;
         c0[i] = std::log(pm) + (log_prior_mass(ctx->pk.log_mass_norm, h.mass1[s]) + g);
         la[i] = std::log1p(-pm) + log_fs;
+        ea[i] = std::exp(la[i]);
         flags[i] = (h.wd_type[s] > 0 ? 1 : 0) | (h.stage[s] << 8);
         permp[i] = s;
     }
@@ -217,6 +211,7 @@ int build_stars(b9_ctx *ctx)
     if ((rc = upload(ctx, ctx->star_allocs, c0.data(), c0.size(), &st.c0))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, c0m.data(), c0m.size(), &st.c0m))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, la.data(), la.size(), &st.la))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, ea.data(), ea.size(), &st.ea))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, flags.data(), flags.size(), &st.flags))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, permp.data(), permp.size(), &st.perm))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, heavy_mass.data(), heavy_mass.size(), &st.heavy_mass))) return rc;
@@ -311,6 +306,7 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     for (int k = 0; k < 12; ++k) { ctx->pr.mean[k] = 0.0; ctx->pr.var[k] = 0.0; }
     ctx->pr.log_age_min = -INFINITY; ctx->pr.log_age_max = INFINITY;
     if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
+    if (const char *s = getenv("B9_WALKERS_PER_LANE")) ctx->walkers_per_lane = atoi(s) >= 2 ? 2 : 1;
     *out = ctx;
     return B9_OK;
 }
@@ -467,7 +463,7 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
 {
     const int n_pops = ctx->opt.n_pops;
     const Plan plan = make_plan(ctx, n_walkers, n_pops);
-    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)plan.n_groups * n_walkers, false);
+    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)plan.n_groups * 4 * n_walkers, false);
     if (rc) return rc;
     HIPCHK(ctx, b9k_derive_iso(ctx->pk, d_params, n_walkers, n_pops, ctx->d_hdr, ctx->d_iso, ctx->iso_stride,
                                ctx->mass_cap, mc, stream));
@@ -484,11 +480,11 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
         HIPCHK(ctx, hipEventRecord(ctx->ev_start[slot], stream));
     }
     HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, d_params,
-                              n_walkers, n_pops, ctx->d_partial, d_perstar, plan.tiles_per_block,
+                              n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, d_perstar, plan.tiles_per_block,
                               plan.n_groups, stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
     HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->d_partial,
-                             plan.n_groups, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, stream));
+                             plan.n_groups * 4, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, stream));
     return B9_OK;
 }
 
@@ -525,7 +521,7 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
         if (blk->free_idx[i] < 0 || blk->free_idx[i] >= B9_NPARAM) return fail(ctx, B9_ERR_INVALID, "free_idx out of range");
     {   // make sure the shared work buffers exist before taking pointers into them
         const Plan plan = make_plan(ctx, W, ctx->opt.n_pops);
-        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)plan.n_groups * W, false);
+        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)plan.n_groups * 4 * W, false);
         if (rc) return rc;
     }
     // one device allocation for the block's state
@@ -581,7 +577,7 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     int rc = check_ready(ctx);
     if (rc) return rc;
     const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
-    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)plan.n_groups * n_walkers, out_perstar != nullptr);
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)plan.n_groups * 4 * n_walkers, out_perstar != nullptr);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
     rc = b9_logpost_device(ctx, ctx->d_params, n_walkers, ctx->d_logpost, out_perstar ? ctx->d_perstar : nullptr, ctx->stream);

@@ -41,6 +41,7 @@ struct DevStars {
     const double *c0;                // [n_pad] log p + logPriorMass(mass1) + sum_f -0.5 log(2 pi sigma_f^2)
     const double *c0m;               // [n_pad] log p + sum_f -0.5 log(2 pi sigma_f^2)   (marginalised mode)
     const double *la;                // [n_pad] log((1-p) fsLike)  (-inf when p == 1)
+    const double *ea;                // [n_pad] (1-p) fsLike = exp(la)   (the hot kernel's form)
     const int *flags;                // [n_pad] bit0 = DB atmosphere, bits 8.. = stage
     const int *perm;                 // [n_pad] original index of the star in slot i, -1 = empty
     const double *heavy_mass;        // [n] primary masses in descending order ...

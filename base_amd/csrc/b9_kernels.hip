@@ -93,8 +93,26 @@ __device__ __forceinline__ double log_ge1(double x)
     return fma(dk, ln2_hi, -((hfsq - fma(sq, hfsq + R, dk * ln2_lo)) - f));
 }
 
+// exp(x) to 1 ulp for the hot kernel (~20 VALU instructions; the library exp is 42): Cody-Waite
+// reduction by ln 2 and a degree-13 Horner polynomial on [-ln2/2, ln2/2], scaled by v_ldexp_f64.
+// x is clamped to [-750, 750] (0 / +inf result); NaN propagates.
+__device__ __forceinline__ double exp_fast(double x)
+{
+    x = x < -750.0 ? -750.0 : (x > 750.0 ? 750.0 : x);
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0); p = fma(p, r, 1.0 / 39916800.0); p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);    p = fma(p, r, 1.0 / 40320.0);    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);       p = fma(p, r, 1.0 / 120.0);      p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);         p = fma(p, r, 0.5);              p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
 // log(1 + exp(x)), any x (x = -inf gives 0)
-__device__ __forceinline__ double log1pexp(double x) { return log_ge1(1.0 + exp(x)); }
+__device__ __forceinline__ double log1pexp(double x) { return log_ge1(1.0 + exp_fast(x)); }
 
 __device__ __forceinline__ double logaddexp(double a, double b)
 {
@@ -560,11 +578,18 @@ __device__ __forceinline__ void find_bracket(const double *mass, int n, double m
 // star data is already in registers (loaded at kernel entry, in flight while the mass column
 // is staged); both binary searches (primary, secondary) run in LDS BEFORE any magnitude row
 // is requested, then the rows of both components are requested together (one L2 round trip).
+#ifndef B9_EARLY_OBS
+#define B9_LATE_OBS 1        // measured: 20.3 us vs 22.3 us (early) on the 50k x 8 x 8 bench shape
+#endif
+#ifdef B9_LATE_OBS
+#define B9_OBS_ARGS const DevStars &st, int il
+#else
+#define B9_OBS_ARGS double c0, const double (&obs)[NFP], const double (&wgt)[NFP]
+#endif
 template <int NFP, int NPOPS>
 __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP> (&iso)[NPOPS],
-                                           const double *__restrict__ par, double m1, double q,
-                                           double c0, double la, const double (&obs)[NFP],
-                                           const double (&wgt)[NFP], double log_lam, double log_1ml)
+                                           double mod, double av, double m1, double q,
+                                           B9_OBS_ARGS, double log_lam, double log_1ml)
 {
     const bool binary = q > 0.0;
     const double m2 = q * m1;
@@ -609,7 +634,18 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         if (binary) { for (int j = 0; j < NFP / 2; ++j) { p[2 * j] += a2[j].x * t2; p[2 * j + 1] += a2[NFP / 2 + j].y; } }
 #endif
         STAMP(6);
-        const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
+#ifdef B9_LATE_OBS
+        // observed magnitudes and weights are requested only now: they cost 32 VGPRs while live,
+        // and keeping them out of the search / row / combine phases buys a wave per SIMD
+        __builtin_amdgcn_sched_barrier(0);
+        double obs[NFP], wgt[NFP];
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            obs[f] = st.obs[(size_t)f * st.n_pad + il];
+            wgt[f] = st.w[(size_t)f * st.n_pad + il];
+        }
+        const double c0 = st.c0[il];
+#endif
         double chi2 = 0.0;
 #pragma unroll
         for (int f = 0; f < NFP; ++f) {
@@ -620,14 +656,54 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
     }
     double l = ll[0];
     if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[NPOPS - 1]);
-#ifdef B9_ABL_NOMIX
-    return la + l;
-#else
-    return logaddexp(la, l);
-#endif
+    return l;       // log p_i L_i ; the field-star mixture is applied by the caller in product form
 }
 
-template <int NFP, int NPOPS>
+// Field-star mixture in PRODUCT form.  sum_i log(A_i + e^{l_i}) = log prod_i (A_i + e^{l_i}),
+// A_i = (1 - p_i) fsLike (a per-star constant staged at load): each star costs one exp and one
+// multiply; the running product is kept as (mantissa in [0.5,1), binary exponent) so it can neither
+// overflow nor underflow, and ONE log per wave turns it back into a sum.  Stars with A_i = 0
+// (certain members) or l_i > 600 (e^{l} would overflow; A_i is then negligible) contribute l_i
+// additively instead.
+struct MixAcc {
+    double mant;    // product of factors, renormalised
+    int expo;       // its binary exponent
+    double add;     // additive part
+};
+
+__device__ __forceinline__ void mix_add(MixAcc &a, double ea, double l)
+{
+    const bool additive = (ea == 0.0) || (l > 600.0);
+    const double u = additive ? 1.0 : ea + exp_fast(l);
+    a.add += additive ? l : 0.0;
+    const double m = a.mant * u;
+    a.expo += __builtin_amdgcn_frexp_exp(m);
+    a.mant = __builtin_amdgcn_frexp_mant(m);
+}
+
+// per-star value for the diagnostic per-star output (library log: u may be < 1)
+__device__ __forceinline__ double mix_value(double ea, double l)
+{
+    return ((ea == 0.0) || (l > 600.0)) ? l : log(ea + exp_fast(l));
+}
+
+// wave-wide combine; result valid in lane 0:  log(prod) + sum(add)
+__device__ __forceinline__ double mix_wave_total(MixAcc a)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double m2 = __shfl_down(a.mant, o, 64);
+        const int e2 = __shfl_down(a.expo, o, 64);
+        const double d2 = __shfl_down(a.add, o, 64);
+        const double m = a.mant * m2;                      // both in [0.5, 1): product in [0.25, 1)
+        a.expo += e2 + __builtin_amdgcn_frexp_exp(m);
+        a.mant = __builtin_amdgcn_frexp_mant(m);
+        a.add += d2;
+    }
+    return (log(a.mant) + (double)a.expo * 0.693147180559945309417) + a.add;
+}
+
+template <int NFP, int NPOPS, int WB>
 __global__ __launch_bounds__(256, B9_K1_MIN_WAVES) void k_star_like(DevPack pk, DevStars st,
                                                     const IsoHdr *__restrict__ hdr,
                                                     const double *__restrict__ iso_data,
@@ -636,102 +712,121 @@ __global__ __launch_bounds__(256, B9_K1_MIN_WAVES) void k_star_like(DevPack pk, 
                                                     double *__restrict__ partial, int n_groups,
                                                     double *__restrict__ perstar, int tiles_per_block)
 {
-    // LDS: [0..7] reduction scratch, then the mass column of each population's isochrone -- the
-    // binary search runs in LDS (dependent ds_reads instead of dependent L2 round trips); the
-    // magnitude rows a star needs are then read from L2 (coalesced: stars are sorted by mass,
-    // so neighbouring lanes hit the same or adjacent rows).
+    // LDS: the mass column of each (walker, population) isochrone this workgroup evaluates -- the binary search runs in LDS (dependent ds_reads
+    // instead of dependent L2 round trips); the magnitude rows a star needs are then read from L2
+    // (coalesced: stars are sorted by mass, so neighbouring lanes hit the same or adjacent rows).
+    // A lane keeps its star in registers and evaluates it for WB walkers in turn, so the star data
+    // crosses the L2 -> CU fabric once per WB walkers.
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     STAMP(0);
+    const int n_wsets = (n_walkers + WB - 1) / WB;
     const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
-    const int w = s % n_walkers;
-    const int group = (s / n_walkers) * 8 + xcd;        // tile group = tiles_per_block consecutive tiles
+    const int wset = s % n_wsets, w0 = wset * WB;
+    const int group = (s / n_wsets) * 8 + xcd;          // tile group = tiles_per_block consecutive tiles
     if (group >= n_groups) return;
-    const double *par = params + (size_t)w * B9_NPARAM;
+    const int nwb = (n_walkers - w0) < WB ? (n_walkers - w0) : WB;   // walkers in this set
     const int tile0 = group * tiles_per_block;
 
     // ---- first round trip: everything that depends only on the kernel arguments ------------
-    // (1) this lane's star of the first tile
     int i = tile0 * 256 + tid;
-    double obs[NFP], wgt[NFP], m1, q, c0, la;
-    {
-        const int il = i < st.n_pad ? i : st.n_pad - 1;     // stay inside the padded arrays
+    int il = i < st.n_pad ? i : st.n_pad - 1;               // stay inside the padded arrays
+    double m1, q, ea;
+#ifndef B9_LATE_OBS
+    double obs[NFP], wgt[NFP], c0;
 #pragma unroll
-        for (int f = 0; f < NFP; ++f) {
-            obs[f] = st.obs[(size_t)f * st.n_pad + il];
-            wgt[f] = st.w[(size_t)f * st.n_pad + il];
-        }
-        m1 = st.mass1[il]; q = st.q[il]; c0 = st.c0[il]; la = st.la[il];
+    for (int f = 0; f < NFP; ++f) {
+        obs[f] = st.obs[(size_t)f * st.n_pad + il];
+        wgt[f] = st.w[(size_t)f * st.n_pad + il];
     }
-    // (2) the mass column(s): the source address needs no header field, and copying the full
-    //     capacity instead of hdr.n entries costs nothing (the tail is never searched)
-    IsoView<NFP> iso[NPOPS];
-#pragma unroll
-    for (int k = 0; k < NPOPS; ++k) {
-        const double *g = iso_data + (size_t)(w * NPOPS + k) * iso_stride;
-        double *dst = smem + 8 + (size_t)k * mass_cap;
-        const double2 *sm = reinterpret_cast<const double2 *>(g);
-        double2 *dm = reinterpret_cast<double2 *>(dst);
+    c0 = st.c0[il];
+#endif
+    m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
+    // the mass columns: the source address needs no header field, and copying the full capacity
+    // instead of hdr.n entries costs nothing (the tail is never searched)
+    double *const lds_mass = smem;
+    for (int c = 0; c < nwb * NPOPS; ++c) {
+        const double2 *sm = reinterpret_cast<const double2 *>(iso_data + (size_t)(w0 * NPOPS + c) * iso_stride);
+        double2 *dm = reinterpret_cast<double2 *>(lds_mass + (size_t)c * mass_cap);
         for (int j = tid; j < mass_cap / 2; j += 256) dm[j] = sm[j];
-        iso[k].mass = dst; iso[k].mags = g + mass_cap;
     }
-    // (3) the header(s)
-    bool valid = true;
-    double tip_min = __builtin_inf();
+    // headers and the few parameters the star loop needs (scalar loads, same round trip)
+    IsoView<NFP> iso[WB][NPOPS];
+    bool valid[WB];
+    double tip_min[WB], mod[WB], av[WB], log_lam[WB], log_1ml[WB];
 #pragma unroll
-    for (int k = 0; k < NPOPS; ++k) {
-        const IsoHdr h = hdr[w * NPOPS + k];
-        valid = valid && h.valid;
-        iso[k].n = h.n; iso[k].tip = h.agb_tip;
-        iso[k].i_feh = h.i_feh; iso[k].i_y = h.i_y; iso[k].t_feh = h.t_feh; iso[k].t_y = h.t_y;
-        tip_min = h.agb_tip < tip_min ? h.agb_tip : tip_min;
+    for (int b = 0; b < WB; ++b) {
+        const int w = (b < nwb) ? w0 + b : w0;
+        const double *par = params + (size_t)w * B9_NPARAM;
+        bool ok = b < nwb;
+        double tmin = __builtin_inf();
+#pragma unroll
+        for (int kp = 0; kp < NPOPS; ++kp) {
+            const IsoHdr h = hdr[w * NPOPS + kp];
+            ok = ok && h.valid;
+            iso[b][kp].n = h.n; iso[b][kp].tip = h.agb_tip;
+            iso[b][kp].i_feh = h.i_feh; iso[b][kp].i_y = h.i_y; iso[b][kp].t_feh = h.t_feh; iso[b][kp].t_y = h.t_y;
+            iso[b][kp].mass = lds_mass + (size_t)(b * NPOPS + kp) * mass_cap;
+            iso[b][kp].mags = iso_data + (size_t)(w * NPOPS + kp) * iso_stride + mass_cap;
+            tmin = h.agb_tip < tmin ? h.agb_tip : tmin;
+        }
+        valid[b] = ok; tip_min[b] = tmin;
+        mod[b] = par[B9_P_MOD]; av[b] = par[B9_P_ABS];
+        const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+        log_lam[b] = NPOPS == 2 ? log(lam) : 0.0;
+        log_1ml[b] = NPOPS == 2 ? log1p(-lam) : 0.0;
     }
-    const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
     STAMP(1);
     __syncthreads();
     STAMP(2);
-    if (!valid) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
-        if (tid == 0) partial[(size_t)w * n_groups + group] = 0.0;
-        if (perstar)
-            for (int t = 0; t < tiles_per_block; ++t) {
-                int ii = (tile0 + t) * 256 + tid;
-                if (ii < st.n_pad && st.perm[ii] >= 0) perstar[(size_t)w * st.n + st.perm[ii]] = NEG_INF;
-            }
-        return;
-    }
-    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
-    double acc = 0.0;
+
+    MixAcc acc[WB];
+#pragma unroll
+    for (int b = 0; b < WB; ++b) { acc[b].mant = 0.5; acc[b].expo = 1; acc[b].add = 0.0; }   // = 1.0
     for (int t = 0; t < tiles_per_block; ++t) {
         if ((tile0 + t) * 256 >= st.n_pad) break;
         if (t > 0) {
             i = (tile0 + t) * 256 + tid;
-            const int il = i < st.n_pad ? i : st.n_pad - 1;
+            il = i < st.n_pad ? i : st.n_pad - 1;
+#ifndef B9_LATE_OBS
 #pragma unroll
             for (int f = 0; f < NFP; ++f) {
                 obs[f] = st.obs[(size_t)f * st.n_pad + il];
                 wgt[f] = st.w[(size_t)f * st.n_pad + il];
             }
-            m1 = st.mass1[il]; q = st.q[il]; c0 = st.c0[il]; la = st.la[il];
+            c0 = st.c0[il];
+#endif
+            m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
         }
         STAMP(3);
-        double v = 0.0;
-        if (i < st.n_pad && !(m1 > tip_min)) {     // empty slots hold m1 = +inf
-#ifdef B9_ABL_LOADONLY
-            v = m1 + q + c0 + la + iso[0].mass[tid & 127];
-            for (int f = 0; f < NFP; ++f) v += obs[f] * wgt[f];
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+            if (b >= nwb) continue;
+            const int w = w0 + b;
+            if (!valid[b]) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
+                if (perstar && i < st.n_pad && st.perm[i] >= 0) perstar[(size_t)w * st.n + st.perm[i]] = NEG_INF;
+                continue;
+            }
+            if (i < st.n_pad && !(m1 > tip_min[b])) {     // empty slots hold m1 = +inf
+#ifdef B9_LATE_OBS
+                const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, st, il, log_lam[b], log_1ml[b]);
 #else
-            v = hot_star<NFP, NPOPS>(pk, iso, par, m1, q, c0, la, obs, wgt, log_lam, log_1ml);
+                const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, c0, obs, wgt, log_lam[b], log_1ml[b]);
 #endif
-            if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
+                mix_add(acc[b], ea, l);
+                if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = mix_value(ea, l);
+            }
         }
-        acc += v;
     }
     STAMP(7);
-    // wave shuffle reduction, then fixed-order LDS sum of the 4 wave partials
-    double sum = wave_sum(acc);
-    if ((tid & 63) == 0) smem[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) partial[(size_t)w * n_groups + group] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    // wave combine (one log per wave and walker); every wave stores its own partial -- no
+    // end-of-kernel barrier, so a cheap (single-star) wave never waits for an expensive one
+#pragma unroll
+    for (int b = 0; b < WB; ++b) {
+        const double tot = mix_wave_total(acc[b]);
+        if ((tid & 63) == 0 && b < nwb)
+            partial[(size_t)(w0 + b) * (n_groups * 4) + group * 4 + (tid >> 6)] = valid[b] ? tot : 0.0;
+    }
     STAMP(8);
 }
 
@@ -917,25 +1012,26 @@ hipError_t b9k_derive_iso(const DevPack &pk, double *d_params, int n_walkers, in
     return hipGetLastError();
 }
 
-size_t b9k_star_like_lds_bytes(int n_pops, int mass_cap)
+size_t b9k_star_like_lds_bytes(int n_pops, int mass_cap, int wb)
 {
-    return sizeof(double) * (8 + (size_t)n_pops * mass_cap);
+    return sizeof(double) * ((size_t)wb * n_pops * mass_cap);
 }
 
-template <int NFP, int NPOPS>
+template <int NFP, int NPOPS, int WB>
 static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                                    const double *iso_data, long long iso_stride, int mass_cap,
                                    const double *d_params, int n_walkers, double *partial,
                                    double *perstar, int tiles_per_block, int n_groups, hipStream_t stream)
 {
-    const size_t lds = b9k_star_like_lds_bytes(NPOPS, mass_cap);
-    auto kern = k_star_like<NFP, NPOPS>;
+    const size_t lds = b9k_star_like_lds_bytes(NPOPS, mass_cap, WB);
+    auto kern = k_star_like<NFP, NPOPS, WB>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int blocks = 8 * ((n_groups + 7) / 8) * n_walkers;     // padded so every XCD sees whole walker sets
+    const int n_wsets = (n_walkers + WB - 1) / WB;
+    const int blocks = 8 * ((n_groups + 7) / 8) * n_wsets;     // padded so every XCD sees whole walker sets
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, pk, st, hdr, iso_data,
                        iso_stride, mass_cap, d_params, n_walkers, partial, n_groups, perstar, tiles_per_block);
     return hipGetLastError();
@@ -968,13 +1064,13 @@ static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const I
 
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
-                         const double *d_params, int n_walkers, int n_pops,
+                         const double *d_params, int n_walkers, int n_pops, int wb,
                          double *partial, double *perstar, int tiles_per_block, int n_groups,
                          hipStream_t stream)
 {
 #define SL_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, n_groups, stream
-#define SL2(NFP) launch_star_like<NFP, 2>(SL_ARGS)
-#define SL1(NFP) launch_star_like<NFP, 1>(SL_ARGS)
+#define SL2(NFP) (wb >= 2 ? launch_star_like<NFP, 2, 2>(SL_ARGS) : launch_star_like<NFP, 2, 1>(SL_ARGS))
+#define SL1(NFP) (wb >= 2 ? launch_star_like<NFP, 1, 2>(SL_ARGS) : launch_star_like<NFP, 1, 1>(SL_ARGS))
     B9_SWITCH_NFP(SL2, SL1)
 #undef SL1
 #undef SL2

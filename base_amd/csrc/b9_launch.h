@@ -6,11 +6,11 @@ hipError_t b9k_derive_iso(const DevPack &pk, double *d_params, int n_walkers, in
                           IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap,
                           const McmcDev &mc, hipStream_t stream);
 
-size_t b9k_star_like_lds_bytes(int n_pops, int mass_cap);
+size_t b9k_star_like_lds_bytes(int n_pops, int mass_cap, int wb);
 
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
-                         const double *d_params, int n_walkers, int n_pops,
+                         const double *d_params, int n_walkers, int n_pops, int wb,
                          double *partial, double *perstar, int tiles_per_block, int n_groups,
                          hipStream_t stream);
 
