@@ -1,0 +1,108 @@
+// b9host.hpp -- C++ host side above the C ABI: settings, model-pack loaders, photometry reader,
+// result writer and the adaptive-MCMC driver behind the singlePopMcmc / multiPopMcmc / makeCMD
+// command-line surface.
+//
+// The reference's sources are not mounted (/root/reference/README.md:4); names, flags and file
+// formats below follow the public BASE-9 conventions as [RECALL]ed and are documented in
+// docs/FORMATS.md.  Nothing here computes a likelihood: every number comes from libbase9hip.so.
+#pragma once
+#include "../../include/base9_hip.h"
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace b9h {
+
+// ---- settings: "section.key" -> value, from a YAML subset plus --flag overrides -------------
+class Settings {
+  public:
+    void load_yaml(const std::string &path);              // nested maps by indentation, scalars only
+    void parse_args(int argc, char **argv);               // --key value | --key=value
+    bool has(const std::string &key) const { return kv.count(key) != 0; }
+    std::string str(const std::string &key, const std::string &def = "") const;
+    double num(const std::string &key, double def) const;
+    long integer(const std::string &key, long def) const;
+    void set(const std::string &key, const std::string &value) { kv[key] = value; }
+    std::string dump() const;
+    // flag name ([RECALL] BASE-9 long options) -> settings key
+    static const std::map<std::string, std::string> &flag_map();
+
+  private:
+    std::map<std::string, std::string> kv;
+};
+
+// ---- model pack in host memory (owns the arrays a b9_pack points to) ------------------------
+struct ModelPack {
+    std::vector<std::string> filters;                     // columns, in photometry order
+    std::vector<double> feh, y, log_age;
+    std::vector<int32_t> iso_first_eep, iso_n_eep;
+    std::vector<int64_t> iso_offset;
+    std::vector<double> mass, mags, abs_coeff;
+    std::vector<double> wc_carb, wc_mass, wc_log_age, wc_log_teff, wc_log_radius;
+    std::vector<double> at_logg, at_log_teff, at_mags;
+    int n_at_type = 0;
+    int ifmr_id = B9_IFMR_WILLIAMS;
+    double m_wd_up = 8.0;
+    b9_pack view() const;                                 // plain-pointer view for b9_load_pack
+};
+
+// Loads <dir>/msrgb/<ms_model>.model (+ absorption.dat, wd/cooling_<wd_model>.dat,
+// wd/atmos_DA.dat, wd/atmos_DB.dat when present), keeping the filter columns named in `filters`
+// (in that order).  Throws std::runtime_error with a message on malformed input.
+ModelPack load_model_pack(const std::string &dir, const std::string &ms_model,
+                          const std::string &wd_model, const std::vector<std::string> &filters);
+// The filter names a .model file provides (its %f line).
+std::vector<std::string> model_filters(const std::string &dir, const std::string &ms_model);
+
+// ---- photometry -------------------------------------------------------------------------------
+struct Photometry {
+    std::vector<std::string> ids, filters;
+    std::vector<double> obs, sigma, mass1, mass_ratio, clust_prior;
+    std::vector<int32_t> stage, wd_type, use_dbi;
+    std::vector<double> filter_prior_min, filter_prior_max;
+    int n_stars() const { return (int)mass1.size(); }
+    b9_stars view() const;
+};
+// [RECALL] .phot: header "id <filters> sig<filters> mass1 massRatio stage CMprior useDBI", one
+// whitespace-separated row per star; sigma < 0 marks an unused filter.  Stars outside
+// [min_mag, max_mag] in filter `index` are dropped, as the reference's minMag/maxMag/index do.
+Photometry read_photometry(const std::string &path, double min_mag = -1e300, double max_mag = 1e300, int index = 0);
+
+// ---- results ------------------------------------------------------------------------------------
+// [RECALL] .res: header naming the sampled columns + logPost + stage, one row per kept iteration.
+class ResultWriter {
+  public:
+    ResultWriter(const std::string &path, const std::vector<std::string> &columns);
+    ~ResultWriter();
+    void row(const std::vector<double> &values, double logpost, int stage);
+  private:
+    void *fp;
+};
+
+// ---- the sampler ----------------------------------------------------------------------------------
+struct McmcConfig {
+    std::vector<int32_t> free_idx;        // sampled parameters (B9_P_*)
+    std::vector<double> step;             // initial step size per sampled parameter
+    int n_walkers = 1;
+    long burn_iter = 2000, run_iter = 10000, thin = 1, block = 50;
+    uint64_t seed = 73;
+    bool verbose = false;
+};
+
+struct McmcResult {
+    long accepted = 0, steps = 0;
+    double seconds = 0.0, star_evals_per_s = 0.0;
+};
+
+// Adaptive Metropolis ([RECALL] the staged burn-in of MpiMcmcApplication): device-resident blocks
+// (b9_mcmc_run_block); after every block the pooled covariance of all walkers' history and the
+// acceptance rate re-derive the proposal.  Burn-in rows are written with stage 1..2, the main run
+// with stage 3.  Only the walkers' samples and log-posteriors ever leave the GPU.
+McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double> &start_row,
+                    int n_stars, ResultWriter *out);
+
+const char *param_name(int idx);          // "logAge", "Y", "FeH", "modulus", "absorption", ...
+
+}  // namespace b9h

@@ -1,0 +1,47 @@
+"""Builds the C++ host programs (base_amd/host/): libbase9host.so + singlePopMcmc, multiPopMcmc,
+makeCMD.  Plain g++ against the C ABI; they link libbase9hip.so by rpath."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOST = os.path.join(HERE, "host")
+BIN = os.path.join(HOST, "bin")
+CSRC = os.path.join(HERE, "csrc")
+CXX = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
+
+
+def _run(cmd: List[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+
+
+def _stale(target: str, sources: List[str]) -> bool:
+    return not os.path.exists(target) or any(os.path.getmtime(s) > os.path.getmtime(target) for s in sources)
+
+
+def build_host(force: bool = False) -> None:
+    os.makedirs(BIN, exist_ok=True)
+    hdrs = [os.path.join(HOST, f) for f in ("b9host.hpp", "cli_common.hpp")] + [os.path.join(HERE, "..", "include", "base9_hip.h")]
+    lib = os.path.join(HOST, "libbase9host.so")
+    lib_src = [os.path.join(HOST, f) for f in ("b9host.cpp", "cli_common.cpp", "capi_host.cpp")]
+    link = ["-L" + CSRC, "-lbase9hip", "-Wl,-rpath," + CSRC, "-Wl,-rpath,$ORIGIN/../../csrc"]
+    if force or _stale(lib, lib_src + hdrs):
+        _run(CXX + ["-shared", "-o", lib] + lib_src + link)
+    progs = {"singlePopMcmc": ("mcmc_main.cpp", ["-DB9_N_POPS=1"]), "multiPopMcmc": ("mcmc_main.cpp", ["-DB9_N_POPS=2"]),
+             "makeCMD": ("makecmd_main.cpp", [])}
+    for name, (src, defs) in progs.items():
+        exe = os.path.join(BIN, name)
+        srcp = os.path.join(HOST, src)
+        if force or _stale(exe, [srcp, lib] + hdrs):
+            _run(CXX + defs + ["-o", exe, srcp, "-L" + HOST, "-lbase9host", "-Wl,-rpath," + HOST, "-Wl,-rpath,$ORIGIN/.."] + link)
+
+
+if __name__ == "__main__":
+    build_host(force="--force" in sys.argv)
+    print(BIN)

@@ -365,3 +365,132 @@ def walker_params(truth: np.ndarray, n_walkers: int, seed: int = 42, n_pops: int
     if n_pops == 2:
         p[:, abi.P_LAMBDA] = np.clip(p[:, abi.P_LAMBDA] + rng.normal(0, 0.05 * scale, n_walkers), 0.02, 0.98)
     return np.ascontiguousarray(p)
+
+
+# ------------------------------------------------------------------------------------------
+# on-disk formats (docs/FORMATS.md): what the C++ host loaders in base_amd/host/ parse
+# ------------------------------------------------------------------------------------------
+def _g(x) -> str:
+    return repr(float(x))          # shortest round-trip representation: files reload bit-exactly
+
+
+def write_models_dir(pack: Dict, root: str, ms_name: Optional[str] = None, wd_name: str = "montgomery") -> str:
+    """Write a synthetic pack as <root>/msrgb/<name>.model, absorption.dat, wd/cooling_*.dat, wd/atmos_D?.dat."""
+    import os
+    ms_name = ms_name or pack.get("name", "parsec")
+    nf = pack["n_filt"]
+    filters = list(pack["filters"])
+    os.makedirs(os.path.join(root, "msrgb"), exist_ok=True)
+    os.makedirs(os.path.join(root, "wd"), exist_ok=True)
+    nY, nA = len(pack["y"]), len(pack["log_age"])
+    mags = pack["mags"].reshape(-1, nf)
+    with open(os.path.join(root, "msrgb", ms_name + ".model"), "w") as f:
+        f.write("# synthetic MS/RGB grid (base_amd.synth); format: docs/FORMATS.md\n")
+        f.write("%f " + " ".join(filters) + "\n")
+        for i_f, fe in enumerate(pack["feh"]):
+            for i_y, yy in enumerate(pack["y"]):
+                f.write(f"%s [Fe/H]={_g(fe)} [alpha/Fe]=0.0 l/Hp=1.938 Y={_g(yy)}\n")
+                for i_a, la in enumerate(pack["log_age"]):
+                    k = (i_f * nY + i_y) * nA + i_a
+                    off, n, e0 = int(pack["iso_offset"][k]), int(pack["iso_n_eep"][k]), int(pack["iso_first_eep"][k])
+                    f.write(f"%a logAge={_g(la)}\n")
+                    for j in range(n):
+                        f.write(f"{e0 + j} {_g(pack['mass'][off + j])} " + " ".join(_g(v) for v in mags[off + j]) + "\n")
+    with open(os.path.join(root, "absorption.dat"), "w") as f:
+        f.write("# filter  A_filter/A_V\n")
+        for name, c in zip(filters, pack["abs_coeff"]):
+            f.write(f"{name} {_g(c)}\n")
+    if len(pack.get("wc_mass", [])) >= 2:
+        nC, nM, nT = len(pack["wc_carb"]), len(pack["wc_mass"]), len(pack["wc_log_age"])
+        te, ra = pack["wc_log_teff"].reshape(nC, nM, nT), pack["wc_log_radius"].reshape(nC, nM, nT)
+        with open(os.path.join(root, "wd", f"cooling_{wd_name}.dat"), "w") as f:
+            f.write("# logCoolAge logTeff logRadius\n")
+            for ic, c in enumerate(pack["wc_carb"]):
+                f.write(f"%c carbonicity={_g(c)}\n")
+                for im, m in enumerate(pack["wc_mass"]):
+                    f.write(f"%m mass={_g(m)}\n")
+                    for it in range(nT):
+                        f.write(f"{_g(pack['wc_log_age'][it])} {_g(te[ic, im, it])} {_g(ra[ic, im, it])}\n")
+        nG, nTe = len(pack["at_logg"]), len(pack["at_log_teff"])
+        at = pack["at_mags"].reshape(-1, nG, nTe, nf)
+        for t in range(at.shape[0]):
+            with open(os.path.join(root, "wd", f"atmos_{'DB' if t else 'DA'}.dat"), "w") as f:
+                f.write("%f " + " ".join(filters) + "\n")
+                for ig, g in enumerate(pack["at_logg"]):
+                    f.write(f"%g logg={_g(g)}\n")
+                    for it in range(nTe):
+                        f.write(f"{_g(pack['at_log_teff'][it])} " + " ".join(_g(v) for v in at[t, ig, it]) + "\n")
+    return root
+
+
+def write_phot(cluster: Dict, filters, path: str, wd_type_column: bool = True) -> str:
+    """[RECALL] .phot: id <filters> sig<filters> mass1 massRatio stage CMprior useDBI (+ wdType)."""
+    nf = len(filters)
+    obs = np.asarray(cluster["obs"]).reshape(-1, nf)
+    sig = np.asarray(cluster["sigma"]).reshape(-1, nf)
+    with open(path, "w") as f:
+        f.write("id " + " ".join(filters) + " " + " ".join("sig" + x for x in filters) + " mass1 massRatio stage CMprior useDBI\n")
+        for i in range(obs.shape[0]):
+            row = [str(i + 1)] + [_g(v) for v in obs[i]] + [_g(v) for v in sig[i]] + [
+                _g(cluster["mass1"][i]), _g(cluster["mass_ratio"][i]), str(int(cluster["stage"][i])),
+                _g(cluster["clust_prior"][i]), "1"]
+            if wd_type_column:
+                row.append(str(int(cluster["wd_type"][i])))
+            f.write(" ".join(row) + "\n")
+    return path
+
+
+def write_yaml(path: str, phot: str, models: str, out_base: str, truth, ms_model: str = "parsec",
+               sigmas: Optional[Dict] = None, **extra) -> str:
+    """A base9.yaml in the layout the reference uses [RECALL], restricted to what this build reads."""
+    sg = dict(Fe_H=0.3, distMod=0.3, Av=0.1, Y=0.0, carbonicity=0.0)
+    sg.update(sigmas or {})
+    t = np.asarray(truth)
+    txt = f"""general:
+  files:
+    photFile: "{phot}"
+    outputFileBase: "{out_base}"
+    modelDirectory: "{models}"
+  main_sequence:
+    msRgbModel: {ms_model}
+  white_dwarfs:
+    wdModel: montgomery
+    ifmr: 1
+    M_wd_up: 8.0
+  cluster:
+    starting:
+      Fe_H: {_g(t[abi.P_FEH])}
+      Av: {_g(t[abi.P_ABS])}
+      Y: {_g(t[abi.P_Y])}
+      carbonicity: {_g(t[abi.P_CARBONICITY])}
+      logAge: {_g(t[abi.P_LOGAGE])}
+      distMod: {_g(t[abi.P_MOD])}
+    priors:
+      means:
+        Fe_H: {_g(t[abi.P_FEH])}
+        distMod: {_g(t[abi.P_MOD])}
+        Av: {_g(t[abi.P_ABS])}
+        Y: {_g(t[abi.P_Y])}
+        carbonicity: {_g(t[abi.P_CARBONICITY])}
+      sigmas:
+        Fe_H: {sg['Fe_H']}
+        distMod: {sg['distMod']}
+        Av: {sg['Av']}
+        Y: {sg['Y']}
+        carbonicity: {sg['carbonicity']}
+    minMag: -99.0       # magnitude window of the stars to use ...
+    maxMag: 99.0
+    index: 0            # ... in this filter column
+  seed: {extra.get('seed', 73)}
+  verbose: 0
+singlePopMcmc:
+  stage2IterMax: {extra.get('burn', 1000)}
+  runIter: {extra.get('run', 2000)}
+  thin: {extra.get('thin', 1)}
+gpu:
+  walkers: {extra.get('walkers', 4)}
+  block: 50
+"""
+    with open(path, "w") as f:
+        f.write(txt)
+    return path

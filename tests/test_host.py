@@ -1,0 +1,171 @@
+"""Host side (C++, base_amd/host/): the model-pack / photometry / settings parsers round-trip what
+base_amd.synth writes (CPU, through libbase9host.so); the CLI programs run on the GPU and their
+outputs agree with the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from base_amd import abi, host_build, synth
+from conftest import build_problem
+
+HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "base_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    from base_amd import build
+    build.build_hip()
+    host_build.build_host()
+    lib = C.CDLL(os.path.join(HOST, "libbase9host.so"))
+    lib.b9h_last_error.restype = C.c_char_p
+    lib.b9h_load_pack.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(abi.b9_pack)]
+    lib.b9h_free_pack.argtypes = [C.c_void_p]
+    lib.b9h_read_phot.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_void_p), C.POINTER(abi.b9_stars), C.c_char_p, C.c_int]
+    lib.b9h_free_phot.argtypes = [C.c_void_p]
+    lib.b9h_settings_dump.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
+    return lib
+
+
+def _arr(ptr, n, dtype=np.float64):
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).copy() if n else np.zeros(0, dtype)
+
+
+@pytest.mark.parametrize("name,n_filt,n_y", [("parsec", 8, 1), ("dsed", 5, 3)])
+def test_model_pack_round_trip(hostlib, tmp_path, name, n_filt, n_y):
+    pack_d = synth.make_pack(name, n_filt=n_filt, n_y=n_y, n_feh=3, n_age=4, n_eep=30)
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    # ask for the filters in a different order than the files hold them
+    want = list(reversed(pack_d["filters"]))
+    h, view = C.c_void_p(), abi.b9_pack()
+    rc = hostlib.b9h_load_pack(root.encode(), name.encode(), b"montgomery", ",".join(want).encode(), C.byref(h), C.byref(view))
+    assert rc == 0, hostlib.b9h_last_error()
+    try:
+        assert (view.n_filt, view.n_feh, view.n_y, view.n_age) == (n_filt, 3, n_y, 4)
+        np.testing.assert_array_equal(_arr(view.feh, 3), pack_d["feh"])
+        np.testing.assert_array_equal(_arr(view.log_age, 4), pack_d["log_age"])
+        n_iso = 3 * n_y * 4
+        np.testing.assert_array_equal(_arr(view.iso_first_eep, n_iso, np.int32), pack_d["iso_first_eep"])
+        np.testing.assert_array_equal(_arr(view.iso_n_eep, n_iso, np.int32), pack_d["iso_n_eep"])
+        np.testing.assert_array_equal(_arr(view.iso_offset, n_iso, np.int64), pack_d["iso_offset"])
+        np.testing.assert_array_equal(_arr(view.mass, view.n_points), pack_d["mass"])
+        np.testing.assert_array_equal(_arr(view.mags, view.n_points * n_filt).reshape(-1, n_filt), pack_d["mags"][:, ::-1])
+        np.testing.assert_array_equal(_arr(view.abs_coeff, n_filt), pack_d["abs_coeff"][::-1])
+        np.testing.assert_array_equal(_arr(view.wc_log_teff, view.n_wc_carb * view.n_wc_mass * view.n_wc_age), pack_d["wc_log_teff"])
+        at = pack_d["at_mags"].reshape(2, view.n_at_logg, view.n_at_teff, n_filt)[..., ::-1]
+        np.testing.assert_array_equal(_arr(view.at_mags, at.size), at.ravel())
+        assert view.n_at_type == 2
+    finally:
+        hostlib.b9h_free_pack(h)
+    # a filter the model does not provide is an error, not a silent column of zeros
+    rc = hostlib.b9h_load_pack(root.encode(), name.encode(), b"montgomery", b"U,Zz", C.byref(h), C.byref(view))
+    assert rc != 0 and b"Zz" in hostlib.b9h_last_error()
+
+
+def test_photometry_round_trip_and_magnitude_window(hostlib, tmp_path):
+    pack_d, cl, *_ = build_problem("parsec", 8, n_stars=120, wd_frac=0.1)
+    path = synth.write_phot(cl, pack_d["filters"], str(tmp_path / "c.phot"))
+    h, view, buf = C.c_void_p(), abi.b9_stars(), C.create_string_buffer(256)
+    assert hostlib.b9h_read_phot(path.encode(), -1e300, 1e300, 0, C.byref(h), C.byref(view), buf, 256) == 0
+    assert buf.value.decode().split(",") == list(pack_d["filters"]) and view.n_stars == 120
+    np.testing.assert_array_equal(_arr(view.obs, 120 * 8).reshape(120, 8), cl["obs"])
+    np.testing.assert_array_equal(_arr(view.sigma, 120 * 8).reshape(120, 8), cl["sigma"])
+    np.testing.assert_array_equal(_arr(view.mass1, 120), cl["mass1"])
+    np.testing.assert_array_equal(_arr(view.clust_prior, 120), cl["clust_prior"])
+    np.testing.assert_array_equal(_arr(view.stage, 120, np.int32), cl["stage"])
+    np.testing.assert_array_equal(_arr(view.wd_type, 120, np.int32), cl["wd_type"])
+    hostlib.b9h_free_phot(h)
+    # magnitude window in filter 2 drops MS stars outside it but keeps WDs
+    v = cl["obs"][:, 2]
+    lo, hi = np.percentile(v, 20), np.percentile(v, 80)
+    assert hostlib.b9h_read_phot(path.encode(), lo, hi, 2, C.byref(h), C.byref(view), buf, 256) == 0
+    keep = ((v >= lo) & (v <= hi)) | (cl["stage"] == abi.STAGE_WD)
+    assert view.n_stars == keep.sum()
+    hostlib.b9h_free_phot(h)
+    bad = tmp_path / "bad.phot"
+    bad.write_text("id U B sigU mass1 massRatio stage CMprior useDBI\n1 1 2 0.1 1 0 1 0.9 1\n")
+    assert hostlib.b9h_read_phot(str(bad).encode(), -1e300, 1e300, 0, C.byref(h), C.byref(view), buf, 256) != 0
+
+
+def test_settings_yaml_and_flag_override(hostlib, tmp_path):
+    pack_d, cl, *_ = build_problem("dsed", 3, n_stars=10)
+    y = synth.write_yaml(str(tmp_path / "base9.yaml"), "a.phot", "models", "out", cl["truth"], ms_model="dsed")
+    args = [b"prog", b"--config", y.encode(), b"--sigmaFe_H", b"0.05", b"--photFile=b.phot", b"--runIter", b"123"]
+    argv = (C.c_char_p * len(args))(*args)
+    out = C.create_string_buffer(8192)
+    assert hostlib.b9h_settings_dump(len(args), argv, out, 8192) == 0, hostlib.b9h_last_error()
+    kv = dict(l.split(" = ", 1) for l in out.value.decode().strip().split("\n"))
+    assert kv["general.files.photFile"] == "b.phot" and kv["general.files.modelDirectory"] == "models"
+    assert kv["general.cluster.priors.sigmas.Fe_H"] == "0.05" and kv["general.cluster.priors.sigmas.distMod"] == "0.3"
+    assert kv["singlePopMcmc.runIter"] == "123" and kv["general.main_sequence.msRgbModel"] == "dsed"
+    assert float(kv["general.cluster.starting.logAge"]) == cl["truth"][abi.P_LOGAGE]
+    args = [b"prog", b"--noSuchFlag", b"1"]
+    assert hostlib.b9h_settings_dump(2, (C.c_char_p * 3)(*args), out, 8192) != 0
+
+
+def _cli(name, *args):
+    exe = os.path.join(HOST, "bin", name)
+    return subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.gpu
+def test_makecmd_matches_oracle(hostlib, tmp_path):
+    pack_d = synth.make_pack("parsec", 8, n_feh=4, n_age=6, n_eep=80)
+    truth = synth.default_params(pack_d)
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    y = synth.write_yaml(str(tmp_path / "base9.yaml"), "unused.phot", root, str(tmp_path / "iso"), truth)
+    r = _cli("makeCMD", "--config", y)
+    assert r.returncode == 0, r.stderr
+    rows = np.loadtxt(str(tmp_path / "iso.cmd"), skiprows=2)
+    first, mass, mags, tip = oracle.derive_isochrone(oracle.load(), abi.make_pack(pack_d), truth)
+    assert rows.shape == (len(mass), 10) and int(rows[0, 0]) == first
+    np.testing.assert_allclose(rows[:, 1], mass, rtol=0, atol=1e-10)
+    app = mags + truth[abi.P_MOD] + (pack_d["abs_coeff"] - 1.0) * truth[abi.P_ABS]
+    np.testing.assert_allclose(rows[:, 2:], app, rtol=0, atol=1e-8)
+    r = _cli("makeCMD", "--config", y, "--logAge", "3.0")
+    assert r.returncode != 0 and "outside the model grid" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,n_pops,n_y", [("singlePopMcmc", 1, 1), ("multiPopMcmc", 2, 3)])
+def test_mcmc_cli_runs_and_recovers_truth(hostlib, tmp_path, prog, n_pops, n_y):
+    pack_d = synth.make_pack("dsed", 8, n_y=n_y, n_feh=4, n_age=8, n_eep=90)
+    truth = synth.default_params(pack_d)
+    cl = synth.make_cluster(pack_d, 1500, seed=21, truth=truth, wd_frac=0.03, n_pops=n_pops)
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    phot = synth.write_phot(cl, pack_d["filters"], str(tmp_path / "c.phot"))
+    y = synth.write_yaml(str(tmp_path / "base9.yaml"), phot, root, str(tmp_path / "run"), truth, ms_model="dsed",
+                         burn=1500, run=1500, walkers=4)
+    extra = ["--startingYA", repr(float(truth[abi.P_Y])), "--startingYB", repr(float(truth[abi.P_Y2])), "--startingLambda", "0.5"] if n_pops == 2 else []
+    r = _cli(prog, "--config", y, *extra)
+    assert r.returncode == 0, r.stderr
+    assert "star-likelihood evals/s" in r.stderr
+    head = open(str(tmp_path / "run.res")).readline().split()
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
+    assert head[0] == "logAge" and head[-2:] == ["logPost", "stage"] and res.shape == (3000 * 4, len(head))
+    main = res[res[:, -1] == 3]
+    assert len(main) == 1500 * 4 and np.all(np.isfinite(main[:, -2]))
+    col = {n: i for i, n in enumerate(head)}
+    for name, idx in (("logAge", abi.P_LOGAGE), ("FeH", abi.P_FEH), ("modulus", abi.P_MOD)):
+        m, sd = main[:, col[name]].mean(), main[:, col[name]].std()
+        assert abs(m - truth[idx]) < 6 * sd + 2e-3, (name, m, truth[idx], sd)
+    # the recorded log-posterior of the last row is what the oracle gives at that position
+    pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
+    cl2 = dict(cl)
+    lo, hi = np.where(np.asarray(cl["sigma"]) > 0, cl["obs"], np.inf).min(axis=0), np.where(np.asarray(cl["sigma"]) > 0, cl["obs"], -np.inf).max(axis=0)
+    cl2["filter_prior_min"], cl2["filter_prior_max"] = lo, hi          # the reader's field-star box
+    pri = synth.default_priors(pack_d, truth, n_pops)
+    for k, v in ((abi.P_Y, 0.0), (abi.P_Y2, 0.0)):
+        pri.var[k] = v
+    row = truth.copy()
+    for name, i in col.items():
+        key = {"logAge": abi.P_LOGAGE, "FeH": abi.P_FEH, "modulus": abi.P_MOD, "absorption": abi.P_ABS, "Y": abi.P_Y,
+               "YA": abi.P_Y, "YB": abi.P_Y2, "lambda": abi.P_LAMBDA}.get(name)
+        if key is not None:
+            row[key] = main[-1, i]
+    row[abi.P_IFMR_INTERCEPT], row[abi.P_IFMR_SLOPE], row[abi.P_IFMR_QUAD] = 0.77, 0.08, 0.0
+    want = oracle.Oracle(pack, abi.make_stars(cl2), pri, abi.make_options(n_pops=n_pops)).logpost(row[None, :])[0]
+    assert abs(main[-1, -2] - want) <= 2e-4 * max(1.0, abs(want))     # .res holds 6 decimals of each parameter
