@@ -463,10 +463,21 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
 {
     const int n_pops = ctx->opt.n_pops;
     const Plan plan = make_plan(ctx, n_walkers, n_pops);
-    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)plan.n_groups * 4 * n_walkers, false);
+    const bool marg = ctx->opt.mode == B9_MODE_MARGINALISED;
+    const size_t n_part = marg ? (size_t)ctx->st.n_pad : (size_t)plan.n_groups * 4;
+    int rc = ensure_capacity(ctx, n_walkers, n_pops, n_part * n_walkers, false);
     if (rc) return rc;
     HIPCHK(ctx, b9k_derive_iso(ctx->pk, d_params, n_walkers, n_pops, ctx->d_hdr, ctx->d_iso, ctx->iso_stride,
                                ctx->mass_cap, mc, stream));
+    if (marg) {
+        const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
+        const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
+        HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, d_params,
+                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, stream));
+        HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->d_partial,
+                                 (int)n_part, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, true, stream));
+        return B9_OK;
+    }
     size_t slot = 0;
     const bool timed = ctx->timing > 0 && (ctx->launch_no++ % (unsigned)ctx->timing) == 0;
     if (timed) {
@@ -484,7 +495,7 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
                               plan.n_groups, stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
     HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->d_partial,
-                             plan.n_groups * 4, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, stream));
+                             plan.n_groups * 4, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, false, stream));
     return B9_OK;
 }
 
@@ -493,7 +504,6 @@ static int check_ready(b9_ctx *ctx)
     if (!ctx->have_pack || !ctx->have_stars) return fail(ctx, B9_ERR_STATE, "load the pack and the stars first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
-    if (ctx->opt.mode == B9_MODE_MARGINALISED) return fail(ctx, B9_ERR_STATE, "marginalised mode is not built in this revision");
     return B9_OK;
 }
 
@@ -521,7 +531,7 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
         if (blk->free_idx[i] < 0 || blk->free_idx[i] >= B9_NPARAM) return fail(ctx, B9_ERR_INVALID, "free_idx out of range");
     {   // make sure the shared work buffers exist before taking pointers into them
         const Plan plan = make_plan(ctx, W, ctx->opt.n_pops);
-        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)plan.n_groups * 4 * W, false);
+        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)std::max(plan.n_groups * 4, ctx->st.n_pad) * W, false);
         if (rc) return rc;
     }
     // one device allocation for the block's state
@@ -577,7 +587,7 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     int rc = check_ready(ctx);
     if (rc) return rc;
     const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
-    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)plan.n_groups * 4 * n_walkers, out_perstar != nullptr);
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)std::max(plan.n_groups * 4, ctx->st.n_pad) * n_walkers, out_perstar != nullptr);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
     rc = b9_logpost_device(ctx, ctx->d_params, n_walkers, ctx->d_logpost, out_perstar ? ctx->d_perstar : nullptr, ctx->stream);

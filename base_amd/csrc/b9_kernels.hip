@@ -838,6 +838,171 @@ extern "C" int b9_debug_read_stamps(unsigned long long *out, int n_waves)
 #endif
 
 // ------------------------------------------------------------------------------------------
+// k_star_marg  (marginalised mode; SURVEY 8a row a6 "marg.cpp-like", [RECALL] margEvolveWithBinary)
+//
+// ONE WAVEFRONT PER STAR.  The star's likelihood is integrated over primary mass (iso_increm equal
+// sub-steps inside every EEP interval of the derived isochrone, left-endpoint rule) and mass ratio
+// (n_q nodes j / n_q): lane l takes primary nodes l, l + 64, ...; for each it interpolates the
+// primary once and loops over the mass ratios (secondary: binary search in the LDS-resident mass
+// column, rows from LDS, flux combine); every node contributes exp(ll) dM / n_q to a per-lane
+// online log-sum-exp, the 64 lanes are combined with wavefront shuffles, and the star's value is
+// written to its slot (the per-walker sum over stars is k_finalize's fixed-order block sum).
+// A star of stage WD integrates over (AGB tip, M_wd_up] in 8 iso_increm steps through the WD branch.
+// The whole isochrone (mass column + magnitude rows) of the walker lives in LDS.
+// ------------------------------------------------------------------------------------------
+struct Lse { double mx, sm; };      // online log-sum-exp:  value = mx + log(sm)
+
+__device__ __forceinline__ void lse_add(Lse &a, double x)
+{
+    if (x == NEG_INF) return;
+    if (x > a.mx) { a.sm = a.sm * exp_fast(a.mx - x) + 1.0; a.mx = x; }
+    else a.sm += exp_fast(x - a.mx);
+}
+
+__device__ __forceinline__ Lse lse_merge(Lse a, Lse b)
+{
+    if (b.mx == NEG_INF) return a;
+    if (a.mx == NEG_INF) return b;
+    Lse r;
+    if (a.mx >= b.mx) { r.mx = a.mx; r.sm = a.sm + b.sm * exp_fast(b.mx - a.mx); }
+    else { r.mx = b.mx; r.sm = b.sm + a.sm * exp_fast(a.mx - b.mx); }
+    return r;
+}
+
+__device__ __forceinline__ double log_prior_mass_dev(double lmn, double m)
+{
+    const double z = (log10(m) - MF_MU) / MF_SIGMA;
+    return lmn - 0.5 * z * z - log(m) - log(LN10);
+}
+
+template <int NFP, int NPOPS>
+__global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
+                                                    const double *__restrict__ iso_data, long long iso_stride,
+                                                    int mass_cap, const double *__restrict__ params,
+                                                    double *__restrict__ vals, double *__restrict__ perstar,
+                                                    int K, int Q)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.y;
+    const double *par = params + (size_t)w * B9_NPARAM;
+    IsoView<NFP> iso[NPOPS];
+    double tip_min;
+    const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
+    const int slot = blockIdx.x * 4 + wave;
+    if (!valid) {
+        if (slot < st.n_pad && lane == 0) {
+            vals[(size_t)w * st.n_pad + slot] = 0.0;
+            if (perstar && st.perm[slot] >= 0) perstar[(size_t)w * st.n + st.perm[slot]] = NEG_INF;
+        }
+        return;
+    }
+    // stage the isochrone(s): [pop][ mass[cap] | mags[cap][NFP] ]
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        double *dst = smem + (size_t)kp * mass_cap * (NFP + 1);
+        const double2 *src = reinterpret_cast<const double2 *>(iso[kp].mass);
+        double2 *d2 = reinterpret_cast<double2 *>(dst);
+        const int n2 = (mass_cap + iso[kp].n * NFP + 1) / 2;         // mass column (full capacity) + n rows
+        for (int j = tid; j < n2; j += 256) d2[j] = src[j];
+        iso[kp].mass = dst; iso[kp].mags = dst + mass_cap;
+    }
+    __syncthreads();
+    if (slot >= st.n_pad) return;
+    const int orig = st.perm[slot];
+    if (orig < 0) { if (lane == 0) vals[(size_t)w * st.n_pad + slot] = 0.0; return; }
+
+    double obs[NFP], wgt[NFP];
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) { obs[f] = st.obs[(size_t)f * st.n_pad + slot]; wgt[f] = st.w[(size_t)f * st.n_pad + slot]; }
+    const double c0m = st.c0m[slot], la = st.la[slot];
+    const int flags = st.flags[slot], stage = flags >> 8, wd_type = flags & 1;
+    const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
+    double shift[NFP];
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) shift[f] = mod + pk.abs_m1[f] * av;
+
+    double ll[NPOPS];
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        const IsoView<NFP> &is = iso[kp];
+        Lse acc; acc.mx = NEG_INF; acc.sm = 0.0;
+        if (stage == B9_STAGE_WD) {
+            WdAxes ax;
+            ax.log_age = pk.log_age;
+            const int ny = pk.n_y > 1 ? 2 : 1;
+            for (int df = 0; df < 2; ++df) for (int dy = 0; dy < 2; ++dy)
+                ax.tips[df * 2 + dy] = pk.tips + (size_t)((is.i_feh + df) * pk.n_y + (is.i_y + (dy < ny ? dy : 0))) * pk.n_age;
+            ax.wc_log_age = pk.wc_log_age; ax.wc_mass = pk.wc_mass; ax.wc_carb = pk.wc_carb;
+            ax.at_log_teff = pk.at_log_teff; ax.at_logg = pk.at_logg;
+            const int steps = 8 * K;
+            const double dM = (pk.m_wd_up - is.tip) / steps;
+            if (dM > 0.0) {
+                const double log_w = log(dM);
+                for (int j = 1 + lane; j <= steps; j += 64) {
+                    const double m1 = is.tip + dM * j;
+                    double p[NFP];
+                    star_mags<NFP>(pk, ax, is, par, m1, wd_type, p);
+                    double chi2 = 0.0;
+#pragma unroll
+                    for (int f = 0; f < NFP; ++f) { const double d = (p[f] + shift[f]) - obs[f]; chi2 = fma(wgt[f] * d, d, chi2); }
+                    if (isfinite(chi2)) lse_add(acc, (log_prior_mass_dev(pk.log_mass_norm, m1) - 0.5 * chi2) + log_w);
+                }
+            }
+        } else {
+            const int n_nodes = (is.n - 1) * K;
+            for (int pnode = lane; pnode < n_nodes; pnode += 64) {
+                const int e = pnode / K, s = pnode - e * K;
+                const double a = is.mass[e], d = is.mass[e + 1] - a;
+                if (!(d > 0.0)) continue;
+                const double dM = d / K;
+                const double m1 = fma((double)s, dM, a);
+                const double t1 = (m1 - a) / d;
+                double p1[NFP];
+                const double *r0 = is.mags + (size_t)e * NFP;
+#pragma unroll
+                for (int f = 0; f < NFP; ++f) p1[f] = lerp(r0[f], r0[NFP + f], t1);
+                const double base = log_prior_mass_dev(pk.log_mass_norm, m1) + log(dM / Q);
+                for (int j = 0; j < Q; ++j) {
+                    double chi2 = 0.0;
+                    if (j == 0) {
+#pragma unroll
+                        for (int f = 0; f < NFP; ++f) { const double dd = (p1[f] + shift[f]) - obs[f]; chi2 = fma(wgt[f] * dd, dd, chi2); }
+                    } else {
+                        const double m2 = ((double)j / (double)Q) * m1;
+                        const bool dark2 = m2 < is.mass[0];
+                        int lo2; double t2;
+                        find_bracket(is.mass, is.n, m2, lo2, t2);
+                        const double *s0 = is.mags + (size_t)lo2 * NFP;
+#pragma unroll
+                        for (int f = 0; f < NFP; ++f) {
+                            const double p2 = dark2 ? B9_MAG_NOFLUX : lerp(s0[f], s0[NFP + f], t2);
+                            const double pc = p1[f] - (2.5 / LN10) * log1pexp((-0.4 * LN10) * (p2 - p1[f]));
+                            const double dd = (pc + shift[f]) - obs[f];
+                            chi2 = fma(wgt[f] * dd, dd, chi2);
+                        }
+                    }
+                    if (isfinite(chi2)) lse_add(acc, base - 0.5 * chi2);
+                }
+            }
+        }
+        // wavefront shuffle reduction of the 64 partial log-sum-exps
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            Lse b; b.mx = __shfl_down(acc.mx, o, 64); b.sm = __shfl_down(acc.sm, o, 64);
+            acc = lse_merge(acc, b);
+        }
+        ll[kp] = (acc.mx == NEG_INF) ? NEG_INF : c0m + (acc.mx + log(acc.sm));
+    }
+    if (lane == 0) {
+        double l = ll[0];
+        if (NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; l = logaddexp(log(lam) + ll[0], log1p(-lam) + ll[NPOPS - 1]); }
+        const double v = logaddexp(la, l);
+        vals[(size_t)w * st.n_pad + slot] = v;
+        if (perstar) perstar[(size_t)w * st.n + orig] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_finalize: one workgroup per walker.
 //   (1) the stars k_star_like skipped -- primary heavier than the AGB tip (SURVEY 8a row a7:
 //       IFMR -> WD cooling -> WD atmosphere, or NS/BH) -- through the general per-star code;
@@ -930,8 +1095,9 @@ __global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStar
         return;
     }
     // (1) heavy stars: count = first k with heavy_mass[k] <= tip_min, by a 512-ary search in
-    //     which every thread probes one point per round (two rounds for 50k stars)
-    int lo = 0, hi = st.n;
+    //     which every thread probes one point per round (two rounds for 50k stars).
+    //     (axes_in_lds < 0: marginalised mode -- k_star_marg has already handled every star.)
+    int lo = 0, hi = axes_in_lds < 0 ? 0 : st.n;
     while (lo < hi) {
         const int span = hi - lo, step = (span + B9_FIN_THREADS - 1) / B9_FIN_THREADS;
         const int p = lo + tid * step;
@@ -1042,13 +1208,14 @@ static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const I
                                   const double *iso_data, long long iso_stride, int mass_cap,
                                   const double *partial, int n_partial, const double *d_params,
                                   const DevPriors &pr, int n_walkers, double *d_logpost, double *perstar,
-                                  const McmcDev &mc, hipStream_t stream)
+                                  const McmcDev &mc, bool marg, hipStream_t stream)
 {
     const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
     size_t lds = has_wd ? sizeof(double) * ((size_t)(1 + 4 * NPOPS) * pk.n_age + pk.n_wc_age + pk.n_wc_mass + pk.n_wc_carb +
                                             pk.n_at_teff + pk.n_at_logg) : 0;
-    const int in_lds = has_wd && lds <= 48 * 1024;
+    int in_lds = has_wd && lds <= 48 * 1024;
     if (!in_lds) lds = 0;
+    if (marg) in_lds = -1;
     hipLaunchKernelGGL((k_finalize<NFP, NPOPS>), dim3(n_walkers), dim3(B9_FIN_THREADS), lds, stream, pk, st, hdr,
                        iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, d_logpost, perstar, in_lds, mc);
     return hipGetLastError();
@@ -1080,13 +1247,43 @@ hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 hipError_t b9k_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                         long long iso_stride, int mass_cap, const double *partial, int n_partial, int n_pops,
                         const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        double *perstar, const McmcDev &mc, hipStream_t stream)
+                        double *perstar, const McmcDev &mc, bool marg, hipStream_t stream)
 {
-#define FN_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, n_walkers, d_logpost, perstar, mc, stream
+#define FN_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, n_walkers, d_logpost, perstar, mc, marg, stream
 #define FN2(NFP) launch_finalize<NFP, 2>(FN_ARGS)
 #define FN1(NFP) launch_finalize<NFP, 1>(FN_ARGS)
     B9_SWITCH_NFP(FN2, FN1)
 #undef FN1
 #undef FN2
 #undef FN_ARGS
+}
+
+template <int NFP, int NPOPS>
+static hipError_t launch_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
+                                   long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
+                                   double *vals, double *perstar, int K, int Q, hipStream_t stream)
+{
+    const size_t lds = sizeof(double) * (size_t)NPOPS * mass_cap * (NFP + 1);
+    auto kern = k_star_marg<NFP, NPOPS>;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((st.n_pad + 3) / 4, n_walkers), dim3(256), lds, stream, pk, st, hdr, iso_data, iso_stride,
+                       mass_cap, d_params, vals, perstar, K, Q);
+    return hipGetLastError();
+}
+
+hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
+                         long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
+                         double *vals, double *perstar, int K, int Q, hipStream_t stream)
+{
+#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, stream
+#define SM2(NFP) launch_star_marg<NFP, 2>(SM_ARGS)
+#define SM1(NFP) launch_star_marg<NFP, 1>(SM_ARGS)
+    B9_SWITCH_NFP(SM2, SM1)
+#undef SM1
+#undef SM2
+#undef SM_ARGS
 }

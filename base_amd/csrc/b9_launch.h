@@ -17,4 +17,8 @@ hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 hipError_t b9k_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                         long long iso_stride, int mass_cap, const double *partial, int n_partial, int n_pops,
                         const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        double *perstar, const McmcDev &mc, hipStream_t stream);
+                        double *perstar, const McmcDev &mc, bool marg, hipStream_t stream);
+
+hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
+                         long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
+                         double *vals, double *perstar, int K, int Q, hipStream_t stream);
