@@ -15,6 +15,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -62,6 +63,11 @@ struct b9_ctx {
     // launch plan
     int tiles_per_block = 0;   // 0 = auto
     int walkers_per_lane = 1;  // WB template parameter of k_star_like (1 or 2)
+    int stream_groups = 1;     // b9_mcmc_run_block: walker groups on their own streams + host threads (measured: no gain in one process)
+    std::vector<hipStream_t> group_streams;
+    std::vector<hipEvent_t> group_events;
+    hipEvent_t fork_event = nullptr;
+    int fuse_steps = 0;        // device sampler: 1/2 = k_finalize also proposes (+ derives) the next step; measured no faster
 
     // timing of the dominant kernel
     int timing = 0;            // 0 off, n > 0: bracket every n-th launch of the dominant kernel with events
@@ -232,9 +238,11 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
         int cw = std::max(n_walkers, ctx->cap_walkers), cp = std::max(n_pops, ctx->cap_pops);
         ctx->mass_cap = (ctx->pk.max_eep + 1) & ~1;
         ctx->iso_stride = (long long)ctx->mass_cap * (ctx->pk.nfp + 1);
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_hdr, sizeof(IsoHdr) * cw * cp));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_iso, sizeof(double) * (size_t)ctx->iso_stride * cw * cp));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_params, sizeof(double) * B9_NPARAM * cw));
+        // two sets (ping-pong): the fused sampler's k_finalize writes step t+1's proposal and
+        // isochrones while step t's are still the ones it reads
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_hdr, sizeof(IsoHdr) * cw * cp * 2));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_iso, sizeof(double) * (size_t)ctx->iso_stride * cw * cp * 2));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_params, sizeof(double) * B9_NPARAM * cw * 2));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_logpost, sizeof(double) * cw));
         ctx->cap_walkers = cw; ctx->cap_pops = cp;
     }
@@ -307,6 +315,8 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     ctx->pr.log_age_min = -INFINITY; ctx->pr.log_age_max = INFINITY;
     if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
     if (const char *s = getenv("B9_WALKERS_PER_LANE")) ctx->walkers_per_lane = atoi(s) >= 2 ? 2 : 1;
+    if (const char *s = getenv("B9_FUSE_STEPS")) ctx->fuse_steps = atoi(s);
+    if (const char *s = getenv("B9_STREAM_GROUPS")) ctx->stream_groups = std::max(1, atoi(s));
     *out = ctx;
     return B9_OK;
 }
@@ -322,6 +332,9 @@ void b9_ctx_destroy(b9_ctx *ctx)
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
+    for (auto e : ctx->group_events) (void)hipEventDestroy(e);
+    for (auto gs : ctx->group_streams) (void)hipStreamDestroy(gs);
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -455,31 +468,51 @@ int b9_set_options(b9_ctx *ctx, const b9_options *o)
     return B9_OK;
 }
 
-// The three stream-ordered launches of one log-posterior evaluation.  With mc.enabled the first
-// kernel also draws the Metropolis proposal (and writes it to d_params) and the last one accepts
-// or rejects it: a whole MCMC step without the host.
+// The stream-ordered launches of one log-posterior evaluation: k_derive_iso -> k_star_like (or
+// k_star_marg) -> k_finalize.  Work buffers come in two sets (ping-pong).  With mc.enabled the
+// first kernel also draws the Metropolis proposal (writing it to the set's parameter rows) and the
+// last one accepts or rejects it; with mc.fuse_next the last kernel additionally draws the NEXT
+// step's proposal and derives its isochrones into the other set, so that the next step starts at
+// the star-likelihood kernel (run_k0 = false): two launches per MCMC step.
 static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, double *d_logpost,
-                          double *d_perstar, const McmcDev &mc, hipStream_t stream)
+                          double *d_perstar, const McmcDev &mc, hipStream_t stream, int set = 0, bool run_k0 = true,
+                          bool k0_proposes = true, int w_off = 0, int w_cap = 0, bool allow_timing = true)
 {
+    // w_off / w_cap: this launch evaluates walkers [w_off, w_off + n_walkers) of a larger batch of
+    // w_cap walkers (stream groups of b9_mcmc_run_block); its slices of the work buffers start there
     const int n_pops = ctx->opt.n_pops;
     const Plan plan = make_plan(ctx, n_walkers, n_pops);
     const bool marg = ctx->opt.mode == B9_MODE_MARGINALISED;
     const size_t n_part = marg ? (size_t)ctx->st.n_pad : (size_t)plan.n_groups * 4;
-    int rc = ensure_capacity(ctx, n_walkers, n_pops, n_part * n_walkers, false);
+    // partial sums: one slice of n_pad doubles per walker covers every plan (n_part <= n_pad)
+    int rc = ensure_capacity(ctx, std::max(n_walkers, w_cap), n_pops, (size_t)ctx->st.n_pad * std::max(n_walkers, w_cap), false);
     if (rc) return rc;
-    HIPCHK(ctx, b9k_derive_iso(ctx->pk, d_params, n_walkers, n_pops, ctx->d_hdr, ctx->d_iso, ctx->iso_stride,
-                               ctx->mass_cap, mc, stream));
+    const size_t set_rows = (size_t)ctx->cap_walkers * ctx->cap_pops;
+    IsoHdr *hdr = ctx->d_hdr + (size_t)set * set_rows + (size_t)w_off * n_pops;
+    double *iso = ctx->d_iso + ((size_t)set * set_rows + (size_t)w_off * n_pops) * ctx->iso_stride;
+    double *const d_partial = ctx->d_partial + (size_t)w_off * ctx->st.n_pad;
+    B9Next nx{nullptr, nullptr, nullptr};
+    if (mc.enabled && mc.fuse_next) {
+        nx.params = ctx->d_params + ((size_t)(set ^ 1) * ctx->cap_walkers + w_off) * B9_NPARAM;
+        nx.hdr = ctx->d_hdr + (size_t)(set ^ 1) * set_rows + (size_t)w_off * n_pops;
+        nx.iso = ctx->d_iso + ((size_t)(set ^ 1) * set_rows + (size_t)w_off * n_pops) * ctx->iso_stride;
+    }
+    if (run_k0) {
+        McmcDev mc0 = mc;
+        if (!k0_proposes) mc0.enabled = 0;       // the row was already drawn by the previous k_finalize
+        HIPCHK(ctx, b9k_derive_iso(ctx->pk, d_params, n_walkers, n_pops, hdr, iso, ctx->iso_stride, ctx->mass_cap, mc0, stream));
+    }
     if (marg) {
         const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
         const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
-        HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, d_params,
-                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, stream));
-        HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->d_partial,
-                                 (int)n_part, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, true, stream));
+        HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, hdr, iso, ctx->iso_stride, ctx->mass_cap, d_params,
+                                  n_walkers, n_pops, d_partial, d_perstar, K, Q, stream));
+        HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, hdr, iso, ctx->iso_stride, ctx->mass_cap, d_partial,
+                                 (int)n_part, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, true, nx, stream));
         return B9_OK;
     }
     size_t slot = 0;
-    const bool timed = ctx->timing > 0 && (ctx->launch_no++ % (unsigned)ctx->timing) == 0;
+    const bool timed = allow_timing && ctx->timing > 0 && (ctx->launch_no++ % (unsigned)ctx->timing) == 0;
     if (timed) {
         if (ctx->ev_used == ctx->ev_start.size()) {
             hipEvent_t a, b;
@@ -490,12 +523,12 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
         slot = ctx->ev_used++;
         HIPCHK(ctx, hipEventRecord(ctx->ev_start[slot], stream));
     }
-    HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, d_params,
-                              n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, d_perstar, plan.tiles_per_block,
+    HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, hdr, iso, ctx->iso_stride, ctx->mass_cap, d_params,
+                              n_walkers, n_pops, ctx->walkers_per_lane, d_partial, d_perstar, plan.tiles_per_block,
                               plan.n_groups, stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
-    HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, ctx->d_partial,
-                             plan.n_groups * 4, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, false, stream));
+    HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, hdr, iso, ctx->iso_stride, ctx->mass_cap, d_partial,
+                             plan.n_groups * 4, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, false, nx, stream));
     return B9_OK;
 }
 
@@ -531,7 +564,8 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
         if (blk->free_idx[i] < 0 || blk->free_idx[i] >= B9_NPARAM) return fail(ctx, B9_ERR_INVALID, "free_idx out of range");
     {   // make sure the shared work buffers exist before taking pointers into them
         const Plan plan = make_plan(ctx, W, ctx->opt.n_pops);
-        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)std::max(plan.n_groups * 4, ctx->st.n_pad) * W, false);
+        (void)plan;
+        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)ctx->st.n_pad * W, false);
         if (rc) return rc;
     }
     // one device allocation for the block's state
@@ -564,11 +598,64 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     HIPCHK(ctx, hipMemcpyAsync(d_free, blk->free_idx, d * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(d_ids, blk->walker_ids, W * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemsetAsync(mc.n_acc, 0, sizeof(unsigned long long), s));
-    for (int k = 0; k < S; ++k) {
-        mc.step = (unsigned long long)(blk->step0 + k);
-        mc.row = k;
-        rc = launch_logpost(ctx, ctx->d_params, W, ctx->d_logpost, nullptr, mc, s);
+    // Stream groups: the local walkers are independent chains, so they are split into G groups
+    // that run on their own streams -- the latency-bound small kernels of one group overlap the
+    // star-likelihood kernel of another (measured: two groups ~1.4x the throughput of one).
+    // fuse_steps: 0 (default) = k_derive_iso draws each step's proposal; 1 = k_finalize draws the
+    // next step's proposal right after its accept decision and k_derive_iso only derives;
+    // 2 = k_finalize also derives the next isochrones (two launches per step; measured slower)
+    const int fuse = ctx->fuse_steps;
+    int G = std::max(1, std::min(ctx->stream_groups, W));
+    while ((int)ctx->group_streams.size() < G) {
+        hipStream_t gs; hipEvent_t ge;
+        HIPCHK(ctx, hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ge, hipEventDisableTiming));
+        ctx->group_streams.push_back(gs); ctx->group_events.push_back(ge);
+    }
+    if (!ctx->fork_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+    {   // size the shared work buffers for the whole block before any group launches
+        McmcDev none{};
+        (void)none;
+        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)ctx->st.n_pad * W, false);
         if (rc) return rc;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->fork_event, s));
+    mc.w_total = W;
+    for (int g = 0; g < G; ++g) HIPCHK(ctx, hipStreamWaitEvent(ctx->group_streams[g], ctx->fork_event, 0));
+    // one host thread per group issues that group's launches (the HIP runtime is thread-safe; a
+    // single thread is launch-bound at ~6.5 us per launch).  Only group 0 brackets its
+    // star-likelihood launches with timing events.
+    std::vector<int> group_rc(G, B9_OK);
+    auto run_group = [&](int g) {
+        (void)hipSetDevice(ctx->device);
+        const int w0 = (int)((long long)W * g / G), w1 = (int)((long long)W * (g + 1) / G);
+        if (w1 <= w0) return;
+        for (int k = 0; k < S; ++k) {
+            McmcDev m = mc;
+            m.step = (unsigned long long)(blk->step0 + k);
+            m.row = k;
+            m.fuse_next = (fuse && k + 1 < S) ? fuse : 0;
+            m.w_off = w0;
+            m.cur = mc.cur + (size_t)w0 * B9_NPARAM; m.lp_cur = mc.lp_cur + w0; m.walker_ids = mc.walker_ids + w0;
+            const int set = fuse ? (k & 1) : 0;
+            double *prm = ctx->d_params + ((size_t)set * ctx->cap_walkers + w0) * B9_NPARAM;
+            int r = launch_logpost(ctx, prm, w1 - w0, ctx->d_logpost + w0, nullptr, m, ctx->group_streams[g], set,
+                                   /*run_k0=*/fuse < 2 || k == 0, /*k0_proposes=*/fuse == 0 || k == 0, w0, W,
+                                   /*allow_timing=*/g == 0);
+            if (r) { group_rc[g] = r; return; }
+        }
+    };
+    if (G == 1) run_group(0);
+    else {
+        std::vector<std::thread> th;
+        for (int g = 1; g < G; ++g) th.emplace_back(run_group, g);
+        run_group(0);
+        for (auto &t : th) t.join();
+    }
+    for (int g = 0; g < G; ++g) if (group_rc[g]) return group_rc[g];
+    for (int g = 0; g < G; ++g) {
+        HIPCHK(ctx, hipEventRecord(ctx->group_events[g], ctx->group_streams[g]));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->group_events[g], 0));
     }
     unsigned long long n_acc = 0;
     HIPCHK(ctx, hipMemcpyAsync(blk->params, mc.cur, n_cur * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -587,7 +674,8 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     int rc = check_ready(ctx);
     if (rc) return rc;
     const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
-    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)std::max(plan.n_groups * 4, ctx->st.n_pad) * n_walkers, out_perstar != nullptr);
+    (void)plan;
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)ctx->st.n_pad * n_walkers, out_perstar != nullptr);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
     rc = b9_logpost_device(ctx, ctx->d_params, n_walkers, ctx->d_logpost, out_perstar ? ctx->d_perstar : nullptr, ctx->stream);

@@ -74,4 +74,6 @@ struct McmcDev {
     double *lps;                     // [n_steps][W] or null
     unsigned long long *n_acc;       // accepted proposals
     int row;                         // step index inside the block
+    int fuse_next;                   // k_finalize also proposes + derives the next step
+    int w_total, w_off;              // walkers in the whole block / first walker of this launch (stream groups)
 };

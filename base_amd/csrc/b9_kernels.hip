@@ -198,47 +198,46 @@ __device__ __forceinline__ int bracket_wave(const double *__restrict__ ax, int n
     return i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
 }
 
-// grid = (walkers * pops, ceil(mass_cap * (nfp + 1) / 256)): every block re-derives the (cheap)
-// header -- three dependent round trips: {parameters, axes} -> corner index rows -> table
-// values -- and then each THREAD produces exactly one output value, so the table reads of one
-// isochrone are a single round trip spread over ~15 workgroups.  Block y == 0 publishes the header.
-__global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restrict__ params,
-                                                     int n_pops, IsoHdr *__restrict__ hdr,
-                                                     double *__restrict__ iso_data, long long iso_stride,
-                                                     int mass_cap, McmcDev mc)
+// Metropolis proposal of walker w for step `step` (device-resident sampler), by the first few
+// threads of a workgroup:  s_par = cur;  s_par[free[i]] += sum_j chol[i][j] z_j,  z from Philox +
+// Box-Muller.  Every workgroup that calls it with the same arguments gets the same row.
+// Contains barriers: call from all threads.
+__device__ __forceinline__ void propose_row(const McmcDev &mc, int w, unsigned long long step,
+                                            const double *__restrict__ cur_row, double *s_par, double *s_z)
 {
-    const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double *par = params + (size_t)w * B9_NPARAM;
+    const int tid = threadIdx.x, d = mc.d, n_pairs = (d + 1) >> 1;
+    if (tid < B9_NPARAM) s_par[tid] = cur_row[tid];
+    if (tid < n_pairs) {
+        unsigned r[4];
+        philox4x32((unsigned)step, (unsigned)(step >> 32), (unsigned)mc.walker_ids[w], (unsigned)tid, mc.k0, mc.k1, r);
+        const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+        const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+        s_z[2 * tid] = rad * cos(ang);
+        s_z[2 * tid + 1] = rad * sin(ang);
+    }
+    __syncthreads();
+    double delta = 0.0;
+    if (tid < d) for (int j = 0; j < d; ++j) delta = delta + mc.chol[tid * d + j] * s_z[j];
+    __syncthreads();
+    if (tid < d) s_par[mc.free_idx[tid]] += delta;
+    __syncthreads();
+}
+
+// Derives the isochrone of (walker w, population pop) from parameter row `par` (any address
+// space).  All threads of the workgroup call it; workgroup `part` of `parts` produces its share of
+// the output values (one value per thread and iteration) and part 0 publishes the header.
+// Three dependent round trips: {parameters, axes} -> corner index rows -> table values.
+__device__ __forceinline__ void derive_iso_block(const DevPack &pk, const double *par, int pop, int wp,
+                                                 IsoHdr *__restrict__ hdr, double *__restrict__ iso_data,
+                                                 long long iso_stride, int mass_cap, int part, int parts)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
     __shared__ IsoHdr sh;
     __shared__ Corners sc;
     __shared__ int s_br[3];
-    __shared__ double s_par[B9_NPARAM], s_z[12];
-    if (mc.enabled) {
-        // Metropolis proposal of walker w, recomputed identically by every block of the row:
-        //   prop = cur;  prop[free[i]] += sum_j chol[i][j] z_j,   z from Philox + Box-Muller.
-        // Block (y == 0, pop == 0) publishes the row to `params` for the two kernels that follow.
-        const int d = mc.d, n_pairs = (d + 1) >> 1;
-        if (tid < B9_NPARAM) s_par[tid] = mc.cur[(size_t)w * B9_NPARAM + tid];
-        if (tid < n_pairs) {
-            unsigned r[4];
-            philox4x32((unsigned)mc.step, (unsigned)(mc.step >> 32), (unsigned)mc.walker_ids[w], (unsigned)tid, mc.k0, mc.k1, r);
-            const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
-            const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
-            s_z[2 * tid] = rad * cos(ang);
-            s_z[2 * tid + 1] = rad * sin(ang);
-        }
-        __syncthreads();
-        double delta = 0.0;
-        if (tid < d) for (int j = 0; j < d; ++j) delta = delta + mc.chol[tid * d + j] * s_z[j];
-        __syncthreads();
-        if (tid < d) s_par[mc.free_idx[tid]] += delta;
-        __syncthreads();
-        if (blockIdx.y == 0 && pop == 0 && tid < B9_NPARAM) params[(size_t)w * B9_NPARAM + tid] = s_par[tid];
-        par = s_par;
-    }
     const double log_age = par[B9_P_LOGAGE], feh = par[B9_P_FEH];
     const double y = pop ? par[B9_P_Y2] : par[B9_P_Y];
+    __syncthreads();                                     // sh / sc / s_br may still be in use (previous call)
     // three waves bracket the three axes concurrently
     if (wave == 0) { int i = bracket_wave(pk.log_age, pk.n_age, log_age, lane); if (lane == 0) s_br[0] = i; }
     if (wave == 1) { int i = bracket_wave(pk.feh, pk.n_feh, feh, lane); if (lane == 0) s_br[1] = i; }
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restri
         const int kk = ((i_feh + df) * pk.n_y + (i_y + dyc)) * pk.n_age + i_age + da;
         int f0 = -2147483647, f1 = 2147483647;
         long long off = 0;
-        double ax0 = 0.0, ax1 = 1.0;
+        double ax0 = 0.0;
         if (lane < 8) { f0 = pk.first[kk]; f1 = f0 + pk.cnt[kk]; off = pk.off[kk]; }
         // lanes 8..13 fetch the axis values the interpolation weights need (same round trip)
         if (lane == 8)  ax0 = pk.log_age[i_age];
@@ -262,7 +261,6 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restri
         if (lane == 11) ax0 = pk.feh[i_feh + 1];
         if (lane == 12) ax0 = pk.y[i_y];
         if (lane == 13) ax0 = pk.y[ny == 2 ? i_y + 1 : i_y];
-        (void)ax1;
         int lo = f0, hi = f1;
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) {
@@ -297,26 +295,42 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restri
         }
     }
     __syncthreads();
-    if (!sh.valid) { if (tid == 0 && blockIdx.y == 0) hdr[wp] = sh; return; }
+    if (!sh.valid) { if (tid == 0 && part == 0) hdr[wp] = sh; return; }
     const int n = sh.n, nfp = pk.nfp;
     double *omass = iso_data + (size_t)wp * iso_stride;
     double *omags = omass + mass_cap;
-    const int idx = blockIdx.y * 256 + tid;
-    const int e = idx / (nfp + 1), c = idx - e * (nfp + 1);
-    double v = 0.0;
-    if (e < n) {
-        if (c == nfp) v = interp_corner<true>(pk, sc, e, 0);
-        else if (c < pk.nf) v = interp_corner<false>(pk, sc, e, c);
-    }
-    // the thread that owns the last point's mass also knows the AGB-tip mass: it publishes the header
-    if (blockIdx.y == 0 && tid == 0) {
+    // the thread that starts first also interpolates the last point's mass = the AGB-tip mass
+    if (part == 0 && tid == 0) {
         IsoHdr h = sh;
         h.agb_tip = interp_corner<true>(pk, sc, n - 1, 0);
         hdr[wp] = h;
     }
-    if (e < n) {
-        if (c == nfp) omass[e] = v; else omags[(size_t)e * nfp + c] = v;
+    const int total = n * (nfp + 1);
+    for (int idx = part * nthreads + tid; idx < total; idx += parts * nthreads) {
+        const int e = idx / (nfp + 1), c = idx - e * (nfp + 1);
+        if (c == nfp) omass[e] = interp_corner<true>(pk, sc, e, 0);
+        else omags[(size_t)e * nfp + c] = (c < pk.nf) ? interp_corner<false>(pk, sc, e, c) : 0.0;
     }
+}
+
+// grid = (walkers * pops, parts): every workgroup of a row re-derives the (cheap) header and then
+// produces its share of the values, so the table reads of one isochrone are a single round trip
+// spread over ~15 workgroups.  With mc.enabled the row is first drawn as a Metropolis proposal.
+__global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restrict__ params,
+                                                     int n_pops, IsoHdr *__restrict__ hdr,
+                                                     double *__restrict__ iso_data, long long iso_stride,
+                                                     int mass_cap, McmcDev mc)
+{
+    const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops;
+    const double *par = params + (size_t)w * B9_NPARAM;
+    __shared__ double s_par[B9_NPARAM], s_z[12];
+    if (mc.enabled) {
+        propose_row(mc, w, mc.step, mc.cur + (size_t)w * B9_NPARAM, s_par, s_z);
+        // block (y == 0, pop == 0) publishes the row to `params` for the two kernels that follow
+        if (blockIdx.y == 0 && pop == 0 && threadIdx.x < B9_NPARAM) params[(size_t)w * B9_NPARAM + threadIdx.x] = s_par[threadIdx.x];
+        par = s_par;
+    }
+    derive_iso_block(pk, par, pop, wp, hdr, iso_data, iso_stride, mass_cap, blockIdx.y, gridDim.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1029,6 +1043,25 @@ __device__ inline double log_prior_cluster(const DevPriors &pr, const double *__
 #define B9_FIN_THREADS 512
 #define B9_FIN_WAVES (B9_FIN_THREADS / 64)
 
+// Next step's proposal + isochrone derivation for walker w, inside k_finalize (all threads call).
+// Reads the walker's current row AFTER this workgroup's own accept decision.
+__device__ __forceinline__ void next_step(const DevPack &pk, const McmcDev &mc, int w, int n_pops,
+                                          double *__restrict__ params_next, IsoHdr *__restrict__ hdr_next,
+                                          double *__restrict__ iso_next, long long iso_stride, int mass_cap)
+{
+    __shared__ double s_par[B9_NPARAM], s_z[12];
+    __threadfence_block();
+    __syncthreads();                                     // thread 0's update of mc.cur[w] is done
+    propose_row(mc, w, mc.step + 1, mc.cur + (size_t)w * B9_NPARAM, s_par, s_z);
+    if (threadIdx.x < B9_NPARAM) params_next[(size_t)w * B9_NPARAM + threadIdx.x] = s_par[threadIdx.x];
+    // fuse_next == 2 also derives the isochrones here.  Measured SLOWER than a separate
+    // k_derive_iso launch (42.7 vs 36.8 us/step at 8 walkers): one workgroup per walker cannot pull
+    // the 8 corner tables (230 KB) as fast as the 15 workgroups per isochrone of k_derive_iso do.
+    if (mc.fuse_next >= 2)
+        for (int pop = 0; pop < n_pops; ++pop)
+            derive_iso_block(pk, s_par, pop, w * n_pops + pop, hdr_next, iso_next, iso_stride, mass_cap, 0, 1);
+}
+
 // Metropolis accept/reject of walker w's proposal (one thread; device-resident sampler only):
 // accept when log u < lp_prop - lp_cur, u from the walker's Philox stream (draw index n_pairs).
 __device__ inline void metropolis_accept(const McmcDev &mc, const double *__restrict__ params, int w, double lp_prop)
@@ -1045,9 +1078,11 @@ __device__ inline void metropolis_accept(const McmcDev &mc, const double *__rest
         mc.lp_cur[w] = lp_prop;
         atomicAdd(mc.n_acc, 1ull);
     }
-    const int W = gridDim.x;
-    if (mc.samples) for (int i = 0; i < mc.d; ++i) mc.samples[((size_t)mc.row * W + w) * mc.d + i] = cur[mc.free_idx[i]];
-    if (mc.lps) mc.lps[(size_t)mc.row * W + w] = ok ? lp_prop : lp_cur;
+    // cur / lp_cur / walker_ids are already offset to this launch's first walker; the chain
+    // records are indexed by the walker's position in the whole block
+    const size_t rec = (size_t)mc.row * mc.w_total + mc.w_off + w;
+    if (mc.samples) for (int i = 0; i < mc.d; ++i) mc.samples[rec * mc.d + i] = cur[mc.free_idx[i]];
+    if (mc.lps) mc.lps[rec] = ok ? lp_prop : lp_cur;
 }
 
 // block-wide sum of one int per thread (all threads get the result)
@@ -1072,7 +1107,9 @@ __global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStar
                                                               const double *__restrict__ partial, int n_partial,
                                                               const double *__restrict__ params, DevPriors pr,
                                                               double *__restrict__ logpost,
-                                                              double *__restrict__ perstar, int axes_in_lds, McmcDev mc)
+                                                              double *__restrict__ perstar, int axes_in_lds, McmcDev mc,
+                                                              double *__restrict__ params_next, IsoHdr *__restrict__ hdr_next,
+                                                              double *__restrict__ iso_next)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];   // WD axes (when axes_in_lds)
     __shared__ double s_red[B9_FIN_WAVES];
@@ -1092,6 +1129,7 @@ __global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStar
         // kernel; the oracle reports -inf for them as well
         if (perstar && valid)
             for (int i = tid; i < st.n; i += B9_FIN_THREADS) perstar[(size_t)w * st.n + i] = NEG_INF;
+        if (mc.enabled && mc.fuse_next) next_step(pk, mc, w, NPOPS, params_next, hdr_next, iso_next, iso_stride, mass_cap);
         return;
     }
     // (1) heavy stars: count = first k with heavy_mass[k] <= tip_min, by a 512-ary search in
@@ -1163,6 +1201,9 @@ __global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStar
         logpost[w] = lp + t;   // (3)
         if (mc.enabled) metropolis_accept(mc, params, w, lp + t);
     }
+    // (4) device-resident sampler: with the accept decision made, draw the NEXT step's proposal
+    //     and derive its isochrone(s) right here -- one launch and one kernel boundary fewer per step
+    if (mc.enabled && mc.fuse_next) next_step(pk, mc, w, NPOPS, params_next, hdr_next, iso_next, iso_stride, mass_cap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1208,7 +1249,7 @@ static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const I
                                   const double *iso_data, long long iso_stride, int mass_cap,
                                   const double *partial, int n_partial, const double *d_params,
                                   const DevPriors &pr, int n_walkers, double *d_logpost, double *perstar,
-                                  const McmcDev &mc, bool marg, hipStream_t stream)
+                                  const McmcDev &mc, bool marg, const B9Next &nx, hipStream_t stream)
 {
     const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
     size_t lds = has_wd ? sizeof(double) * ((size_t)(1 + 4 * NPOPS) * pk.n_age + pk.n_wc_age + pk.n_wc_mass + pk.n_wc_carb +
@@ -1217,7 +1258,8 @@ static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const I
     if (!in_lds) lds = 0;
     if (marg) in_lds = -1;
     hipLaunchKernelGGL((k_finalize<NFP, NPOPS>), dim3(n_walkers), dim3(B9_FIN_THREADS), lds, stream, pk, st, hdr,
-                       iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, d_logpost, perstar, in_lds, mc);
+                       iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, d_logpost, perstar, in_lds, mc,
+                       nx.params, nx.hdr, nx.iso);
     return hipGetLastError();
 }
 
@@ -1247,9 +1289,9 @@ hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 hipError_t b9k_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                         long long iso_stride, int mass_cap, const double *partial, int n_partial, int n_pops,
                         const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        double *perstar, const McmcDev &mc, bool marg, hipStream_t stream)
+                        double *perstar, const McmcDev &mc, bool marg, const B9Next &nx, hipStream_t stream)
 {
-#define FN_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, n_walkers, d_logpost, perstar, mc, marg, stream
+#define FN_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, n_walkers, d_logpost, perstar, mc, marg, nx, stream
 #define FN2(NFP) launch_finalize<NFP, 2>(FN_ARGS)
 #define FN1(NFP) launch_finalize<NFP, 1>(FN_ARGS)
     B9_SWITCH_NFP(FN2, FN1)

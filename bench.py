@@ -66,12 +66,32 @@ def cpu_baseline(pack_d, cl, truth, budget_s: float = 12.0):
                       f"BASE-9 itself is not mounted: build's CPU oracle, parity unpinned)"}
 
 
+def marginalised_leg(pack, stars, priors, truth, local_rank, n_calls: int = 5):
+    """Secondary figure: the marginalised mode (one wavefront per star; every star integrated over
+    primary mass and mass ratio, 4 sub-steps per EEP interval x 4 mass ratios = 6384 nodes/star)."""
+    from base_amd import abi, engine, synth
+    K = Q = 4
+    eng = engine.Engine(pack, stars, priors, abi.make_options(abi.MODE_MARGINALISED, 1, K, Q), device=local_rank)
+    params = synth.walker_params(truth, WALKERS_PER_GPU, seed=43, scale=0.02)
+    eng.logpost(params)
+    t0 = time.perf_counter()
+    for _ in range(n_calls):
+        eng.logpost(params)
+    dt = (time.perf_counter() - t0) / n_calls
+    nodes = (eng.max_eep() - 1) * K * Q
+    eng.close()
+    return {"value": N_STARS * WALKERS_PER_GPU / dt, "unit": "star-likelihood evals/s", "iso_increm": K, "n_q": Q,
+            "nodes_per_star_eval": nodes, "node_evals_per_s": N_STARS * WALKERS_PER_GPU * nodes / dt,
+            "ms_per_logpost_call": 1e3 * dt, "calls": n_calls}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the HIP-event bracketing of k_star_like")
     args = ap.parse_args()
 
@@ -84,10 +104,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    local_rank = local_rank % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            torch.distributed.init_process_group(args.backend)
 
     # ---- synthetic inputs (identical on every rank: fixed seeds) -----------------------------
     pack_d = synth.make_pack("parsec", N_FILT)
@@ -98,7 +122,7 @@ def main():
     eng = engine.Engine(pack, stars, priors, options, device=local_rank)
     n_walkers = WALKERS_PER_GPU * world
     start = synth.walker_params(truth, n_walkers, seed=42, scale=0.02)
-    gather = mcmc.torch_all_gather("cuda") if world > 1 else None
+    gather = mcmc.torch_all_gather("cuda" if args.backend == "nccl" else None) if world > 1 else None
     block = 50
     sampler = mcmc.WalkerSampler(start, mcmc.DeviceBlockRunner(eng, record=True), rank, world, gather,
                                  seed=2024, block=block)
@@ -122,7 +146,7 @@ def main():
     eng.enable_timing(0)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -132,6 +156,16 @@ def main():
         bytes_launch = float(bytes_eval) * N_STARS * WALKERS_PER_GPU
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
         achieved = bytes_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        # HBM traffic per launch of the dominant kernel: from the committed PMC passes of this same
+        # command (profiles/<round>_summary.json, tools/profile_round.sh); null when absent
+        traffic = None
+        for tag in ("r01",):
+            pth = os.path.join(ROOT, "profiles", f"{tag}_summary.json")
+            if os.path.exists(pth):
+                pm = json.load(open(pth)).get("pmc", {})
+                for kname, c in pm.items():
+                    if kname.startswith("k_star_like") and "hbm_bytes_per_launch" in c:
+                        traffic = c["hbm_bytes_per_launch"]
         out = {
             "metric": "star-likelihood evals/sec", "value": evals / dt, "unit": "star-likelihood evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -145,7 +179,7 @@ def main():
                        "mcmc_block": block,
                        "collective": "one all_gather of [logpost, position, moments] rows per 50-step block" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_star_like", "launches_timed": k_n, "timed_every": TIMING_EVERY,
                          "avg_launch_us": 1e6 * k_avg_s,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_star_eval": bytes_eval},
@@ -155,6 +189,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pack_d, cl, truth)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1:
+            out["marginalised_mode"] = marginalised_leg(pack, stars, priors, truth, local_rank)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
