@@ -21,7 +21,7 @@ HIP_LIB = os.path.join(CSRC, "libbase9hip.so")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-             "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"]
+             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
 def _newer(target: str, sources: List[str]) -> bool:

@@ -15,7 +15,6 @@
 #include <cstring>
 #include <numeric>
 #include <string>
-#include <thread>
 #include <vector>
 
 namespace {
@@ -63,11 +62,6 @@ struct b9_ctx {
     // launch plan
     int tiles_per_block = 0;   // 0 = auto
     int walkers_per_lane = 1;  // WB template parameter of k_star_like (1 or 2)
-    int stream_groups = 1;     // b9_mcmc_run_block: walker groups on their own streams + host threads (measured: no gain in one process)
-    std::vector<hipStream_t> group_streams;
-    std::vector<hipEvent_t> group_events;
-    hipEvent_t fork_event = nullptr;
-    int fuse_steps = 0;        // device sampler: 1/2 = k_finalize also proposes (+ derives) the next step; measured no faster
 
     // timing of the dominant kernel
     int timing = 0;            // 0 off, n > 0: bracket every n-th launch of the dominant kernel with events
@@ -315,8 +309,6 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     ctx->pr.log_age_min = -INFINITY; ctx->pr.log_age_max = INFINITY;
     if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
     if (const char *s = getenv("B9_WALKERS_PER_LANE")) ctx->walkers_per_lane = atoi(s) >= 2 ? 2 : 1;
-    if (const char *s = getenv("B9_FUSE_STEPS")) ctx->fuse_steps = atoi(s);
-    if (const char *s = getenv("B9_STREAM_GROUPS")) ctx->stream_groups = std::max(1, atoi(s));
     *out = ctx;
     return B9_OK;
 }
@@ -332,9 +324,6 @@ void b9_ctx_destroy(b9_ctx *ctx)
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
-    for (auto e : ctx->group_events) (void)hipEventDestroy(e);
-    for (auto gs : ctx->group_streams) (void)hipStreamDestroy(gs);
-    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -468,51 +457,39 @@ int b9_set_options(b9_ctx *ctx, const b9_options *o)
     return B9_OK;
 }
 
-// The stream-ordered launches of one log-posterior evaluation: k_derive_iso -> k_star_like (or
-// k_star_marg) -> k_finalize.  Work buffers come in two sets (ping-pong).  With mc.enabled the
-// first kernel also draws the Metropolis proposal (writing it to the set's parameter rows) and the
-// last one accepts or rejects it; with mc.fuse_next the last kernel additionally draws the NEXT
-// step's proposal and derives its isochrones into the other set, so that the next step starts at
-// the star-likelihood kernel (run_k0 = false): two launches per MCMC step.
-static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, double *d_logpost,
-                          double *d_perstar, const McmcDev &mc, hipStream_t stream, int set = 0, bool run_k0 = true,
-                          bool k0_proposes = true, int w_off = 0, int w_cap = 0, bool allow_timing = true)
+#define B9_HEAVY_PARTS 4        // workgroups per walker for the stars above the AGB tip
+
+struct Bufs { double *params; IsoHdr *hdr; double *iso; };
+
+// ping-pong work-buffer set (0 / 1)
+static Bufs buffer_set(const b9_ctx *ctx, int set)
 {
-    // w_off / w_cap: this launch evaluates walkers [w_off, w_off + n_walkers) of a larger batch of
-    // w_cap walkers (stream groups of b9_mcmc_run_block); its slices of the work buffers start there
+    const size_t rows = (size_t)ctx->cap_walkers * ctx->cap_pops;
+    return Bufs{ctx->d_params + (size_t)set * ctx->cap_walkers * B9_NPARAM, ctx->d_hdr + (size_t)set * rows,
+                ctx->d_iso + (size_t)set * rows * ctx->iso_stride};
+}
+
+// number of partial sums one walker gets from the star kernel under the current plan / mode
+static int partial_count(const b9_ctx *ctx, const Plan &plan)
+{
+    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.n_pad : plan.n_groups * 4 + B9_HEAVY_PARTS;
+}
+
+// The star-likelihood launch (given-mass: hot + heavy workgroups; marginalised: one wave per star)
+// on buffer set `set`, bracketed by timing events when sampled.
+static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *d_perstar, const Plan &plan,
+                        hipStream_t stream)
+{
     const int n_pops = ctx->opt.n_pops;
-    const Plan plan = make_plan(ctx, n_walkers, n_pops);
-    const bool marg = ctx->opt.mode == B9_MODE_MARGINALISED;
-    const size_t n_part = marg ? (size_t)ctx->st.n_pad : (size_t)plan.n_groups * 4;
-    // partial sums: one slice of n_pad doubles per walker covers every plan (n_part <= n_pad)
-    int rc = ensure_capacity(ctx, std::max(n_walkers, w_cap), n_pops, (size_t)ctx->st.n_pad * std::max(n_walkers, w_cap), false);
-    if (rc) return rc;
-    const size_t set_rows = (size_t)ctx->cap_walkers * ctx->cap_pops;
-    IsoHdr *hdr = ctx->d_hdr + (size_t)set * set_rows + (size_t)w_off * n_pops;
-    double *iso = ctx->d_iso + ((size_t)set * set_rows + (size_t)w_off * n_pops) * ctx->iso_stride;
-    double *const d_partial = ctx->d_partial + (size_t)w_off * ctx->st.n_pad;
-    B9Next nx{nullptr, nullptr, nullptr};
-    if (mc.enabled && mc.fuse_next) {
-        nx.params = ctx->d_params + ((size_t)(set ^ 1) * ctx->cap_walkers + w_off) * B9_NPARAM;
-        nx.hdr = ctx->d_hdr + (size_t)(set ^ 1) * set_rows + (size_t)w_off * n_pops;
-        nx.iso = ctx->d_iso + ((size_t)(set ^ 1) * set_rows + (size_t)w_off * n_pops) * ctx->iso_stride;
-    }
-    if (run_k0) {
-        McmcDev mc0 = mc;
-        if (!k0_proposes) mc0.enabled = 0;       // the row was already drawn by the previous k_finalize
-        HIPCHK(ctx, b9k_derive_iso(ctx->pk, d_params, n_walkers, n_pops, hdr, iso, ctx->iso_stride, ctx->mass_cap, mc0, stream));
-    }
-    if (marg) {
+    if (ctx->opt.mode == B9_MODE_MARGINALISED) {
         const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
         const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
-        HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, hdr, iso, ctx->iso_stride, ctx->mass_cap, d_params,
-                                  n_walkers, n_pops, d_partial, d_perstar, K, Q, stream));
-        HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, hdr, iso, ctx->iso_stride, ctx->mass_cap, d_partial,
-                                 (int)n_part, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, true, nx, stream));
+        HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
+                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, stream));
         return B9_OK;
     }
     size_t slot = 0;
-    const bool timed = allow_timing && ctx->timing > 0 && (ctx->launch_no++ % (unsigned)ctx->timing) == 0;
+    const bool timed = ctx->timing > 0 && (ctx->launch_no++ % (unsigned)ctx->timing) == 0;
     if (timed) {
         if (ctx->ev_used == ctx->ev_start.size()) {
             hipEvent_t a, b;
@@ -523,12 +500,32 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
         slot = ctx->ev_used++;
         HIPCHK(ctx, hipEventRecord(ctx->ev_start[slot], stream));
     }
-    HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, hdr, iso, ctx->iso_stride, ctx->mass_cap, d_params,
-                              n_walkers, n_pops, ctx->walkers_per_lane, d_partial, d_perstar, plan.tiles_per_block,
-                              plan.n_groups, stream));
+    HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
+                              n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, ctx->st.n_pad, d_perstar,
+                              plan.tiles_per_block, plan.n_groups, B9_HEAVY_PARTS, stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
-    HIPCHK(ctx, b9k_finalize(ctx->pk, ctx->st, hdr, iso, ctx->iso_stride, ctx->mass_cap, d_partial,
-                             plan.n_groups * 4, n_pops, d_params, ctx->pr, n_walkers, d_logpost, d_perstar, mc, false, nx, stream));
+    return B9_OK;
+}
+
+// One log-posterior evaluation of rows that are already in buffer set 0's parameter rows (or in
+// d_params when that is a caller's device pointer): derive -> stars -> finalize.
+static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, double *d_logpost,
+                          double *d_perstar, hipStream_t stream)
+{
+    const int n_pops = ctx->opt.n_pops;
+    const Plan plan = make_plan(ctx, n_walkers, n_pops);
+    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)ctx->st.n_pad * n_walkers, false);
+    if (rc) return rc;
+    Bufs bf = buffer_set(ctx, 0);
+    bf.params = d_params;
+    const McmcDev off{};
+    const B9Prev none{nullptr, 0, 0, nullptr, nullptr};
+    HIPCHK(ctx, b9k_derive_iso(ctx->pk, bf.params, n_walkers, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap,
+                               off, ctx->pr, none, stream));
+    rc = launch_stars(ctx, bf, n_walkers, d_perstar, plan, stream);
+    if (rc) return rc;
+    HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, partial_count(ctx, plan), ctx->st.n_pad, n_pops, bf.params, ctx->pr,
+                             n_walkers, d_logpost, d_perstar, ctx->st.n, off, stream));
     return B9_OK;
 }
 
@@ -547,11 +544,14 @@ int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, do
     int rc = check_ready(ctx);
     if (rc) return rc;
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
-    McmcDev mc{};
-    return launch_logpost(ctx, const_cast<double *>(d_params), n_walkers, d_logpost, d_perstar, mc, stream);
+    return launch_logpost(ctx, const_cast<double *>(d_params), n_walkers, d_logpost, d_perstar, stream);
 }
 
-/* Device-resident Metropolis block (the caller of the hot path). */
+/* Device-resident Metropolis block (the caller of the hot path).
+ * Launch sequence for S steps:  D(0) L(0)  D(1) L(1)  ...  D(S-1) L(S-1)  F
+ *   D(t) = k_derive_iso: finishes step t-1 (sum + prior + accept; t > 0), proposes step t, derives
+ *   L(t) = star likelihood of step t's proposals;   F = k_finalize: finishes the last step.
+ * Two launches per step; buffers and walker state ping-pong between two halves. */
 int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
 {
     if (!ctx || !blk || blk->n_walkers < 1 || blk->n_steps < 0 || blk->n_free < 1 || blk->n_free > 11 ||
@@ -559,19 +559,17 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
         return B9_ERR_INVALID;
     int rc = check_ready(ctx);
     if (rc) return rc;
-    const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps;
+    const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps, n_pops = ctx->opt.n_pops;
     for (int i = 0; i < d; ++i)
         if (blk->free_idx[i] < 0 || blk->free_idx[i] >= B9_NPARAM) return fail(ctx, B9_ERR_INVALID, "free_idx out of range");
-    {   // make sure the shared work buffers exist before taking pointers into them
-        const Plan plan = make_plan(ctx, W, ctx->opt.n_pops);
-        (void)plan;
-        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)ctx->st.n_pad * W, false);
-        if (rc) return rc;
-    }
+    if (S == 0) { blk->n_accept = 0; return B9_OK; }
+    const Plan plan = make_plan(ctx, W, n_pops);
+    rc = ensure_capacity(ctx, W, n_pops, (size_t)ctx->st.n_pad * W, false);
+    if (rc) return rc;
     // one device allocation for the block's state
     const size_t n_cur = (size_t)W * B9_NPARAM, n_samp = blk->samples ? (size_t)S * W * d : 0,
                  n_lps = blk->lps ? (size_t)S * W : 0;
-    const size_t doubles = n_cur + W + (size_t)d * d + n_samp + n_lps + 1;
+    const size_t doubles = 2 * n_cur + 2 * (size_t)W + (size_t)d * d + n_samp + n_lps + 1;
     const size_t bytes = doubles * sizeof(double) + (size_t)(d + W) * sizeof(int);
     if (bytes > ctx->mcmc_cap) {
         if (ctx->d_mcmc) (void)hipFree(ctx->d_mcmc);
@@ -581,9 +579,9 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     }
     double *p = static_cast<double *>(ctx->d_mcmc);
     McmcDev mc{};
-    mc.enabled = 1; mc.d = d;
-    mc.cur = p; p += n_cur;
-    mc.lp_cur = p; p += W;
+    mc.enabled = 1; mc.d = d; mc.n_walkers = W;
+    mc.cur = p; p += 2 * n_cur;
+    mc.lp_cur = p; p += 2 * (size_t)W;
     double *d_chol = p; p += (size_t)d * d;
     mc.samples = n_samp ? p : nullptr; p += n_samp;
     mc.lps = n_lps ? p : nullptr; p += n_lps;
@@ -598,68 +596,33 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     HIPCHK(ctx, hipMemcpyAsync(d_free, blk->free_idx, d * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(d_ids, blk->walker_ids, W * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemsetAsync(mc.n_acc, 0, sizeof(unsigned long long), s));
-    // Stream groups: the local walkers are independent chains, so they are split into G groups
-    // that run on their own streams -- the latency-bound small kernels of one group overlap the
-    // star-likelihood kernel of another (measured: two groups ~1.4x the throughput of one).
-    // fuse_steps: 0 (default) = k_derive_iso draws each step's proposal; 1 = k_finalize draws the
-    // next step's proposal right after its accept decision and k_derive_iso only derives;
-    // 2 = k_finalize also derives the next isochrones (two launches per step; measured slower)
-    const int fuse = ctx->fuse_steps;
-    int G = std::max(1, std::min(ctx->stream_groups, W));
-    while ((int)ctx->group_streams.size() < G) {
-        hipStream_t gs; hipEvent_t ge;
-        HIPCHK(ctx, hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ge, hipEventDisableTiming));
-        ctx->group_streams.push_back(gs); ctx->group_events.push_back(ge);
-    }
-    if (!ctx->fork_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
-    {   // size the shared work buffers for the whole block before any group launches
-        McmcDev none{};
-        (void)none;
-        rc = ensure_capacity(ctx, W, ctx->opt.n_pops, (size_t)ctx->st.n_pad * W, false);
+    const int n_part = partial_count(ctx, plan);
+    for (int t = 0; t < S; ++t) {
+        const Bufs bf = buffer_set(ctx, t & 1), bp = buffer_set(ctx, (t & 1) ^ 1);
+        mc.step = (unsigned long long)(blk->step0 + t);     // the step being proposed
+        mc.has_prev = t > 0;
+        mc.pin = t > 0 ? (t - 1) & 1 : 0;                   // state half on entry
+        mc.row = t - 1;                                     // chain row of the step being finished
+        const B9Prev prev{ctx->d_partial, n_part, (long long)ctx->st.n_pad, bp.hdr, bp.params};
+        HIPCHK(ctx, b9k_derive_iso(ctx->pk, bf.params, W, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap,
+                                   mc, ctx->pr, prev, s));
+        rc = launch_stars(ctx, bf, W, nullptr, plan, s);
         if (rc) return rc;
     }
-    HIPCHK(ctx, hipEventRecord(ctx->fork_event, s));
-    mc.w_total = W;
-    for (int g = 0; g < G; ++g) HIPCHK(ctx, hipStreamWaitEvent(ctx->group_streams[g], ctx->fork_event, 0));
-    // one host thread per group issues that group's launches (the HIP runtime is thread-safe; a
-    // single thread is launch-bound at ~6.5 us per launch).  Only group 0 brackets its
-    // star-likelihood launches with timing events.
-    std::vector<int> group_rc(G, B9_OK);
-    auto run_group = [&](int g) {
-        (void)hipSetDevice(ctx->device);
-        const int w0 = (int)((long long)W * g / G), w1 = (int)((long long)W * (g + 1) / G);
-        if (w1 <= w0) return;
-        for (int k = 0; k < S; ++k) {
-            McmcDev m = mc;
-            m.step = (unsigned long long)(blk->step0 + k);
-            m.row = k;
-            m.fuse_next = (fuse && k + 1 < S) ? fuse : 0;
-            m.w_off = w0;
-            m.cur = mc.cur + (size_t)w0 * B9_NPARAM; m.lp_cur = mc.lp_cur + w0; m.walker_ids = mc.walker_ids + w0;
-            const int set = fuse ? (k & 1) : 0;
-            double *prm = ctx->d_params + ((size_t)set * ctx->cap_walkers + w0) * B9_NPARAM;
-            int r = launch_logpost(ctx, prm, w1 - w0, ctx->d_logpost + w0, nullptr, m, ctx->group_streams[g], set,
-                                   /*run_k0=*/fuse < 2 || k == 0, /*k0_proposes=*/fuse == 0 || k == 0, w0, W,
-                                   /*allow_timing=*/g == 0);
-            if (r) { group_rc[g] = r; return; }
-        }
-    };
-    if (G == 1) run_group(0);
-    else {
-        std::vector<std::thread> th;
-        for (int g = 1; g < G; ++g) th.emplace_back(run_group, g);
-        run_group(0);
-        for (auto &t : th) t.join();
+    {   // finish the last step
+        const Bufs bf = buffer_set(ctx, (S - 1) & 1);
+        mc.step = (unsigned long long)(blk->step0 + S - 1);
+        mc.has_prev = 0;
+        mc.pin = S > 1 ? (S - 2) & 1 : 0;                   // the half D(S-1) wrote (or the initial half)
+        if (S > 1) mc.pin ^= 1;
+        mc.row = S - 1;
+        HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, n_part, ctx->st.n_pad, n_pops, bf.params, ctx->pr, W,
+                                 ctx->d_logpost, nullptr, ctx->st.n, mc, s));
     }
-    for (int g = 0; g < G; ++g) if (group_rc[g]) return group_rc[g];
-    for (int g = 0; g < G; ++g) {
-        HIPCHK(ctx, hipEventRecord(ctx->group_events[g], ctx->group_streams[g]));
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->group_events[g], 0));
-    }
+    const int fin = mc.pin ^ 1;                             // half that holds the final state
     unsigned long long n_acc = 0;
-    HIPCHK(ctx, hipMemcpyAsync(blk->params, mc.cur, n_cur * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipMemcpyAsync(blk->logpost, mc.lp_cur, W * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(blk->params, mc.cur + (size_t)fin * n_cur, n_cur * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(blk->logpost, mc.lp_cur + (size_t)fin * W, W * sizeof(double), hipMemcpyDeviceToHost, s));
     if (n_samp) HIPCHK(ctx, hipMemcpyAsync(blk->samples, mc.samples, n_samp * sizeof(double), hipMemcpyDeviceToHost, s));
     if (n_lps) HIPCHK(ctx, hipMemcpyAsync(blk->lps, mc.lps, n_lps * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(&n_acc, mc.n_acc, sizeof n_acc, hipMemcpyDeviceToHost, s));
@@ -700,7 +663,7 @@ int b9_derive_isochrone(b9_ctx *ctx, const double *param_row, int32_t pop, int32
     std::memcpy(row, param_row, sizeof row);
     if (pop) row[B9_P_Y] = row[B9_P_Y2];
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, row, sizeof row, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, b9k_derive_iso(ctx->pk, ctx->d_params, 1, 1, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, McmcDev{}, ctx->stream));
+    HIPCHK(ctx, b9k_derive_iso(ctx->pk, ctx->d_params, 1, 1, ctx->d_hdr, ctx->d_iso, ctx->iso_stride, ctx->mass_cap, McmcDev{}, ctx->pr, B9Prev{nullptr, 0, 0, nullptr, nullptr}, ctx->stream));
     IsoHdr h;
     HIPCHK(ctx, hipMemcpyAsync(&h, ctx->d_hdr, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -731,6 +694,43 @@ int b9_enable_timing(b9_ctx *ctx, int on)
     if (!ctx) return B9_ERR_INVALID;
     ctx->timing = on > 0 ? on : 0;
     ctx->launch_no = 0;
+    if (on > 0) {   // create the event pool now: hipEventCreate inside a timed region costs ~40 us each
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        while (ctx->ev_start.size() < 512) {
+            hipEvent_t a, b;
+            HIPCHK(ctx, hipEventCreate(&a));
+            HIPCHK(ctx, hipEventCreate(&b));
+            ctx->ev_start.push_back(a); ctx->ev_stop.push_back(b);
+        }
+    }
+    return B9_OK;
+}
+
+int b9_calibrate_timing(b9_ctx *ctx, double *bracket_overhead_ms)
+{
+    if (!ctx || !bracket_overhead_ms) return B9_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int reps = 64;
+    std::vector<hipEvent_t> ea(reps), eb(reps);
+    for (int i = 0; i < reps; ++i) { HIPCHK(ctx, hipEventCreate(&ea[i])); HIPCHK(ctx, hipEventCreate(&eb[i])); }
+    // Queue everything behind a ~1.5 ms spin so the brackets execute back to back, as the real
+    // launches do; each has the real bracket's shape: predecessor kernel, start event, kernel, stop event.
+    HIPCHK(ctx, b9k_spin(1500.0, ctx->stream));
+    for (int i = 0; i < reps; ++i) {
+        HIPCHK(ctx, b9k_noop(ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ea[i], ctx->stream));
+        HIPCHK(ctx, b9k_noop(ctx->stream));
+        HIPCHK(ctx, hipEventRecord(eb[i], ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ea[i], eb[i]));
+        tot += ms;
+        (void)hipEventDestroy(ea[i]); (void)hipEventDestroy(eb[i]);
+    }
+    *bracket_overhead_ms = tot / reps;
     return B9_OK;
 }
 

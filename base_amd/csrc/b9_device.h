@@ -61,19 +61,25 @@ struct DevPriors {
 
 // Device-resident Metropolis state of the local walkers (b9_mcmc_run_block).  Passed by value;
 // enabled == 0 makes the kernels behave as the plain log-posterior path.
+//
+// State is kept twice (ping-pong): the derive kernel of step t first FINISHES step t-1 -- every
+// workgroup of a walker re-sums that walker's partials, adds the prior and takes the same
+// accept/reject decision from state half `pin`; one of them stores the new state into the other
+// half -- and then draws the proposal of step t from it.  A step is therefore two launches.
 struct McmcDev {
     int enabled, d;                  // d = number of free parameters (<= 11)
-    double *cur;                     // [W][12] current positions
-    double *lp_cur;                  // [W]
+    int has_prev;                    // k_derive_iso: finish (sum + prior + accept) the previous step first
+    int pin;                         // half of cur / lp_cur that holds the state on entry
+    int n_walkers;                   // W: stride of the halves and of the chain records
+    int row;                         // row of the chain record written by THIS launch's accept
+    double *cur;                     // [2][W][12] positions
+    double *lp_cur;                  // [2][W]
     const double *chol;              // [d][d] row-major proposal factor
     const int *free_idx;             // [d]
     const int *walker_ids;           // [W] global walker ids (RNG streams)
     unsigned k0, k1;                 // Philox key (seed)
-    unsigned long long step;         // global step number of this launch
+    unsigned long long step;         // k_derive_iso: step being PROPOSED; k_finalize: step being ACCEPTED
     double *samples;                 // [n_steps][W][d] or null
     double *lps;                     // [n_steps][W] or null
     unsigned long long *n_acc;       // accepted proposals
-    int row;                         // step index inside the block
-    int fuse_next;                   // k_finalize also proposes + derives the next step
-    int w_total, w_off;              // walkers in the whole block / first walker of this launch (stream groups)
 };

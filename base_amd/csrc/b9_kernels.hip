@@ -19,6 +19,7 @@
 // No MFMA anywhere: there is no dense contraction on this path (BASELINE.json north_star).
 #include "b9_device.h"
 #include "b9_launch.h"
+#include <algorithm>
 #include "../../include/base9_hip.h"
 
 #define LOG_G_PLUS_LOG_MSUN 26.12302173752
@@ -156,6 +157,118 @@ __device__ __forceinline__ double u01(unsigned hi, unsigned lo)
 }
 
 // ------------------------------------------------------------------------------------------
+// Finishing a log-posterior evaluation: fixed-order sum of a walker's partials + cluster prior
+// (SURVEY 8a row a8), and -- for the device-resident sampler -- the Metropolis accept/reject.
+// Used by k_finalize (one workgroup per walker) and, redundantly by every workgroup of a walker,
+// as the prologue of the NEXT step's k_derive_iso.
+// ------------------------------------------------------------------------------------------
+__device__ inline double log_prior_cluster(const DevPriors &pr, const double *__restrict__ par, int n_pops)
+{
+    if (!(par[B9_P_LOGAGE] >= pr.log_age_min && par[B9_P_LOGAGE] <= pr.log_age_max)) return NEG_INF;
+    if (par[B9_P_ABS] < 0.0) return NEG_INF;
+    if (n_pops == 2 && !(par[B9_P_LAMBDA] >= 0.0 && par[B9_P_LAMBDA] <= 1.0)) return NEG_INF;
+    double lp = 0.0;
+    for (int k = 0; k < B9_NPARAM; ++k) {
+        if (k == B9_P_LOGAGE) continue;
+        if (n_pops < 2 && (k == B9_P_Y2 || k == B9_P_LAMBDA)) continue;
+        if (pr.var[k] > 0.0) {
+            double d = par[k] - pr.mean[k];
+            lp -= 0.5 * d * d / pr.var[k];
+        }
+    }
+    return lp;
+}
+
+// block-wide sum of one int per thread (all threads get the result); blockDim.x = 256
+__device__ __forceinline__ int block_count(bool pred, int *s_cnt)
+{
+    const int tid = threadIdx.x;
+    const int c = __popcll(__ballot(pred));
+    __syncthreads();                       // s_cnt may still be read from the previous round
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
+    __syncthreads();
+    return (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+}
+
+// log-posterior of walker w from its partials; all 256 threads call, all get the value.
+// The summation order is fixed (thread-strided, wave shuffle tree, four wave totals in order), so
+// every workgroup that calls this for the same walker obtains the same bits.
+__device__ __forceinline__ double finish_logpost(const IsoHdr *__restrict__ hdr, const double *__restrict__ partial,
+                                                 int n_partial, const double *__restrict__ par_row,
+                                                 const DevPriors &pr, int n_pops, int w, double *s_red,
+                                                 bool *in_support = nullptr)
+{
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int j = tid; j < n_partial; j += 256) acc += partial[j];
+    bool valid = true;
+    for (int k = 0; k < n_pops; ++k) valid = valid && hdr[w * n_pops + k].valid;
+    const double lp = log_prior_cluster(pr, par_row, n_pops);
+    const double sum = wave_sum(acc);
+    __syncthreads();                       // s_red may still be read by an earlier use
+    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+    __syncthreads();
+    const double t = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (in_support) *in_support = valid && lp != NEG_INF;      // inside the grid and the prior's support
+    return (valid && lp != NEG_INF) ? lp + t : NEG_INF;
+}
+
+// Metropolis accept/reject of walker w's proposal `prop_row` with log-posterior lp_prop
+// (SURVEY 8f row 1).  All threads call (the decision is needed by all); the new state lands in
+// s_cur[12] / *s_lp (LDS); `writer` workgroups also store it to the other state half and append
+// the chain record.  u comes from the walker's Philox stream (draw index n_pairs of step `step`).
+__device__ __forceinline__ void metropolis_accept(const McmcDev &mc, int w, unsigned long long step, int row,
+                                                  const double *__restrict__ prop_row, double lp_prop,
+                                                  bool writer, double *s_cur, double *s_lp)
+{
+    const int tid = threadIdx.x;
+    unsigned r[4];
+    philox4x32((unsigned)step, (unsigned)(step >> 32), (unsigned)mc.walker_ids[w], (unsigned)((mc.d + 1) >> 1), mc.k0, mc.k1, r);
+    const double u = u01(r[0], r[1]);
+    const double *cur_in = mc.cur + ((size_t)mc.pin * mc.n_walkers + w) * B9_NPARAM;
+    const double lp_cur = mc.lp_cur[(size_t)mc.pin * mc.n_walkers + w];
+    const bool ok = isfinite(lp_prop) && (log(u) < lp_prop - lp_cur);
+    __syncthreads();
+    if (tid < B9_NPARAM) s_cur[tid] = ok ? prop_row[tid] : cur_in[tid];
+    if (tid == 0) *s_lp = ok ? lp_prop : lp_cur;
+    __syncthreads();
+    if (writer) {
+        double *cur_out = mc.cur + ((size_t)(mc.pin ^ 1) * mc.n_walkers + w) * B9_NPARAM;
+        if (tid < B9_NPARAM) cur_out[tid] = s_cur[tid];
+        if (tid == 0) {
+            mc.lp_cur[(size_t)(mc.pin ^ 1) * mc.n_walkers + w] = *s_lp;
+            if (ok) atomicAdd(mc.n_acc, 1ull);
+            if (mc.lps) mc.lps[(size_t)row * mc.n_walkers + w] = *s_lp;
+        }
+        if (mc.samples && tid < mc.d) mc.samples[((size_t)row * mc.n_walkers + w) * mc.d + tid] = s_cur[mc.free_idx[tid]];
+    }
+}
+
+// Metropolis proposal for step `step` from the row in s_cur:  s_par = s_cur;
+// s_par[free[i]] += sum_j chol[i][j] z_j,  z from Philox + Box-Muller.  All threads call.
+__device__ __forceinline__ void propose_row(const McmcDev &mc, int w, unsigned long long step,
+                                            const double *cur_row, double *s_par, double *s_z)
+{
+    const int tid = threadIdx.x, d = mc.d, n_pairs = (d + 1) >> 1;
+    __syncthreads();
+    if (tid < B9_NPARAM) s_par[tid] = cur_row[tid];
+    if (tid < n_pairs) {
+        unsigned r[4];
+        philox4x32((unsigned)step, (unsigned)(step >> 32), (unsigned)mc.walker_ids[w], (unsigned)tid, mc.k0, mc.k1, r);
+        const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+        const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+        s_z[2 * tid] = rad * cos(ang);
+        s_z[2 * tid + 1] = rad * sin(ang);
+    }
+    __syncthreads();
+    double delta = 0.0;
+    if (tid < d) for (int j = 0; j < d; ++j) delta = delta + mc.chol[tid * d + j] * s_z[j];
+    __syncthreads();
+    if (tid < d) s_par[mc.free_idx[tid]] += delta;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
 // k_derive_iso
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
@@ -196,31 +309,6 @@ __device__ __forceinline__ int bracket_wave(const double *__restrict__ ax, int n
     }
     int i = cnt - 1;
     return i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
-}
-
-// Metropolis proposal of walker w for step `step` (device-resident sampler), by the first few
-// threads of a workgroup:  s_par = cur;  s_par[free[i]] += sum_j chol[i][j] z_j,  z from Philox +
-// Box-Muller.  Every workgroup that calls it with the same arguments gets the same row.
-// Contains barriers: call from all threads.
-__device__ __forceinline__ void propose_row(const McmcDev &mc, int w, unsigned long long step,
-                                            const double *__restrict__ cur_row, double *s_par, double *s_z)
-{
-    const int tid = threadIdx.x, d = mc.d, n_pairs = (d + 1) >> 1;
-    if (tid < B9_NPARAM) s_par[tid] = cur_row[tid];
-    if (tid < n_pairs) {
-        unsigned r[4];
-        philox4x32((unsigned)step, (unsigned)(step >> 32), (unsigned)mc.walker_ids[w], (unsigned)tid, mc.k0, mc.k1, r);
-        const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
-        const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
-        s_z[2 * tid] = rad * cos(ang);
-        s_z[2 * tid + 1] = rad * sin(ang);
-    }
-    __syncthreads();
-    double delta = 0.0;
-    if (tid < d) for (int j = 0; j < d; ++j) delta = delta + mc.chol[tid * d + j] * s_z[j];
-    __syncthreads();
-    if (tid < d) s_par[mc.free_idx[tid]] += delta;
-    __syncthreads();
 }
 
 // Derives the isochrone of (walker w, population pop) from parameter row `par` (any address
@@ -313,21 +401,40 @@ __device__ __forceinline__ void derive_iso_block(const DevPack &pk, const double
     }
 }
 
-// grid = (walkers * pops, parts): every workgroup of a row re-derives the (cheap) header and then
-// produces its share of the values, so the table reads of one isochrone are a single round trip
-// spread over ~15 workgroups.  With mc.enabled the row is first drawn as a Metropolis proposal.
+// k_derive_iso: grid = (walkers * pops, parts).  Every workgroup of a row re-derives the (cheap)
+// header and then produces its share of the values, so the table reads of one isochrone are a
+// single round trip spread over ~15 workgroups.
+//
+// Device-resident sampler (mc.enabled): the launch of step t first finishes step t-1 when
+// mc.has_prev -- each workgroup re-sums walker w's partials of the star kernel's previous launch,
+// adds the prior of the previous proposal (params_prev) and accepts or rejects it (identical bits
+// in every workgroup; workgroup (pop 0, part 0) stores the new state and the chain record) -- and
+// then draws step t's proposal from that state, publishes it to `params`, and derives its
+// isochrone(s).  One MCMC step = this launch + the star-likelihood launch.
 __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restrict__ params,
                                                      int n_pops, IsoHdr *__restrict__ hdr,
                                                      double *__restrict__ iso_data, long long iso_stride,
-                                                     int mass_cap, McmcDev mc)
+                                                     int mass_cap, McmcDev mc, DevPriors pr,
+                                                     const double *__restrict__ partial_prev, int n_partial,
+                                                     long long partial_stride,
+                                                     const IsoHdr *__restrict__ hdr_prev,
+                                                     const double *__restrict__ params_prev)
 {
     const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops;
     const double *par = params + (size_t)w * B9_NPARAM;
-    __shared__ double s_par[B9_NPARAM], s_z[12];
+    __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_lp, s_red[4];
     if (mc.enabled) {
-        propose_row(mc, w, mc.step, mc.cur + (size_t)w * B9_NPARAM, s_par, s_z);
-        // block (y == 0, pop == 0) publishes the row to `params` for the two kernels that follow
-        if (blockIdx.y == 0 && pop == 0 && threadIdx.x < B9_NPARAM) params[(size_t)w * B9_NPARAM + threadIdx.x] = s_par[threadIdx.x];
+        const bool writer = (blockIdx.y == 0 && pop == 0);
+        const double *cur_row = mc.cur + ((size_t)mc.pin * mc.n_walkers + w) * B9_NPARAM;
+        if (mc.has_prev) {
+            const double *prop_prev = params_prev + (size_t)w * B9_NPARAM;
+            const double lp_prop = finish_logpost(hdr_prev, partial_prev + (size_t)w * partial_stride, n_partial,
+                                                  prop_prev, pr, n_pops, w, s_red);
+            metropolis_accept(mc, w, mc.step - 1, mc.row, prop_prev, lp_prop, writer, s_cur, &s_lp);
+            cur_row = s_cur;
+        }
+        propose_row(mc, w, mc.step, cur_row, s_par, s_z);
+        if (writer && threadIdx.x < B9_NPARAM) params[(size_t)w * B9_NPARAM + threadIdx.x] = s_par[threadIdx.x];
         par = s_par;
     }
     derive_iso_block(pk, par, pop, wp, hdr, iso_data, iso_stride, mass_cap, blockIdx.y, gridDim.y);
@@ -717,25 +824,109 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
     return (log(a.mant) + (double)a.expo * 0.693147180559945309417) + a.add;
 }
 
+// The stars the hot path skips -- primary heavier than the walker's AGB tip (SURVEY 8a row a7:
+// IFMR -> WD cooling -> WD atmosphere, or NS/BH) -- are evaluated by extra workgroups of the SAME
+// launch, through the general per-star code.  Because stars are also indexed by descending mass
+// (heavy_mass / heavy_slot), that set is a prefix whose length each heavy workgroup finds with a
+// 256-ary search (two rounds for 50k stars).  The WD axes are staged in LDS.  `parts` workgroups
+// share a walker's heavy stars; each writes one partial.
+template <int NFP, int NPOPS>
+__device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *__restrict__ hdr,
+                                         const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
+                                         const double *__restrict__ params, int w, int part, int parts,
+                                         double *__restrict__ out_partial, double *__restrict__ perstar, double *smem)
+{
+    const int tid = threadIdx.x;
+    int *s_cnt = reinterpret_cast<int *>(smem);         // 4 ints
+    double *s_red = smem + 2;                            // 4 doubles
+    double *s_axes = smem + 8;
+    const double *par = params + (size_t)w * B9_NPARAM;
+    IsoView<NFP> iso[NPOPS];
+    double tip_min;
+    const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
+    if (!valid) { if (tid == 0) *out_partial = 0.0; return; }
+    int lo = 0, hi = st.n;                               // count = first k with heavy_mass[k] <= tip_min
+    while (lo < hi) {
+        const int span = hi - lo, step = (span + 255) / 256;
+        const int p = lo + tid * step;
+        const bool above = (p < hi) && (st.heavy_mass[p] > tip_min);
+        const int c = block_count(above, s_cnt);
+        if (c == 0) { hi = lo; }
+        else { const int nlo = lo + (c - 1) * step + 1, nhi = lo + c * step; lo = nlo; hi = nhi < hi ? nhi : hi; }
+    }
+    const int count = lo;
+    double acc = 0.0;
+    if (count > 0) {
+        WdAxes ax[NPOPS];
+        const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1;
+        double *d = s_axes;
+        const double *src[6] = {pk.log_age, pk.wc_log_age, pk.wc_mass, pk.wc_carb, pk.at_log_teff, pk.at_logg};
+        const int len[6] = {na, pk.n_wc_age, pk.n_wc_mass, pk.n_wc_carb, pk.n_at_teff, pk.n_at_logg};
+        const double *dst[6];
+        for (int a = 0; a < 6; ++a) {
+            dst[a] = d;
+            for (int j = tid; j < len[a]; j += 256) d[j] = src[a][j];
+            d += len[a];
+        }
+        for (int kp = 0; kp < NPOPS; ++kp)               // each population brackets (FeH, Y) on its own
+            for (int c = 0; c < 4; ++c) {
+                const int df = c >> 1, dy = c & 1;
+                const double *tips = pk.tips + (size_t)((iso[kp].i_feh + df) * pk.n_y + (iso[kp].i_y + (dy < ny ? dy : 0))) * na;
+                for (int j = tid; j < na; j += 256) d[j] = tips[j];
+                ax[kp].tips[c] = d;
+                d += na;
+            }
+        __syncthreads();
+        for (int kp = 0; kp < NPOPS; ++kp) {
+            ax[kp].log_age = dst[0]; ax[kp].wc_log_age = dst[1]; ax[kp].wc_mass = dst[2]; ax[kp].wc_carb = dst[3];
+            ax[kp].at_log_teff = dst[4]; ax[kp].at_logg = dst[5];
+        }
+        const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+        const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+        for (int j = part * 256 + tid; j < count; j += parts * 256) {
+            const int i = st.heavy_slot[j];
+            const double v = star_value<NFP, NPOPS>(pk, ax, iso, par, st, i, log_lam, log_1ml);
+            if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
+            acc += v;
+        }
+    }
+    const double sum = wave_sum(acc);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) *out_partial = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
 template <int NFP, int NPOPS, int WB>
 __global__ __launch_bounds__(256, B9_K1_MIN_WAVES) void k_star_like(DevPack pk, DevStars st,
                                                     const IsoHdr *__restrict__ hdr,
                                                     const double *__restrict__ iso_data,
                                                     long long iso_stride, int mass_cap,
                                                     const double *__restrict__ params, int n_walkers,
-                                                    double *__restrict__ partial, int n_groups,
-                                                    double *__restrict__ perstar, int tiles_per_block)
+                                                    double *__restrict__ partial, long long partial_stride, int n_groups,
+                                                    double *__restrict__ perstar, int tiles_per_block,
+                                                    int hot_blocks, int heavy_parts)
 {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // Heavy-star workgroups come FIRST in the grid (hot_blocks = their padded count): they have the
+    // longest dependent chain, so they must start at once and run beside the hot workgroups.
+    if ((int)blockIdx.x < hot_blocks) {        // hot_blocks doubles as "first hot workgroup id"
+        const int hb = blockIdx.x;
+        if (hb >= n_walkers * heavy_parts) return;            // padding to a multiple of 8
+        const int w = hb / heavy_parts, part = hb - w * heavy_parts;
+        heavy_stars<NFP, NPOPS>(pk, st, hdr, iso_data, iso_stride, mass_cap, params, w, part, heavy_parts,
+                                partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part, perstar, smem);
+        return;
+    }
     // LDS: the mass column of each (walker, population) isochrone this workgroup evaluates -- the binary search runs in LDS (dependent ds_reads
     // instead of dependent L2 round trips); the magnitude rows a star needs are then read from L2
     // (coalesced: stars are sorted by mass, so neighbouring lanes hit the same or adjacent rows).
     // A lane keeps its star in registers and evaluates it for WB walkers in turn, so the star data
     // crosses the L2 -> CU fabric once per WB walkers.
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     STAMP(0);
     const int n_wsets = (n_walkers + WB - 1) / WB;
-    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    const int L = blockIdx.x - hot_blocks, xcd = L & 7, s = L >> 3;      // hot_blocks is a multiple of 8
     const int wset = s % n_wsets, w0 = wset * WB;
     const int group = (s / n_wsets) * 8 + xcd;          // tile group = tiles_per_block consecutive tiles
     if (group >= n_groups) return;
@@ -839,7 +1030,7 @@ __global__ __launch_bounds__(256, B9_K1_MIN_WAVES) void k_star_like(DevPack pk, 
     for (int b = 0; b < WB; ++b) {
         const double tot = mix_wave_total(acc[b]);
         if ((tid & 63) == 0 && b < nwb)
-            partial[(size_t)(w0 + b) * (n_groups * 4) + group * 4 + (tid >> 6)] = valid[b] ? tot : 0.0;
+            partial[(size_t)(w0 + b) * partial_stride + group * 4 + (tid >> 6)] = valid[b] ? tot : 0.0;
     }
     STAMP(8);
 }
@@ -1017,193 +1208,27 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
 }
 
 // ------------------------------------------------------------------------------------------
-// k_finalize: one workgroup per walker.
-//   (1) the stars k_star_like skipped -- primary heavier than the AGB tip (SURVEY 8a row a7:
-//       IFMR -> WD cooling -> WD atmosphere, or NS/BH) -- through the general per-star code;
-//   (2) fixed-order sum of the hot kernel's partials (row a8);
-//   (3) cluster prior; -inf for a walker outside the grid.
+// k_finalize: one workgroup per walker: fixed-order sum of the partials + prior -> logpost[w]
+// (SURVEY 8a row a8); -inf for a walker outside the grid; with mc.enabled also the accept/reject
+// of the block's last step.
 // ------------------------------------------------------------------------------------------
-__device__ inline double log_prior_cluster(const DevPriors &pr, const double *__restrict__ par, int n_pops)
+__global__ __launch_bounds__(256) void k_finalize(const IsoHdr *__restrict__ hdr, const double *__restrict__ partial,
+                                                   int n_partial, long long partial_stride, int n_pops,
+                                                   const double *__restrict__ params, DevPriors pr,
+                                                   double *__restrict__ logpost, double *__restrict__ perstar,
+                                                   int n_stars, McmcDev mc)
 {
-    if (!(par[B9_P_LOGAGE] >= pr.log_age_min && par[B9_P_LOGAGE] <= pr.log_age_max)) return NEG_INF;
-    if (par[B9_P_ABS] < 0.0) return NEG_INF;
-    if (n_pops == 2 && !(par[B9_P_LAMBDA] >= 0.0 && par[B9_P_LAMBDA] <= 1.0)) return NEG_INF;
-    double lp = 0.0;
-    for (int k = 0; k < B9_NPARAM; ++k) {
-        if (k == B9_P_LOGAGE) continue;
-        if (n_pops < 2 && (k == B9_P_Y2 || k == B9_P_LAMBDA)) continue;
-        if (pr.var[k] > 0.0) {
-            double d = par[k] - pr.mean[k];
-            lp -= 0.5 * d * d / pr.var[k];
-        }
-    }
-    return lp;
-}
-
-#define B9_FIN_THREADS 512
-#define B9_FIN_WAVES (B9_FIN_THREADS / 64)
-
-// Next step's proposal + isochrone derivation for walker w, inside k_finalize (all threads call).
-// Reads the walker's current row AFTER this workgroup's own accept decision.
-__device__ __forceinline__ void next_step(const DevPack &pk, const McmcDev &mc, int w, int n_pops,
-                                          double *__restrict__ params_next, IsoHdr *__restrict__ hdr_next,
-                                          double *__restrict__ iso_next, long long iso_stride, int mass_cap)
-{
-    __shared__ double s_par[B9_NPARAM], s_z[12];
-    __threadfence_block();
-    __syncthreads();                                     // thread 0's update of mc.cur[w] is done
-    propose_row(mc, w, mc.step + 1, mc.cur + (size_t)w * B9_NPARAM, s_par, s_z);
-    if (threadIdx.x < B9_NPARAM) params_next[(size_t)w * B9_NPARAM + threadIdx.x] = s_par[threadIdx.x];
-    // fuse_next == 2 also derives the isochrones here.  Measured SLOWER than a separate
-    // k_derive_iso launch (42.7 vs 36.8 us/step at 8 walkers): one workgroup per walker cannot pull
-    // the 8 corner tables (230 KB) as fast as the 15 workgroups per isochrone of k_derive_iso do.
-    if (mc.fuse_next >= 2)
-        for (int pop = 0; pop < n_pops; ++pop)
-            derive_iso_block(pk, s_par, pop, w * n_pops + pop, hdr_next, iso_next, iso_stride, mass_cap, 0, 1);
-}
-
-// Metropolis accept/reject of walker w's proposal (one thread; device-resident sampler only):
-// accept when log u < lp_prop - lp_cur, u from the walker's Philox stream (draw index n_pairs).
-__device__ inline void metropolis_accept(const McmcDev &mc, const double *__restrict__ params, int w, double lp_prop)
-{
-    unsigned r[4];
-    philox4x32((unsigned)mc.step, (unsigned)(mc.step >> 32), (unsigned)mc.walker_ids[w], (unsigned)((mc.d + 1) >> 1),
-               mc.k0, mc.k1, r);
-    const double u = u01(r[0], r[1]);
-    const double lp_cur = mc.lp_cur[w];
-    const bool ok = isfinite(lp_prop) && (log(u) < lp_prop - lp_cur);
-    double *cur = mc.cur + (size_t)w * B9_NPARAM;
-    if (ok) {
-        for (int k = 0; k < B9_NPARAM; ++k) cur[k] = params[(size_t)w * B9_NPARAM + k];
-        mc.lp_cur[w] = lp_prop;
-        atomicAdd(mc.n_acc, 1ull);
-    }
-    // cur / lp_cur / walker_ids are already offset to this launch's first walker; the chain
-    // records are indexed by the walker's position in the whole block
-    const size_t rec = (size_t)mc.row * mc.w_total + mc.w_off + w;
-    if (mc.samples) for (int i = 0; i < mc.d; ++i) mc.samples[rec * mc.d + i] = cur[mc.free_idx[i]];
-    if (mc.lps) mc.lps[rec] = ok ? lp_prop : lp_cur;
-}
-
-// block-wide sum of one int per thread (all threads get the result)
-__device__ __forceinline__ int block_count(bool pred, int *s_cnt)
-{
-    const int tid = threadIdx.x;
-    const int c = __popcll(__ballot(pred));
-    __syncthreads();                       // s_cnt may still be read from the previous round
-    if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
-    __syncthreads();
-    int t = 0;
-#pragma unroll
-    for (int k = 0; k < B9_FIN_WAVES; ++k) t += s_cnt[k];
-    return t;
-}
-
-template <int NFP, int NPOPS>
-__global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStars st,
-                                                              const IsoHdr *__restrict__ hdr,
-                                                              const double *__restrict__ iso_data,
-                                                              long long iso_stride, int mass_cap,
-                                                              const double *__restrict__ partial, int n_partial,
-                                                              const double *__restrict__ params, DevPriors pr,
-                                                              double *__restrict__ logpost,
-                                                              double *__restrict__ perstar, int axes_in_lds, McmcDev mc,
-                                                              double *__restrict__ params_next, IsoHdr *__restrict__ hdr_next,
-                                                              double *__restrict__ iso_next)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];   // WD axes (when axes_in_lds)
-    __shared__ double s_red[B9_FIN_WAVES];
-    __shared__ int s_cnt[B9_FIN_WAVES];
+    __shared__ double s_red[4], s_cur[B9_NPARAM], s_lp;
     const int w = blockIdx.x, tid = threadIdx.x;
-    const double *par = params + (size_t)w * B9_NPARAM;
-    IsoView<NFP> iso[NPOPS];
-    double tip_min;
-    const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
-    const double lp = log_prior_cluster(pr, par, NPOPS);
-    // this walker's partials from the hot kernel: requested now, consumed at the end
-    double acc = 0.0;
-    for (int j = tid; j < n_partial; j += B9_FIN_THREADS) acc += partial[(size_t)w * n_partial + j];
-    if (!valid || lp == NEG_INF) {
-        if (tid == 0) { logpost[w] = NEG_INF; if (mc.enabled) metropolis_accept(mc, params, w, NEG_INF); }
-        // a walker inside the grid whose prior is -inf still has per-star values from the hot
-        // kernel; the oracle reports -inf for them as well
-        if (perstar && valid)
-            for (int i = tid; i < st.n; i += B9_FIN_THREADS) perstar[(size_t)w * st.n + i] = NEG_INF;
-        if (mc.enabled && mc.fuse_next) next_step(pk, mc, w, NPOPS, params_next, hdr_next, iso_next, iso_stride, mass_cap);
-        return;
-    }
-    // (1) heavy stars: count = first k with heavy_mass[k] <= tip_min, by a 512-ary search in
-    //     which every thread probes one point per round (two rounds for 50k stars).
-    //     (axes_in_lds < 0: marginalised mode -- k_star_marg has already handled every star.)
-    int lo = 0, hi = axes_in_lds < 0 ? 0 : st.n;
-    while (lo < hi) {
-        const int span = hi - lo, step = (span + B9_FIN_THREADS - 1) / B9_FIN_THREADS;
-        const int p = lo + tid * step;
-        const bool above = (p < hi) && (st.heavy_mass[p] > tip_min);
-        const int c = block_count(above, s_cnt);
-        if (c == 0) { hi = lo; }
-        else { const int nlo = lo + (c - 1) * step + 1, nhi = lo + c * step; lo = nlo; hi = nhi < hi ? nhi : hi; }
-    }
-    const int count = lo;
-    if (count > 0) {
-        WdAxes ax[NPOPS];
-        const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1;
-        const double *tip_src[NPOPS][4];     // each population brackets (FeH, Y) on its own
-        for (int k = 0; k < NPOPS; ++k)
-            for (int df = 0; df < 2; ++df) for (int dy = 0; dy < 2; ++dy)
-                tip_src[k][df * 2 + dy] = pk.tips + (size_t)((iso[k].i_feh + df) * pk.n_y + (iso[k].i_y + (dy < ny ? dy : 0))) * na;
-        if (axes_in_lds) {
-            double *d = smem;
-            const double *src[6] = {pk.log_age, pk.wc_log_age, pk.wc_mass, pk.wc_carb, pk.at_log_teff, pk.at_logg};
-            const int len[6] = {na, pk.n_wc_age, pk.n_wc_mass, pk.n_wc_carb, pk.n_at_teff, pk.n_at_logg};
-            const double *dst[6];
-            for (int a = 0; a < 6; ++a) {
-                dst[a] = d;
-                for (int j = tid; j < len[a]; j += B9_FIN_THREADS) d[j] = src[a][j];
-                d += len[a];
-            }
-            for (int k = 0; k < NPOPS; ++k)
-                for (int c = 0; c < 4; ++c) {
-                    for (int j = tid; j < na; j += B9_FIN_THREADS) d[j] = tip_src[k][c][j];
-                    ax[k].tips[c] = d;
-                    d += na;
-                }
-            __syncthreads();
-            for (int k = 0; k < NPOPS; ++k) {
-                ax[k].log_age = dst[0]; ax[k].wc_log_age = dst[1]; ax[k].wc_mass = dst[2]; ax[k].wc_carb = dst[3];
-                ax[k].at_log_teff = dst[4]; ax[k].at_logg = dst[5];
-            }
-        } else {
-            for (int k = 0; k < NPOPS; ++k) {
-                ax[k].log_age = pk.log_age;
-                for (int c = 0; c < 4; ++c) ax[k].tips[c] = tip_src[k][c];
-                ax[k].wc_log_age = pk.wc_log_age; ax[k].wc_mass = pk.wc_mass; ax[k].wc_carb = pk.wc_carb;
-                ax[k].at_log_teff = pk.at_log_teff; ax[k].at_logg = pk.at_logg;
-            }
-        }
-        const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
-        const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
-        for (int j = tid; j < count; j += B9_FIN_THREADS) {
-            const int i = st.heavy_slot[j];
-            const double v = star_value<NFP, NPOPS>(pk, ax, iso, par, st, i, log_lam, log_1ml);
-            if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
-            acc += v;
-        }
-    }
-    // (2) fixed-order block sum of {hot-kernel partials, heavy stars}
-    double sum = wave_sum(acc);
-    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < B9_FIN_WAVES; ++k) t += s_red[k];
-        logpost[w] = lp + t;   // (3)
-        if (mc.enabled) metropolis_accept(mc, params, w, lp + t);
-    }
-    // (4) device-resident sampler: with the accept decision made, draw the NEXT step's proposal
-    //     and derive its isochrone(s) right here -- one launch and one kernel boundary fewer per step
-    if (mc.enabled && mc.fuse_next) next_step(pk, mc, w, NPOPS, params_next, hdr_next, iso_next, iso_stride, mass_cap);
+    const double *row = params + (size_t)w * B9_NPARAM;
+    bool in_support;
+    const double lp = finish_logpost(hdr, partial + (size_t)w * partial_stride, n_partial, row, pr, n_pops, w, s_red, &in_support);
+    if (tid == 0) logpost[w] = lp;
+    // a walker inside the grid whose prior is -inf still has per-star values from the star kernel;
+    // the oracle reports -inf for them as well
+    if (perstar && !in_support)
+        for (int i = tid; i < n_stars; i += 256) perstar[(size_t)w * n_stars + i] = NEG_INF;
+    if (mc.enabled) metropolis_accept(mc, w, mc.step, mc.row, row, lp, true, s_cur, &s_lp);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1211,55 +1236,43 @@ __global__ __launch_bounds__(B9_FIN_THREADS) void k_finalize(DevPack pk, DevStar
 // ------------------------------------------------------------------------------------------
 hipError_t b9k_derive_iso(const DevPack &pk, double *d_params, int n_walkers, int n_pops,
                           IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap,
-                          const McmcDev &mc, hipStream_t stream)
+                          const McmcDev &mc, const DevPriors &pr, const B9Prev &prev, hipStream_t stream)
 {
     const int gy = (mass_cap * (pk.nfp + 1) + 255) / 256;
     hipLaunchKernelGGL(k_derive_iso, dim3(n_walkers * n_pops, gy), dim3(256), 0, stream,
-                       pk, d_params, n_pops, hdr, iso_data, iso_stride, mass_cap, mc);
+                       pk, d_params, n_pops, hdr, iso_data, iso_stride, mass_cap, mc, pr,
+                       prev.partial, prev.n_partial, prev.partial_stride, prev.hdr, prev.params);
     return hipGetLastError();
 }
 
-size_t b9k_star_like_lds_bytes(int n_pops, int mass_cap, int wb)
+static size_t heavy_lds_doubles(const DevPack &pk, int n_pops)
 {
-    return sizeof(double) * ((size_t)wb * n_pops * mass_cap);
+    const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
+    return 8 + (has_wd ? (size_t)(1 + 4 * n_pops) * pk.n_age + pk.n_wc_age + pk.n_wc_mass + pk.n_wc_carb + pk.n_at_teff + pk.n_at_logg
+                       : (size_t)(1 + 4 * n_pops) * pk.n_age);
 }
 
 template <int NFP, int NPOPS, int WB>
 static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                                    const double *iso_data, long long iso_stride, int mass_cap,
-                                   const double *d_params, int n_walkers, double *partial,
-                                   double *perstar, int tiles_per_block, int n_groups, hipStream_t stream)
+                                   const double *d_params, int n_walkers, double *partial, long long partial_stride,
+                                   double *perstar, int tiles_per_block, int n_groups, int heavy_parts,
+                                   hipStream_t stream)
 {
-    const size_t lds = b9k_star_like_lds_bytes(NPOPS, mass_cap, WB);
+    const size_t lds = sizeof(double) * std::max((size_t)WB * NPOPS * mass_cap, heavy_lds_doubles(pk, NPOPS));
     auto kern = k_star_like<NFP, NPOPS, WB>;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int n_wsets = (n_walkers + WB - 1) / WB;
-    const int blocks = 8 * ((n_groups + 7) / 8) * n_wsets;     // padded so every XCD sees whole walker sets
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, pk, st, hdr, iso_data,
-                       iso_stride, mass_cap, d_params, n_walkers, partial, n_groups, perstar, tiles_per_block);
-    return hipGetLastError();
-}
-
-template <int NFP, int NPOPS>
-static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
-                                  const double *iso_data, long long iso_stride, int mass_cap,
-                                  const double *partial, int n_partial, const double *d_params,
-                                  const DevPriors &pr, int n_walkers, double *d_logpost, double *perstar,
-                                  const McmcDev &mc, bool marg, const B9Next &nx, hipStream_t stream)
-{
-    const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
-    size_t lds = has_wd ? sizeof(double) * ((size_t)(1 + 4 * NPOPS) * pk.n_age + pk.n_wc_age + pk.n_wc_mass + pk.n_wc_carb +
-                                            pk.n_at_teff + pk.n_at_logg) : 0;
-    int in_lds = has_wd && lds <= 48 * 1024;
-    if (!in_lds) lds = 0;
-    if (marg) in_lds = -1;
-    hipLaunchKernelGGL((k_finalize<NFP, NPOPS>), dim3(n_walkers), dim3(B9_FIN_THREADS), lds, stream, pk, st, hdr,
-                       iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, d_logpost, perstar, in_lds, mc,
-                       nx.params, nx.hdr, nx.iso);
+    const int hot = 8 * ((n_groups + 7) / 8) * n_wsets;          // padded so every XCD sees whole walker sets
+    const int heavy = (n_walkers * heavy_parts + 7) / 8 * 8;     // heavy-star workgroups lead the grid
+    hipLaunchKernelGGL(kern, dim3(heavy + hot), dim3(256), lds, stream, pk, st, hdr, iso_data,
+                       iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, n_groups, perstar,
+                       tiles_per_block, heavy, heavy_parts);
     return hipGetLastError();
 }
 
@@ -1274,10 +1287,10 @@ static hipError_t launch_finalize(const DevPack &pk, const DevStars &st, const I
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
                          const double *d_params, int n_walkers, int n_pops, int wb,
-                         double *partial, double *perstar, int tiles_per_block, int n_groups,
-                         hipStream_t stream)
+                         double *partial, long long partial_stride, double *perstar, int tiles_per_block,
+                         int n_groups, int heavy_parts, hipStream_t stream)
 {
-#define SL_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, perstar, tiles_per_block, n_groups, stream
+#define SL_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, tiles_per_block, n_groups, heavy_parts, stream
 #define SL2(NFP) (wb >= 2 ? launch_star_like<NFP, 2, 2>(SL_ARGS) : launch_star_like<NFP, 2, 1>(SL_ARGS))
 #define SL1(NFP) (wb >= 2 ? launch_star_like<NFP, 1, 2>(SL_ARGS) : launch_star_like<NFP, 1, 1>(SL_ARGS))
     B9_SWITCH_NFP(SL2, SL1)
@@ -1286,18 +1299,13 @@ hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 #undef SL_ARGS
 }
 
-hipError_t b9k_finalize(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
-                        long long iso_stride, int mass_cap, const double *partial, int n_partial, int n_pops,
-                        const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        double *perstar, const McmcDev &mc, bool marg, const B9Next &nx, hipStream_t stream)
+hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial, long long partial_stride,
+                        int n_pops, const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
+                        double *perstar, int n_stars, const McmcDev &mc, hipStream_t stream)
 {
-#define FN_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, partial, n_partial, d_params, pr, n_walkers, d_logpost, perstar, mc, marg, nx, stream
-#define FN2(NFP) launch_finalize<NFP, 2>(FN_ARGS)
-#define FN1(NFP) launch_finalize<NFP, 1>(FN_ARGS)
-    B9_SWITCH_NFP(FN2, FN1)
-#undef FN1
-#undef FN2
-#undef FN_ARGS
+    hipLaunchKernelGGL(k_finalize, dim3(n_walkers), dim3(256), 0, stream, hdr, partial, n_partial, partial_stride,
+                       n_pops, d_params, pr, d_logpost, perstar, n_stars, mc);
+    return hipGetLastError();
 }
 
 template <int NFP, int NPOPS>
@@ -1328,4 +1336,28 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 #undef SM1
 #undef SM2
 #undef SM_ARGS
+}
+
+// An empty kernel: bracketing it with HIP events measures what an event bracket adds to a kernel's
+// own duration (dispatch boundary + event processing); b9_calibrate_timing subtracts nothing by
+// itself, it only reports the figure.
+__global__ void k_noop(int *p) { if (p && threadIdx.x == 1024) *p = 0; }
+// keeps the queue busy for ~`ticks` s_memrealtime ticks (100 MHz) so that work enqueued behind it
+// executes back to back (bounded spin; one wave)
+__global__ void k_spin(unsigned long long ticks, int *p)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int guard = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && guard < (1 << 24)) ++guard;
+    if (p && guard < 0) *p = guard;
+}
+hipError_t b9k_spin(double microseconds, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, stream, (unsigned long long)(microseconds * 100.0), (int *)nullptr);
+    return hipGetLastError();
+}
+hipError_t b9k_noop(hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, stream, (int *)nullptr);
+    return hipGetLastError();
 }

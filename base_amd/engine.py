@@ -140,6 +140,12 @@ class Engine:
         """0/False: off; n: bracket every n-th launch of the dominant kernel with HIP events."""
         self._check(self.lib.b9_enable_timing(self._ctx, int(every)))
 
+    def calibrate_timing(self) -> float:
+        """ms an event bracket adds to a kernel's own duration (measured on an empty kernel)."""
+        ms = C.c_double(0)
+        self._check(self.lib.b9_calibrate_timing(self._ctx, C.byref(ms)))
+        return ms.value
+
     def kernel_time_ms(self, reset: bool = True) -> Tuple[float, int]:
         ms, n = C.c_double(0), C.c_int32(0)
         self._check(self.lib.b9_kernel_time_ms(self._ctx, 1 if reset else 0, C.byref(ms), C.byref(n)))

@@ -235,6 +235,9 @@ int b9_bytes_per_star_eval(const b9_ctx *ctx);
  * (n = 1: all of them; each bracket costs the host two hipEventRecord calls).              */
 int b9_enable_timing(b9_ctx *ctx, int on);
 int b9_kernel_time_ms(b9_ctx *ctx, int reset, double *total_ms, int32_t *n_launches);
+/* Mean elapsed ms of the same event bracket around an EMPTY kernel: what the bracket adds to a
+ * kernel's own duration (one dispatch boundary + event processing).  Reported, never applied. */
+int b9_calibrate_timing(b9_ctx *ctx, double *bracket_overhead_ms);
 
 #ifdef __cplusplus
 }
