@@ -244,23 +244,29 @@ __device__ __forceinline__ void metropolis_accept(const McmcDev &mc, int w, unsi
     }
 }
 
-// Metropolis proposal for step `step` from the row in s_cur:  s_par = s_cur;
-// s_par[free[i]] += sum_j chol[i][j] z_j,  z from Philox + Box-Muller.  All threads call.
-__device__ __forceinline__ void propose_row(const McmcDev &mc, int w, unsigned long long step,
-                                            const double *cur_row, double *s_par, double *s_z)
+// Standard normals of walker w's proposal for step `step` (Philox + Box-Muller) into s_z, by
+// threads [t0, t0 + n_pairs).  Depends only on (seed, step, walker): k_derive_iso issues it at
+// kernel entry, on a wave that is otherwise idle while the previous step is being finished.
+__device__ __forceinline__ void draw_z(const McmcDev &mc, int w, unsigned long long step, int t0, double *s_z)
 {
-    const int tid = threadIdx.x, d = mc.d, n_pairs = (d + 1) >> 1;
-    __syncthreads();
-    if (tid < B9_NPARAM) s_par[tid] = cur_row[tid];
-    if (tid < n_pairs) {
+    const int j = (int)threadIdx.x - t0, n_pairs = (mc.d + 1) >> 1;
+    if (j >= 0 && j < n_pairs) {
         unsigned r[4];
-        philox4x32((unsigned)step, (unsigned)(step >> 32), (unsigned)mc.walker_ids[w], (unsigned)tid, mc.k0, mc.k1, r);
+        philox4x32((unsigned)step, (unsigned)(step >> 32), (unsigned)mc.walker_ids[w], (unsigned)j, mc.k0, mc.k1, r);
         const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
         const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
-        s_z[2 * tid] = rad * cos(ang);
-        s_z[2 * tid + 1] = rad * sin(ang);
+        s_z[2 * j] = rad * cos(ang);
+        s_z[2 * j + 1] = rad * sin(ang);
     }
-    __syncthreads();
+}
+
+// Metropolis proposal from the row `cur_row` and the normals in s_z:  s_par = cur;
+// s_par[free[i]] += sum_j chol[i][j] z_j.  All threads call.
+__device__ __forceinline__ void propose_row(const McmcDev &mc, const double *cur_row, double *s_par, const double *s_z)
+{
+    const int tid = threadIdx.x, d = mc.d;
+    __syncthreads();                                     // s_z complete, s_par free
+    if (tid < B9_NPARAM) s_par[tid] = cur_row[tid];
     double delta = 0.0;
     if (tid < d) for (int j = 0; j < d; ++j) delta = delta + mc.chol[tid * d + j] * s_z[j];
     __syncthreads();
@@ -311,13 +317,39 @@ __device__ __forceinline__ int bracket_wave(const double *__restrict__ ax, int n
     return i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
 }
 
+// The three grid axes, one per wave (0: logAge, 1: FeH, 2: Y), preloaded into registers: lane l of
+// the wave holds ax[l] and ax[l + 64].  Loading them needs no parameter, so k_derive_iso requests
+// them at kernel entry, in the same round trip as everything else it reads first.
+struct AxisRegs { double v0, v1; int n; };
+
+__device__ __forceinline__ AxisRegs preload_axis(const DevPack &pk)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *ax = wave == 0 ? pk.log_age : (wave == 1 ? pk.feh : pk.y);
+    AxisRegs a;
+    a.n = wave == 0 ? pk.n_age : (wave == 1 ? pk.n_feh : (wave == 2 ? pk.n_y : 0));
+    a.v0 = lane < a.n ? ax[lane] : __builtin_inf();
+    a.v1 = lane + 64 < a.n ? ax[lane + 64] : __builtin_inf();
+    return a;
+}
+
+// bracket of x on a preloaded axis (n <= 128), else on the axis in memory
+__device__ __forceinline__ int bracket_regs(const AxisRegs &a, const double *__restrict__ ax, double x, int lane)
+{
+    if (a.n > 128) return bracket_wave(ax, a.n, x, lane);
+    const int cnt = __popcll(__ballot(a.v0 <= x)) + __popcll(__ballot(a.v1 <= x));
+    const int i = cnt - 1;
+    return i < 0 ? 0 : (i > a.n - 2 ? a.n - 2 : i);
+}
+
 // Derives the isochrone of (walker w, population pop) from parameter row `par` (any address
 // space).  All threads of the workgroup call it; workgroup `part` of `parts` produces its share of
 // the output values (one value per thread and iteration) and part 0 publishes the header.
 // Three dependent round trips: {parameters, axes} -> corner index rows -> table values.
 __device__ __forceinline__ void derive_iso_block(const DevPack &pk, const double *par, int pop, int wp,
                                                  IsoHdr *__restrict__ hdr, double *__restrict__ iso_data,
-                                                 long long iso_stride, int mass_cap, int part, int parts)
+                                                 long long iso_stride, int mass_cap, int part, int parts,
+                                                 const AxisRegs &axr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
     __shared__ IsoHdr sh;
@@ -327,9 +359,9 @@ __device__ __forceinline__ void derive_iso_block(const DevPack &pk, const double
     const double y = pop ? par[B9_P_Y2] : par[B9_P_Y];
     __syncthreads();                                     // sh / sc / s_br may still be in use (previous call)
     // three waves bracket the three axes concurrently
-    if (wave == 0) { int i = bracket_wave(pk.log_age, pk.n_age, log_age, lane); if (lane == 0) s_br[0] = i; }
-    if (wave == 1) { int i = bracket_wave(pk.feh, pk.n_feh, feh, lane); if (lane == 0) s_br[1] = i; }
-    if (wave == 2) { int i = pk.n_y > 1 ? bracket_wave(pk.y, pk.n_y, y, lane) : 0; if (lane == 0) s_br[2] = i; }
+    if (wave == 0) { int i = bracket_regs(axr, pk.log_age, log_age, lane); if (lane == 0) s_br[0] = i; }
+    if (wave == 1) { int i = bracket_regs(axr, pk.feh, feh, lane); if (lane == 0) s_br[1] = i; }
+    if (wave == 2) { int i = pk.n_y > 1 ? bracket_regs(axr, pk.y, y, lane) : 0; if (lane == 0) s_br[2] = i; }
     __syncthreads();
     if (wave == 0) {
         // lanes 0..7: one corner isochrone each
@@ -423,7 +455,9 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restri
     const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops;
     const double *par = params + (size_t)w * B9_NPARAM;
     __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_lp, s_red[4];
+    const AxisRegs axr = preload_axis(pk);                 // first round trip, needs no parameter
     if (mc.enabled) {
+        draw_z(mc, w, mc.step, 192, s_z);                  // wave 3: this step's normals, independent of the state
         const bool writer = (blockIdx.y == 0 && pop == 0);
         const double *cur_row = mc.cur + ((size_t)mc.pin * mc.n_walkers + w) * B9_NPARAM;
         if (mc.has_prev) {
@@ -433,11 +467,11 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restri
             metropolis_accept(mc, w, mc.step - 1, mc.row, prop_prev, lp_prop, writer, s_cur, &s_lp);
             cur_row = s_cur;
         }
-        propose_row(mc, w, mc.step, cur_row, s_par, s_z);
+        propose_row(mc, cur_row, s_par, s_z);
         if (writer && threadIdx.x < B9_NPARAM) params[(size_t)w * B9_NPARAM + threadIdx.x] = s_par[threadIdx.x];
         par = s_par;
     }
-    derive_iso_block(pk, par, pop, wp, hdr, iso_data, iso_stride, mass_cap, blockIdx.y, gridDim.y);
+    derive_iso_block(pk, par, pop, wp, hdr, iso_data, iso_stride, mass_cap, blockIdx.y, gridDim.y, axr);
 }
 
 // ------------------------------------------------------------------------------------------
