@@ -741,6 +741,9 @@ __device__ __forceinline__ void find_bracket(const double *mass, int n, double m
 #else
 #define B9_OBS_ARGS double c0, const double (&obs)[NFP], const double (&wgt)[NFP]
 #endif
+// -DB9_QUAD_PASS: filters in passes of four (rows + observations of a pass requested together).
+// Measured equal to the all-at-once form (20.7 vs 20.6 us) and only 5 VGPRs leaner -- the pressure
+// comes from the unrolled exp/log temporaries, not the row arrays -- so it is off by default.
 template <int NFP, int NPOPS>
 __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP> (&iso)[NPOPS],
                                            double mod, double av, double m1, double q,
@@ -761,6 +764,46 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         // two consecutive rows = 2*NFP contiguous doubles
         const double2 *r1 = reinterpret_cast<const double2 *>(iso[k].mags + (size_t)lo1 * NFP);
         const double2 *r2 = reinterpret_cast<const double2 *>(iso[k].mags + (size_t)lo2 * NFP);
+        double chi2 = 0.0;
+#if defined(B9_QUAD_PASS) && defined(B9_LATE_OBS)
+        // Passes of four filters.  Each pass requests its slice of the primary rows, of the secondary
+        // rows and of the observed magnitudes / weights TOGETHER (one round trip per pass, the same
+        // two round trips as the all-at-once form at 8 filters), so only a quarter of the row and
+        // observation registers are live at a time.
+#pragma unroll 1
+        for (int h = 0; h < NFP / 4; ++h) {
+            double2 a1[4], a2[4];
+            a1[0] = r1[2 * h]; a1[1] = r1[2 * h + 1]; a1[2] = r1[NFP / 2 + 2 * h]; a1[3] = r1[NFP / 2 + 2 * h + 1];
+            if (binary) { a2[0] = r2[2 * h]; a2[1] = r2[2 * h + 1]; a2[2] = r2[NFP / 2 + 2 * h]; a2[3] = r2[NFP / 2 + 2 * h + 1]; }
+            double o[4], wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = st.obs[(size_t)(4 * h + j) * st.n_pad + il];
+                wv[j] = st.w[(size_t)(4 * h + j) * st.n_pad + il];
+            }
+            double p[4];
+            p[0] = dark1 ? B9_MAG_NOFLUX : lerp(a1[0].x, a1[2].x, t1);
+            p[1] = dark1 ? B9_MAG_NOFLUX : lerp(a1[0].y, a1[2].y, t1);
+            p[2] = dark1 ? B9_MAG_NOFLUX : lerp(a1[1].x, a1[3].x, t1);
+            p[3] = dark1 ? B9_MAG_NOFLUX : lerp(a1[1].y, a1[3].y, t1);
+            if (binary) {
+                double s[4];
+                s[0] = dark2 ? B9_MAG_NOFLUX : lerp(a2[0].x, a2[2].x, t2);
+                s[1] = dark2 ? B9_MAG_NOFLUX : lerp(a2[0].y, a2[2].y, t2);
+                s[2] = dark2 ? B9_MAG_NOFLUX : lerp(a2[1].x, a2[3].x, t2);
+                s[3] = dark2 ? B9_MAG_NOFLUX : lerp(a2[1].y, a2[3].y, t2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s[j] - p[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = (p[j] + (mod + pk.abs_m1[4 * h + j] * av)) - o[j];
+                chi2 = fma(wv[j] * d, d, chi2);
+            }
+        }
+        const double c0 = st.c0[il];
+        STAMP(6);
+#else
         double2 a1[NFP], a2[NFP];
 #pragma unroll
         for (int j = 0; j < NFP; ++j) a1[j] = r1[j];
@@ -775,7 +818,6 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
             p[2 * j + 1] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].y, a1[NFP / 2 + j].y, t1);
         }
         STAMP(5);
-#ifndef B9_ABL_NOBIN
         if (binary) {
 #pragma unroll
             for (int j = 0; j < NFP / 2; ++j) {
@@ -785,9 +827,6 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
                 p[2 * j + 1] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s1 - p[2 * j + 1]));
             }
         }
-#else
-        if (binary) { for (int j = 0; j < NFP / 2; ++j) { p[2 * j] += a2[j].x * t2; p[2 * j + 1] += a2[NFP / 2 + j].y; } }
-#endif
         STAMP(6);
 #ifdef B9_LATE_OBS
         // observed magnitudes and weights are requested only now: they cost 32 VGPRs while live,
@@ -801,12 +840,12 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         }
         const double c0 = st.c0[il];
 #endif
-        double chi2 = 0.0;
 #pragma unroll
         for (int f = 0; f < NFP; ++f) {
             const double d = (p[f] + (mod + pk.abs_m1[f] * av)) - obs[f];
             chi2 = fma(wgt[f] * d, d, chi2);
         }
+#endif
         ll[k] = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
     }
     double l = ll[0];
@@ -948,8 +987,12 @@ __global__ __launch_bounds__(256, B9_K1_MIN_WAVES) void k_star_like(DevPack pk, 
         const int hb = blockIdx.x;
         if (hb >= n_walkers * heavy_parts) return;            // padding to a multiple of 8
         const int w = hb / heavy_parts, part = hb - w * heavy_parts;
+#ifndef B9_ABL_NO_HEAVY
         heavy_stars<NFP, NPOPS>(pk, st, hdr, iso_data, iso_stride, mass_cap, params, w, part, heavy_parts,
                                 partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part, perstar, smem);
+#else
+        if (threadIdx.x == 0) partial[(size_t)w * partial_stride + (size_t)n_groups * 4 + part] = 0.0;   // ablation build
+#endif
         return;
     }
     // LDS: the mass column of each (walker, population) isochrone this workgroup evaluates -- the binary search runs in LDS (dependent ds_reads

@@ -1,0 +1,131 @@
+"""GPU edge cases of the C ABI: filter counts up to the 16-filter limit, long isochrones, call-order
+and argument errors, reloading packs, degenerate inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from base_amd import abi, synth
+from conftest import build_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(a, b):
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin)
+    return float(np.max(np.abs(a[fin] - b[fin]) / np.maximum(1.0, np.abs(b[fin])))) if fin.any() else 0.0
+
+
+@pytest.mark.parametrize("n_filt", [1, 2, 4, 9, 12, 16])
+def test_filter_counts(n_filt):
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", n_filt, n_stars=300, wd_frac=0.05)
+    eng = engine.Engine(pack, stars, priors, options)
+    params = synth.walker_params(cl["truth"], 3)
+    got = eng.logpost(params, perstar=True)
+    want = oracle.Oracle(pack, stars, priors, options).logpost(params, perstar=True)
+    assert _err(got[1], want[1]) <= 1e-9 and _err(got[0], want[0]) <= 1e-9
+    assert eng.bytes_per_star_eval() == 16 * n_filt + 36
+
+
+def test_seventeen_filters_rejected():
+    from base_amd import engine
+    pack_d = synth.make_pack("parsec", 17, n_feh=3, n_age=4, n_eep=30)
+    with pytest.raises(engine.B9Error) as e:
+        engine.Engine(abi.make_pack(pack_d))
+    assert e.value.code == abi.B9_ERR_CAPACITY
+
+
+def test_long_isochrone_2000_eeps():
+    """2000 EEPs x 8 filters: mass column 16 KB in LDS, marginalised-mode isochrone 144 KB in LDS."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=400, n_feh=3, n_age=4, n_eep=2000)
+    eng = engine.Engine(pack, stars, priors, options)
+    params = synth.walker_params(cl["truth"], 2)
+    assert _err(eng.logpost(params, perstar=True)[1], oracle.Oracle(pack, stars, priors, options).logpost(params, perstar=True)[1]) <= 1e-9
+    assert eng.max_eep() >= 1996
+    sub = {k: (np.asarray(v)[:6] if k in ("obs", "sigma", "mass1", "mass_ratio", "clust_prior", "stage", "wd_type") else v) for k, v in cl.items()}
+    mopt = abi.make_options(abi.MODE_MARGINALISED, 1, 1, 2)
+    s6 = abi.make_stars(sub)
+    m_eng = engine.Engine(pack, s6, priors, mopt)
+    assert _err(m_eng.logpost(params), oracle.Oracle(pack, s6, priors, mopt).logpost(params)) <= 1e-9
+
+
+def test_call_order_and_argument_errors():
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("dsed", 8, n_stars=50)
+    eng = engine.Engine()
+    with pytest.raises(engine.B9Error) as e:
+        eng.n_stars = 50
+        eng.logpost(cl["truth"][None, :])
+    assert e.value.code == abi.B9_ERR_STATE
+    eng.load_pack(pack)
+    with pytest.raises(engine.B9Error) as e:
+        eng.logpost(cl["truth"][None, :])
+    assert e.value.code == abi.B9_ERR_STATE
+    # stars with the wrong filter count are refused at first use
+    other = synth.make_cluster(synth.make_pack("dsed", 5, n_feh=4, n_age=8, n_eep=90), 20, seed=1)
+    eng.load_stars(abi.make_stars(other))
+    with pytest.raises(engine.B9Error) as e:
+        eng.logpost(cl["truth"][None, :])
+    assert e.value.code == abi.B9_ERR_INVALID
+    eng.load_stars(stars)
+    assert np.isfinite(eng.logpost(cl["truth"][None, :])[0])
+    # malformed inputs
+    bad = dict(pack_d); bad["feh"] = pack_d["feh"][::-1].copy()
+    with pytest.raises(engine.B9Error):
+        engine.Engine(abi.make_pack(bad))
+    badc = dict(cl); badc["clust_prior"] = np.zeros(50)
+    with pytest.raises(engine.B9Error):
+        engine.Engine(pack, abi.make_stars(badc))
+    with pytest.raises(engine.B9Error):
+        eng.set_options(abi.make_options(n_pops=3))
+    assert eng.lib.b9_logpost(eng._ctx, None, 1, None, None) == abi.B9_ERR_INVALID
+
+
+def test_reload_pack_then_same_stars():
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=200, wd_frac=0.1)
+    eng = engine.Engine(pack, stars, priors, options)
+    a = eng.logpost(cl["truth"][None, :])[0]
+    pack2_d = synth.make_pack("parsec", 8, n_feh=4, n_age=8, n_eep=90, ifmr_id=abi.IFMR_SALARIS_LIN)
+    pack2_d["m_wd_up"] = 7.0                                   # changes the IMF normalisation folded into the star constants
+    pack2 = abi.make_pack(pack2_d)
+    eng.load_pack(pack2)                                       # stars must be re-derived against the new pack
+    b = eng.logpost(cl["truth"][None, :])[0]
+    want = oracle.Oracle(pack2, stars, priors, options).logpost(cl["truth"][None, :])[0]
+    assert abs(b - want) <= 1e-9 * abs(want) and a != b
+
+
+def test_all_stars_heavy_and_all_unused():
+    """Every star above the AGB tip (old walker), and a star with no usable filter."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=300)
+    cl = dict(cl)
+    sig = np.array(cl["sigma"]); sig[7, :] = -1.0; cl["sigma"] = sig
+    stars = abi.make_stars(cl)
+    eng = engine.Engine(pack, stars, priors, options)
+    par = cl["truth"].copy(); par[abi.P_LOGAGE] = pack_d["log_age"][-1] - 1e-6     # oldest isochrone: lowest tip
+    params = np.stack([par, cl["truth"]])
+    got, want = eng.logpost(params, perstar=True), oracle.Oracle(pack, stars, priors, options).logpost(params, perstar=True)
+    assert _err(got[1], want[1]) <= 1e-9 and _err(got[0], want[0]) <= 1e-9
+    heavy = (cl["mass1"] > 0.9).sum()
+    assert heavy > 20       # the old walker really sends stars down the WD branch
+
+
+def test_mcmc_block_argument_errors_and_zero_steps():
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("dsed", 8, n_stars=100)
+    eng = engine.Engine(pack, stars, priors, options)
+    start = synth.walker_params(cl["truth"], 2)
+    lp = eng.logpost(start)
+    out = eng.mcmc_run_block(start, lp, np.arange(2), np.array([0, 2]), np.eye(2) * 1e-3, 1, 0, 0)
+    np.testing.assert_array_equal(out[0], start)
+    assert out[4] == 0
+    with pytest.raises(engine.B9Error):
+        eng.mcmc_run_block(start, lp, np.arange(2), np.array([0, 99]), np.eye(2), 1, 0, 5)
+    one = eng.mcmc_run_block(start, lp, np.arange(2), np.array([0, 2]), np.eye(2) * 1e-3, 1, 0, 1)
+    two = eng.mcmc_run_block(start, lp, np.arange(2), np.array([0, 2]), np.eye(2) * 1e-3, 1, 0, 2)
+    np.testing.assert_array_equal(one[2][0], two[2][0])        # the first step does not depend on the block length
