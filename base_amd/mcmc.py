@@ -157,13 +157,16 @@ class WalkerSampler:
         self.step = 0
         self.accepted = 0
         self._gather = all_gather
-        # pooled running moments over all walkers and all blocks (Chan et al. pairwise update)
-        self.n_mom, self.mean, self.m2 = 0, np.zeros(self.d), np.zeros((self.d, self.d))
+        # pooled running sums over all walkers and all blocks, about the common origin x0
+        self.x0 = start[:, self.free].mean(axis=0)
+        self.n_mom, self.s1, self.s2 = 0.0, np.zeros(self.d), np.zeros((self.d, self.d))
 
     # -- collectives ------------------------------------------------------------------------
     def gather_rows(self, rows: np.ndarray) -> np.ndarray:
         """rows[per, k] on every rank -> [n_walkers, k] in walker order."""
-        if self.world == 1:
+        if self._gather is None:
+            if self.world != 1:
+                raise ValueError("more than one rank needs an all_gather")
             return rows.copy()
         return self._gather(rows)
 
@@ -179,9 +182,11 @@ class WalkerSampler:
             self.params, self.logpost, self.ids, self.free, self.scale * self.chol, self.seed, self.step, n)
         self.step += n
         self.accepted += n_acc
-        # one row per local walker: [lp, full position, #moves, n, sum x, sum x x^T] over the block
-        x = samples                                               # [n, per, d]
-        moved = (np.abs(np.diff(np.concatenate([x[:1] * np.nan, x]), axis=0)).sum(axis=2) > 0)[1:].sum(axis=0)
+        # one row per local walker: [lp, full position, #moves, n, sum x, sum x x^T] over the block,
+        # x measured from the common origin x0 (the ensemble's starting mean) so that the pooled
+        # second moments do not cancel catastrophically
+        x = samples - self.x0                                     # [n, per, d]
+        moved = (np.abs(np.diff(samples, axis=0)).sum(axis=2) > 0).sum(axis=0)
         row = np.concatenate([self.logpost[:, None], self.params, moved[:, None].astype(np.float64),
                               np.full((self.per, 1), float(n)), x.sum(axis=0),
                               np.einsum("swi,swj->wij", x, x).reshape(self.per, -1)], axis=1)
@@ -197,18 +202,16 @@ class WalkerSampler:
         return samples, lps
 
     def _adapt(self, mom: np.ndarray) -> None:
+        """Pool the block's per-walker sums (every rank sees the same gathered rows in the same
+        order, so every rank derives the same proposal factor).  O(1) numpy calls per block,
+        whatever the number of walkers."""
         d = self.d
-        for w in range(self.n_walkers):                           # fixed walker order on every rank
-            n_b, s1, s2 = mom[w, 0], mom[w, 1:1 + d], mom[w, 1 + d:].reshape(d, d)
-            mean_b = s1 / n_b
-            m2_b = s2 - n_b * np.outer(mean_b, mean_b)
-            tot = self.n_mom + n_b
-            dlt = mean_b - self.mean
-            self.m2 += m2_b + np.outer(dlt, dlt) * (self.n_mom * n_b / tot)
-            self.mean += dlt * (n_b / tot)
-            self.n_mom = tot
+        self.n_mom += float(mom[:, 0].sum())
+        self.s1 += mom[:, 1:1 + d].sum(axis=0)
+        self.s2 += mom[:, 1 + d:].sum(axis=0).reshape(d, d)
         if self.n_mom > 20 * d:
-            cov = self.m2 / (self.n_mom - 1) * (2.38 ** 2 / d)
+            mean = self.s1 / self.n_mom
+            cov = (self.s2 - self.n_mom * np.outer(mean, mean)) / (self.n_mom - 1) * (2.38 ** 2 / d)
             scale = np.sqrt(np.maximum(np.diag(cov), 1e-300))
             cov = cov + np.diag((1e-6 * scale) ** 2)              # keep it positive definite
             try:

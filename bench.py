@@ -106,8 +106,12 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     local_rank = local_rank % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("B9_FORCE_DIST") == "1"     # the latter: 1-rank rehearsal of the collectives
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -122,14 +126,14 @@ def main():
     eng = engine.Engine(pack, stars, priors, options, device=local_rank)
     n_walkers = WALKERS_PER_GPU * world
     start = synth.walker_params(truth, n_walkers, seed=42, scale=0.02)
-    gather = mcmc.torch_all_gather("cuda" if args.backend == "nccl" else None) if world > 1 else None
+    gather = mcmc.torch_all_gather("cuda" if args.backend == "nccl" else None) if use_dist else None
     block = 50
     sampler = mcmc.WalkerSampler(start, mcmc.DeviceBlockRunner(eng, record=True), rank, world, gather,
                                  seed=2024, block=block)
     sampler.initialise(eng.logpost)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -146,7 +150,7 @@ def main():
     eng.enable_timing(0)
     bracket_ms = eng.calibrate_timing()     # event bracket around an empty kernel, same stream
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -196,7 +200,7 @@ def main():
         if world == 1:
             out["marginalised_mode"] = marginalised_leg(pack, stars, priors, truth, local_rank)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 
