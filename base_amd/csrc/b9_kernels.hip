@@ -1171,6 +1171,9 @@ extern "C" int b9_debug_read_stamps(unsigned long long *out, int n_waves)
 // The whole isochrone (mass column + magnitude rows) of the walker lives in LDS.
 // ------------------------------------------------------------------------------------------
 struct Lse { double mx, sm; };      // online log-sum-exp:  value = mx + log(sm)
+#ifndef B9_MARG_CUT
+#define B9_MARG_CUT 40.0             // nodes more than this many e-folds below the running maximum are dropped
+#endif
 
 __device__ __forceinline__ void lse_add(Lse &a, double x)
 {
@@ -1269,11 +1272,56 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                 }
             }
         } else {
+            // Pruning (exact to ~1e-13 relative): a node whose log-term lies more than B9_MARG_CUT
+            // below the wave's running maximum adds < e^-40 of the leading term and is dropped.
+            //  (A) a companion only ADDS flux, so every filter in which the primary alone is already
+            //      brighter than observed keeps at least that chi^2 for every mass ratio: if that lower
+            //      bound is past the cut, the whole mass-ratio loop of this primary is skipped;
+            //  (B) inside a node the filters are accumulated one at a time and the wave leaves the
+            //      filter loop as soon as EVERY lane's partial chi^2 is past the cut.
             const int n_nodes = (is.n - 1) * K;
-            for (int pnode = lane; pnode < n_nodes; pnode += 64) {
-                const int e = pnode / K, s = pnode - e * K;
-                const double a = is.mass[e], d = is.mass[e + 1] - a;
-                if (!(d > 0.0)) continue;
+            // seed of the running maximum: the single-star term of the GRID NODE just below the star's
+            // catalogue mass -- an actual term of the sum, hence a rigorous lower bound of its maximum
+            // (only ever used as a pruning bound), so pruning bites from the first iteration
+            double seed = NEG_INF;
+            {
+                const double ms = st.mass1[slot];
+                if (ms >= is.mass[0] && ms <= is.tip) {
+                    int lo; double t;
+                    find_bracket(is.mass, is.n, ms, lo, t);
+                    const double a = is.mass[lo], d = is.mass[lo + 1] - a;
+                    if (d > 0.0) {
+                        const double dMs = d / K;
+                        int s = (int)((ms - a) / dMs);
+                        s = s < 0 ? 0 : (s > K - 1 ? K - 1 : s);
+                        const double mn = fma((double)s, dMs, a), tn = (mn - a) / d;
+                        const double *r = is.mags + (size_t)lo * NFP;
+                        double c = 0.0;
+#pragma unroll
+                        for (int f = 0; f < NFP; ++f) { const double dd = (lerp(r[f], r[NFP + f], tn) + shift[f]) - obs[f]; c = fma(wgt[f] * dd, dd, c); }
+                        if (isfinite(c)) seed = (log_prior_mass_dev(pk.log_mass_norm, mn) + log(dMs / Q)) - 0.5 * c;
+                    }
+                }
+            }
+            // upper bound of (log prior + log weight) over all nodes: the IMF density per unit mass
+            // falls with mass above 0.1 Msun, so its maximum is at the first point; the widest EEP
+            // interval bounds the weight.  Lets dead nodes skip the two logarithms of their own prior.
+            double dmax = 0.0;
+            for (int e2 = lane; e2 + 1 < is.n; e2 += 64) { const double dd = is.mass[e2 + 1] - is.mass[e2]; dmax = dd > dmax ? dd : dmax; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(dmax, o, 64); dmax = t > dmax ? t : dmax; }
+            const double mlow = is.mass[0] > 0.1 ? is.mass[0] : 0.1;
+            const double bmax = (dmax > 0.0) ? log_prior_mass_dev(pk.log_mass_norm, mlow) + log(dmax / K / Q) : NEG_INF;
+            for (int p0 = 0; p0 < n_nodes; p0 += 64) {
+                const int pnode = p0 + lane;
+                // wave-wide running maximum (conservative for every lane)
+                double wmx = acc.mx > seed ? acc.mx : seed;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(wmx, o, 64); wmx = t > wmx ? t : wmx; }
+                bool live = pnode < n_nodes;
+                int e = 0, s = 0;
+                double a = 0.0, d = 1.0;
+                if (live) { e = pnode / K; s = pnode - e * K; a = is.mass[e]; d = is.mass[e + 1] - a; live = d > 0.0; }
                 const double dM = d / K;
                 const double m1 = fma((double)s, dM, a);
                 const double t1 = (m1 - a) / d;
@@ -1281,27 +1329,42 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                 const double *r0 = is.mags + (size_t)e * NFP;
 #pragma unroll
                 for (int f = 0; f < NFP; ++f) p1[f] = lerp(r0[f], r0[NFP + f], t1);
-                const double base = log_prior_mass_dev(pk.log_mass_norm, m1) + log(dM / Q);
-                for (int j = 0; j < Q; ++j) {
-                    double chi2 = 0.0;
-                    if (j == 0) {
+                // j = 0 (single star) and the too-bright lower bound for j >= 1
+                double chi0 = 0.0, chi_lb = 0.0;
 #pragma unroll
-                        for (int f = 0; f < NFP; ++f) { const double dd = (p1[f] + shift[f]) - obs[f]; chi2 = fma(wgt[f] * dd, dd, chi2); }
-                    } else {
-                        const double m2 = ((double)j / (double)Q) * m1;
-                        const bool dark2 = m2 < is.mass[0];
-                        int lo2; double t2;
-                        find_bracket(is.mass, is.n, m2, lo2, t2);
-                        const double *s0 = is.mags + (size_t)lo2 * NFP;
+                for (int f = 0; f < NFP; ++f) {
+                    const double dd = (p1[f] + shift[f]) - obs[f];
+                    chi0 = fma(wgt[f] * dd, dd, chi0);
+                    chi_lb = dd < 0.0 ? fma(wgt[f] * dd, dd, chi_lb) : chi_lb;
+                }
+                // with the bound bmax on this node's (prior + weight) nothing of it can matter: skip
+                const double cut_ub = 2.0 * ((bmax - wmx) + B9_MARG_CUT);
+                live = live && !(chi_lb > cut_ub);                           // chi0 >= chi_lb
+                if (__ballot(live) == 0ull) continue;
+                const double base = live ? log_prior_mass_dev(pk.log_mass_norm, m1) + log(dM / Q) : NEG_INF;
+                if (live && isfinite(chi0)) lse_add(acc, base - 0.5 * chi0);
+                const double cut = 2.0 * ((base - wmx) + B9_MARG_CUT);       // chi^2 beyond this is negligible
+                bool want = live && !(chi_lb > cut);
+                if (__ballot(want) == 0ull) continue;                        // (A) for the whole wave
+                for (int j = 1; j < Q; ++j) {
+                    const double m2 = ((double)j / (double)Q) * m1;
+                    const bool dark2 = m2 < is.mass[0];
+                    int lo2; double t2;
+                    find_bracket(is.mass, is.n, m2, lo2, t2);
+                    const double *s0 = is.mags + (size_t)lo2 * NFP;
+                    double chi2 = want ? 0.0 : __builtin_inf();
+                    bool done = false;
 #pragma unroll
-                        for (int f = 0; f < NFP; ++f) {
+                    for (int f = 0; f < NFP; ++f) {
+                        if (!done) {
                             const double p2 = dark2 ? B9_MAG_NOFLUX : lerp(s0[f], s0[NFP + f], t2);
                             const double pc = p1[f] - (2.5 / LN10) * log1pexp((-0.4 * LN10) * (p2 - p1[f]));
                             const double dd = (pc + shift[f]) - obs[f];
                             chi2 = fma(wgt[f] * dd, dd, chi2);
+                            done = (__ballot(chi2 <= cut) == 0ull);          // (B): uniform across the wave
                         }
                     }
-                    if (isfinite(chi2)) lse_add(acc, base - 0.5 * chi2);
+                    if (want && !done && isfinite(chi2) && chi2 <= cut) lse_add(acc, base - 0.5 * chi2);
                 }
             }
         }
