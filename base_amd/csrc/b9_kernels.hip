@@ -715,6 +715,9 @@ __device__ __forceinline__ bool load_iso_views(const IsoHdr *__restrict__ hdr, c
 #ifndef B9_K1_MIN_WAVES
 #define B9_K1_MIN_WAVES 3
 #endif
+#ifndef B9_K1_MIN_WAVES_2POP
+#define B9_K1_MIN_WAVES_2POP 2      // two populations: the loop-carried state pushes the body past 168 VGPRs
+#endif
 
 // Bracket of mass m in an LDS-resident mass column: the largest i in [0, n-2] with mass[i] <= m
 // (what the oracle's binary search returns -- the bracket is unique for a sorted column, so any
@@ -781,23 +784,30 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
     const bool binary = q > 0.0;
 #endif
     const double m2 = q * m1;
-    double ll[NPOPS];
-#pragma unroll
+    double ll[2] = {0.0, 0.0};
+    // The population loop is deliberately NOT unrolled: unrolled, the compiler overlaps the two
+    // populations' row loads and transcendental temporaries and spills (324 B of scratch per lane,
+    // 5x slower per star-eval); rolled, the body keeps the single-population register footprint.
+    // The isochrone view is picked with wave-uniform selects.
+#pragma unroll 1
     for (int k = 0; k < NPOPS; ++k) {
+        const double *is_mass = (NPOPS == 2 && k) ? iso[NPOPS - 1].mass : iso[0].mass;
+        const double *is_mags = (NPOPS == 2 && k) ? iso[NPOPS - 1].mags : iso[0].mags;
+        const int is_n = (NPOPS == 2 && k) ? iso[NPOPS - 1].n : iso[0].n;
         int lo1, lo2 = 0;
         double t1, t2 = 0.0;
-        const bool dark1 = !(m1 > 0.0) || m1 < iso[k].mass[0];
-        const bool dark2 = !(m2 > 0.0) || m2 < iso[k].mass[0];
+        const bool dark1 = !(m1 > 0.0) || m1 < is_mass[0];
+        const bool dark2 = !(m2 > 0.0) || m2 < is_mass[0];
 #ifdef B9_ABL_NOSEARCH
-        lo1 = (int)(m1 * 100.0) % (iso[k].n - 1); t1 = m1 - (int)m1; lo2 = lo1 / 2; t2 = t1;
+        lo1 = (int)(m1 * 100.0) % (is_n - 1); t1 = m1 - (int)m1; lo2 = lo1 / 2; t2 = t1;
 #else
-        find_bracket(iso[k].mass, iso[k].n, m1, lo1, t1);
-        if (binary) find_bracket(iso[k].mass, iso[k].n, m2, lo2, t2);
+        find_bracket(is_mass, is_n, m1, lo1, t1);
+        if (binary) find_bracket(is_mass, is_n, m2, lo2, t2);
 #endif
         STAMP(4);
         // two consecutive rows = 2*NFP contiguous doubles
-        const double2 *r1 = reinterpret_cast<const double2 *>(iso[k].mags + (size_t)lo1 * NFP);
-        const double2 *r2 = reinterpret_cast<const double2 *>(iso[k].mags + (size_t)lo2 * NFP);
+        const double2 *r1 = reinterpret_cast<const double2 *>(is_mags + (size_t)lo1 * NFP);
+        const double2 *r2 = reinterpret_cast<const double2 *>(is_mags + (size_t)lo2 * NFP);
         double chi2 = 0.0;
 #if defined(B9_QUAD_PASS) && defined(B9_LATE_OBS)
         // Passes of four filters.  Each pass requests its slice of the primary rows, of the secondary
@@ -880,10 +890,11 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
             chi2 = fma(wgt[f] * d, d, chi2);
         }
 #endif
-        ll[k] = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
+        const double llk = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
+        if (k == 0) ll[0] = llk; else ll[1] = llk;
     }
     double l = ll[0];
-    if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[NPOPS - 1]);
+    if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[1]);
     return l;       // log p_i L_i ; the field-star mixture is applied by the caller in product form
 }
 
@@ -1009,7 +1020,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
 }
 
 template <int NFP, int NPOPS, int WB>
-__global__ __launch_bounds__(256, B9_K1_MIN_WAVES) void k_star_like(DevPack pk, DevStars st,
+__global__ __launch_bounds__(256, (NPOPS == 2 && B9_K1_MIN_WAVES > B9_K1_MIN_WAVES_2POP) ? B9_K1_MIN_WAVES_2POP : B9_K1_MIN_WAVES) void k_star_like(DevPack pk, DevStars st,
                                                     const IsoHdr *__restrict__ hdr,
                                                     const double *__restrict__ iso_data,
                                                     long long iso_stride, int mass_cap,
