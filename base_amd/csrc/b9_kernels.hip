@@ -1,14 +1,26 @@
 // b9_kernels.hip -- hand-written gfx950 kernels of the BASE-9 per-step log-posterior path.
 //
-//   k_derive_iso   SURVEY 8a row a3   one workgroup per (walker, population): grid bracket,
-//                                     EEP-range intersection, EEP-wise tri-linear interpolation
-//   k_star_like    rows a4-a6, a9     one LANE per star (given-mass mode): binary search in the
-//                                     LDS-staged mass column + linear interpolation, binary flux
-//                                     combination, Gaussian log-likelihood,
-//                                     population and field-star mixtures; wave-shuffle +
-//                                     LDS block reduction to one partial per workgroup
-//   k_finalize     rows a7, a8        WD-branch stars (IFMR, cooling, atmospheres), fixed-order sum
-//                                     of the partials + cluster prior
+//   k_derive_iso   SURVEY 8a rows a3, a8  one workgroup per (walker, population, slice of EEPs): grid
+//                                     brackets by wave ballot, EEP-range intersection, EEP-wise
+//                                     tri-linear interpolation (one value per thread).  In the
+//                                     device-resident sampler it first FINISHES the previous step
+//                                     (fixed-order sum of partials + prior + Metropolis accept,
+//                                     recomputed identically by every workgroup of the walker) and
+//                                     draws the new proposal (Philox4x32-10 + Box-Muller)
+//   k_star_like    rows a4-a7, a9      given-mass mode, the dominant kernel.  HOT workgroups: one
+//                                     LANE per star -- 8-ary search in the LDS-staged mass column,
+//                                     magnitude rows from L2, binary flux combination, Gaussian
+//                                     chi^2, population mixture, product-form field-star mixture,
+//                                     one partial per wave.  HEAVY workgroups (first in the grid):
+//                                     the stars above the AGB tip (IFMR -> WD cooling -> WD
+//                                     atmosphere, or NS/BH) through the general per-star code
+//   k_star_marg    row a6 (marg.)      marginalised mode: ONE WAVEFRONT PER STAR integrating over
+//                                     primary mass and mass ratio, rigorous pruning, online
+//                                     log-sum-exp, wavefront-shuffle merge
+//   k_finalize     row a8              fixed-order sum of the partials + cluster prior (+ the accept
+//                                     of a sampler block's last step)
+//
+// One MCMC step = k_derive_iso + k_star_like (two launches, no host involvement).
 //
 // The reference source is not mounted (/root/reference/README.md:4), so none of this can
 // cite a reference file:line; DESIGN.md "Math" is the normative restatement and
@@ -17,6 +29,8 @@
 // derived isochrone bit-identical to the oracle's.
 //
 // No MFMA anywhere: there is no dense contraction on this path (BASELINE.json north_star).
+// Diagnostic-only macros (never defined in the shipped library): B9_STAMPS (per-phase s_memtime
+// stamps), B9_ABL_* (ablation builds used for the attribution in DESIGN.md section 8).
 #include "b9_device.h"
 #include "b9_launch.h"
 #include <algorithm>
