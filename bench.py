@@ -38,8 +38,9 @@ MCMC_BLOCK = 100       # steps between adaptation points (= between all-gathers)
 TIMING_EVERY = 8        # HIP-event bracket on every 8th launch of the dominant kernel in the timed region
 
 
-def cpu_baseline(pack_d, cl, truth, budget_s: float = 12.0):
-    """Time the CPU oracle on a bounded sample of the same workload (rank 0 only)."""
+def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0):
+    """Time the CPU oracle on a bounded sample of the same workload (rank 0 only): all host cores
+    (OpenMP over stars, as the reference's thread pool [RECALL]) and one thread."""
     import oracle
     from base_amd import abi, synth
     try:
@@ -51,20 +52,30 @@ def cpu_baseline(pack_d, cl, truth, budget_s: float = 12.0):
     priors, options = synth.default_priors(pack_d, truth), abi.make_options()
     orc = oracle.Oracle(pack, stars, priors, options, native=native)
     params = synth.walker_params(truth, WALKERS_PER_GPU)
-    orc.logpost(params[:1])                       # warm
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        orc.logpost(params)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or reps >= 200:
-            break
-    evals = reps * N_STARS * WALKERS_PER_GPU
-    return {"value": evals / dt, "unit": "star-likelihood evals/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x logpost of {WALKERS_PER_GPU} walkers x {N_STARS} stars x {N_FILT} filters "
-                      f"({dt:.1f} s, oracle/b9_oracle.c -O3 -march=native, 1 thread; "
-                      f"BASE-9 itself is not mounted: build's CPU oracle, parity unpinned)"}
+    # a one-GPU job's CPU share on the GPU boxes is 16 cores, whatever the host exposes
+    cores = max(1, min(int(orc.lib.b9o_max_threads()), len(os.sched_getaffinity(0)), 16))
+
+    def timed(threads, budget):
+        orc.lib.b9o_set_threads(threads)
+        orc.logpost(params[:1])                       # warm
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            orc.logpost(params)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or reps >= 400:
+                break
+        return reps * N_STARS * WALKERS_PER_GPU / dt, reps, dt
+
+    v_all, reps, dt = timed(cores, budget_s / 2)
+    v_one, reps1, dt1 = timed(1, budget_s / 2)
+    best, best_cores = (v_all, cores) if v_all >= v_one else (v_one, 1)      # the CPU's best effort is the baseline
+    return {"value": best, "unit": "star-likelihood evals/s", "cores": best_cores, "kind": "port",
+            "value_all_cores": v_all, "host_cores": cores, "value_1thread": v_one,
+            "sample": f"{reps} x logpost of {WALKERS_PER_GPU} walkers x {N_STARS} stars x {N_FILT} filters on {cores} "
+                      f"OpenMP thread(s) ({dt:.1f} s) and {reps1} x on 1 thread ({dt1:.1f} s); oracle/b9_oracle.c "
+                      f"-O3 -march=native -fopenmp; BASE-9 itself is not mounted: build's CPU oracle, parity unpinned"}
 
 
 def marginalised_leg(pack, stars, priors, truth, local_rank, n_calls: int = 5):

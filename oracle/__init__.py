@@ -43,6 +43,9 @@ def load(native: bool = False) -> C.CDLL:
     lib.b9o_log_prior_mass.restype = C.c_double
     lib.b9o_log_prior_cluster.argtypes = [C.POINTER(abi.b9_priors), _dp, C.c_int]
     lib.b9o_log_prior_cluster.restype = C.c_double
+    lib.b9o_max_threads.restype = C.c_int
+    lib.b9o_set_threads.argtypes = [C.c_int]
+    lib.b9o_set_threads.restype = None
     return lib
 
 

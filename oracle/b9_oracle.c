@@ -26,6 +26,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define B9O_LOG_G_PLUS_LOG_MSUN 26.12302173752 /* log10(G * Msun), cgs ([RECALL] constants.hpp) */
 #define B9O_MF_MU (-1.02)                       /* Miller-Scalo log-normal IMF ([RECALL])        */
@@ -445,6 +448,11 @@ int b9o_logpost(const b9_pack *p, const b9_stars *s, const b9_priors *pr, const 
             continue;
         }
         double total = 0.0;
+        /* Timed "native" build only (-fopenmp): threads over stars, as the reference's thread pool does
+         * [RECALL].  The checker build has no OpenMP: this pragma is then ignored and the sum is sequential. */
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : total) schedule(static)
+#endif
         for (int i = 0; i < s->n_stars; ++i) {
             double ll[2];
             for (int k = 0; k < n_pops; ++k)
@@ -480,4 +488,22 @@ int b9o_derive_isochrone_flat(const b9_pack *p, const double *par, int pop, int 
     *out_n = iso.n; *out_first_eep = iso.first_eep; *out_agb_tip = iso.agb_tip;
     b9o_iso_free(&iso);
     return B9_OK;
+}
+
+/* Thread control for the timed build (no-ops without OpenMP). */
+int b9o_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void b9o_set_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
 }
