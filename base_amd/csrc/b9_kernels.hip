@@ -274,20 +274,6 @@ __device__ __forceinline__ void draw_z(const McmcDev &mc, int w, unsigned long l
     }
 }
 
-// Metropolis proposal from the row `cur_row` and the normals in s_z:  s_par = cur;
-// s_par[free[i]] += sum_j chol[i][j] z_j.  All threads call.
-__device__ __forceinline__ void propose_row(const McmcDev &mc, const double *cur_row, double *s_par, const double *s_z)
-{
-    const int tid = threadIdx.x, d = mc.d;
-    __syncthreads();                                     // s_z complete, s_par free
-    if (tid < B9_NPARAM) s_par[tid] = cur_row[tid];
-    double delta = 0.0;
-    if (tid < d) for (int j = 0; j < d; ++j) delta = delta + mc.chol[tid * d + j] * s_z[j];
-    __syncthreads();
-    if (tid < d) s_par[mc.free_idx[tid]] += delta;
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------------
 // k_derive_iso
 // ------------------------------------------------------------------------------------------
@@ -468,21 +454,57 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restri
 {
     const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops;
     const double *par = params + (size_t)w * B9_NPARAM;
-    __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_lp, s_red[4];
+    __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_prop[B9_NPARAM], s_red[4];
     const AxisRegs axr = preload_axis(pk);                 // first round trip, needs no parameter
     if (mc.enabled) {
-        draw_z(mc, w, mc.step, 192, s_z);                  // wave 3: this step's normals, independent of the state
+        // Everything the prologue reads is requested NOW, in one round trip: the walker's current
+        // row and log-posterior, the previous proposal, this thread's row of the proposal factor,
+        // and (inside finish_logpost) the partials.  Nothing below waits on memory again until the
+        // isochrone tables.
+        const int tid = threadIdx.x, d = mc.d;
         const bool writer = (blockIdx.y == 0 && pop == 0);
-        const double *cur_row = mc.cur + ((size_t)mc.pin * mc.n_walkers + w) * B9_NPARAM;
+        const size_t st_in = (size_t)mc.pin * mc.n_walkers + w;
+        const double cur_v = tid < B9_NPARAM ? mc.cur[st_in * B9_NPARAM + tid] : 0.0;
+        const double prop_v = (mc.has_prev && tid < B9_NPARAM) ? params_prev[(size_t)w * B9_NPARAM + tid] : 0.0;
+        const double lp_cur = mc.lp_cur[st_in];
+        double crow[11];
+#pragma unroll
+        for (int j = 0; j < 11; ++j) crow[j] = (tid < d && j < d) ? mc.chol[tid * d + j] : 0.0;
+        const int fidx = tid < d ? mc.free_idx[tid] : 0;
+        draw_z(mc, w, mc.step, 192, s_z);                  // wave 3: this step's normals, independent of the state
+        if (tid < B9_NPARAM) { s_prop[tid] = prop_v; s_cur[tid] = cur_v; }
+        __syncthreads();
         if (mc.has_prev) {
-            const double *prop_prev = params_prev + (size_t)w * B9_NPARAM;
             const double lp_prop = finish_logpost(hdr_prev, partial_prev + (size_t)w * partial_stride, n_partial,
-                                                  prop_prev, pr, n_pops, w, s_red);
-            metropolis_accept(mc, w, mc.step - 1, mc.row, prop_prev, lp_prop, writer, s_cur, &s_lp);
-            cur_row = s_cur;
+                                                  s_prop, pr, n_pops, w, s_red);
+            // Metropolis accept/reject of step t-1 (u: draw index n_pairs of that step's Philox stream)
+            unsigned r[4];
+            const unsigned long long sp = mc.step - 1;
+            philox4x32((unsigned)sp, (unsigned)(sp >> 32), (unsigned)mc.walker_ids[w], (unsigned)((d + 1) >> 1), mc.k0, mc.k1, r);
+            const bool ok = isfinite(lp_prop) && (log(u01(r[0], r[1])) < lp_prop - lp_cur);
+            const double lp_new = ok ? lp_prop : lp_cur;
+            if (tid < B9_NPARAM && ok) s_cur[tid] = prop_v;      // own slot only: no hazard with the reads above
+            __syncthreads();
+            if (writer) {
+                const size_t st_out = (size_t)(mc.pin ^ 1) * mc.n_walkers + w;
+                if (tid < B9_NPARAM) mc.cur[st_out * B9_NPARAM + tid] = s_cur[tid];
+                if (tid == 0) {
+                    mc.lp_cur[st_out] = lp_new;
+                    if (ok) atomicAdd(mc.n_acc, 1ull);
+                    if (mc.lps) mc.lps[(size_t)mc.row * mc.n_walkers + w] = lp_new;
+                }
+                if (mc.samples && tid < d) mc.samples[((size_t)mc.row * mc.n_walkers + w) * d + tid] = s_cur[fidx];
+            }
         }
-        propose_row(mc, cur_row, s_par, s_z);
-        if (writer && threadIdx.x < B9_NPARAM) params[(size_t)w * B9_NPARAM + threadIdx.x] = s_par[threadIdx.x];
+        // proposal of step t:  s_par = state;  s_par[free[i]] += sum_j chol[i][j] z_j  (j ascending, plain multiply-add)
+        if (tid < B9_NPARAM) s_par[tid] = s_cur[tid];
+        double delta = 0.0;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) if (j < d) delta = delta + crow[j] * s_z[j];
+        __syncthreads();
+        if (tid < d) s_par[fidx] += delta;
+        __syncthreads();
+        if (writer && tid < B9_NPARAM) params[(size_t)w * B9_NPARAM + tid] = s_par[tid];
         par = s_par;
     }
     derive_iso_block(pk, par, pop, wp, hdr, iso_data, iso_stride, mass_cap, blockIdx.y, gridDim.y, axr);
