@@ -1,0 +1,72 @@
+"""Property-based CPU tests (hypothesis): the oracle against the independent numpy statement at
+random in-grid parameters and random small clusters; structural properties of the log-posterior."""
+import numpy as np
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import numpy_ref
+import oracle
+from base_amd import abi, mcmc, synth
+from conftest import build_problem
+
+_PROBLEMS = {}
+
+
+def _problem(key):
+    if key not in _PROBLEMS:
+        name, nf, ny, npops = key
+        pack_d, cl, pack, stars, priors, _ = build_problem(name, nf, n_stars=120, wd_frac=0.1, n_y=ny, n_pops=npops, seed=5)
+        _PROBLEMS[key] = (pack_d, cl, pack, stars, priors)
+    return _PROBLEMS[key]
+
+
+unit = st.floats(min_value=0.0, max_value=1.0, allow_nan=False)
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(key=st.sampled_from([("girardi", 3, 1, 1), ("parsec", 8, 1, 1), ("dsed", 5, 3, 2)]),
+       ua=unit, uf=unit, uy=unit, uy2=unit, lam=st.floats(0.01, 0.99), mod=st.floats(8.0, 12.0), av=st.floats(0.0, 0.5))
+def test_oracle_equals_numpy_anywhere_in_the_grid(key, ua, uf, uy, uy2, lam, mod, av):
+    pack_d, cl, pack, stars, priors = _problem(key)
+    n_pops = key[3]
+    par = cl["truth"].copy()
+    la, fe, yy = pack_d["log_age"], pack_d["feh"], pack_d["y"]
+    par[abi.P_LOGAGE] = la[0] + ua * (la[-1] - la[0])
+    par[abi.P_FEH] = fe[0] + uf * (fe[-1] - fe[0])
+    par[abi.P_Y] = yy[0] + uy * (yy[-1] - yy[0])
+    par[abi.P_Y2] = yy[0] + uy2 * (yy[-1] - yy[0])
+    par[abi.P_LAMBDA], par[abi.P_MOD], par[abi.P_ABS] = lam, mod, av
+    lp, ps = oracle.Oracle(pack, stars, priors, abi.make_options(n_pops=n_pops)).logpost(par[None, :], perstar=True)
+    ref, ref_ps = numpy_ref.logpost(pack_d, cl, priors, par, n_pops)
+    np.testing.assert_allclose(ps[0], ref_ps, rtol=1e-9, atol=1e-8)
+    assert abs(lp[0] - ref) <= 1e-8 * max(1.0, abs(ref))
+    # every per-star value is bounded below by its field-star floor log((1-p) fs)
+    log_fs = -np.sum(np.log(cl["filter_prior_max"] - cl["filter_prior_min"]))
+    assert np.all(ps[0] >= np.log1p(-cl["clust_prior"]) + log_fs - 1e-9)
+
+
+@settings(max_examples=25, deadline=None)
+@given(shift=st.floats(-0.5, 0.5), seed=st.integers(0, 10_000))
+def test_modulus_shift_is_equivalent_to_shifting_every_observation(shift, seed):
+    """logPost(mod + s | obs + s) == logPost(mod | obs) when the prior on the modulus is flat."""
+    pack_d, cl, pack, stars, priors = _problem(("parsec", 8, 1, 1))
+    pr = abi.make_priors(log_age_min=priors.log_age_min, log_age_max=priors.log_age_max)
+    par = synth.walker_params(cl["truth"], 1, seed=seed, scale=0.5)[0]
+    a = oracle.Oracle(pack, stars, pr, abi.make_options()).logpost(par[None, :], perstar=True)[1][0]
+    cl2 = dict(cl)
+    cl2["obs"] = np.asarray(cl["obs"]) + shift
+    cl2["filter_prior_min"] = cl["filter_prior_min"] + shift
+    cl2["filter_prior_max"] = cl["filter_prior_max"] + shift
+    par2 = par.copy(); par2[abi.P_MOD] += shift
+    b = oracle.Oracle(pack, abi.make_stars(cl2), pr, abi.make_options()).logpost(par2[None, :], perstar=True)[1][0]
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-8)
+
+
+@settings(max_examples=30, deadline=None)
+@given(seed=st.integers(0, 2**31 - 1), step=st.integers(0, 2**40), d=st.integers(1, 11))
+def test_philox_draws_depend_only_on_seed_step_walker(seed, step, d):
+    z, u = mcmc.draws(seed, step, np.array([3, 9, 4]), d)
+    z2, u2 = mcmc.draws(seed, step, np.array([9]), d)
+    np.testing.assert_array_equal(z[1], z2[0])
+    assert u[1] == u2[0] and np.all(np.isfinite(z)) and np.all((u > 0) & (u < 1))
+    z3, _ = mcmc.draws(seed, step + 1, np.array([9]), d)
+    assert not np.array_equal(z2, z3)
