@@ -979,7 +979,8 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
         a.mant = __builtin_amdgcn_frexp_mant(m);
         a.add += d2;
     }
-    return (log(a.mant) + (double)a.expo * 0.693147180559945309417) + a.add;
+    // mant in [0.5, 1): log(mant) = log_ge1(2 mant) - ln 2 (the lean log instead of the library one)
+    return (log_ge1(a.mant + a.mant) + (double)(a.expo - 1) * 0.693147180559945309417) + a.add;
 }
 
 // The stars the hot path skips -- primary heavier than the walker's AGB tip (SURVEY 8a row a7:
