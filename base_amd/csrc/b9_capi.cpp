@@ -2,8 +2,9 @@
 //
 // Host side of the hot path: validates and stages the model pack and the stars to HBM once,
 // then turns each b9_logpost call into three stream-ordered launches
-// (k_derive_iso -> k_star_like / k_star_marg -> k_finalize).  No CPU fallback exists: without a HIP
-// device b9_ctx_create fails.  See DESIGN.md for the data layout.
+// (k_derive_iso -> k_star_like / k_star_marg -> k_finalize) and each step of b9_mcmc_run_block into
+// two (k_derive_iso, which also finishes the previous step, -> k_star_like).  No CPU fallback
+// exists: without a HIP device b9_ctx_create fails.  See DESIGN.md for the data layout.
 #include "../../include/base9_hip.h"
 #include "b9_device.h"
 #include "b9_launch.h"
@@ -192,7 +193,7 @@ int build_stars(b9_ctx *ctx)
         flags[i] = (h.wd_type[s] > 0 ? 1 : 0) | (h.stage[s] << 8);
         permp[i] = s;
     }
-    // slots in descending order of primary mass: k_finalize takes the leading run of stars
+    // slots in descending order of primary mass: the heavy-star workgroups of k_star_like take the leading run of stars
     // heavier than a walker's AGB tip (the WD / NS-BH branch) from this list
     std::vector<int> heavy_slot;
     heavy_slot.reserve(n);
@@ -232,8 +233,8 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
         int cw = std::max(n_walkers, ctx->cap_walkers), cp = std::max(n_pops, ctx->cap_pops);
         ctx->mass_cap = (ctx->pk.max_eep + 1) & ~1;
         ctx->iso_stride = (long long)ctx->mass_cap * (ctx->pk.nfp + 1);
-        // two sets (ping-pong): the fused sampler's k_finalize writes step t+1's proposal and
-        // isochrones while step t's are still the ones it reads
+        // two sets (ping-pong): the device sampler's k_derive_iso of step t+1 writes that step's proposal
+        // and isochrones while it still reads step t's headers and proposal to finish step t
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_hdr, sizeof(IsoHdr) * cw * cp * 2));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_iso, sizeof(double) * (size_t)ctx->iso_stride * cw * cp * 2));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_params, sizeof(double) * B9_NPARAM * cw * 2));
