@@ -64,3 +64,36 @@ def logpost(pack_d, cl, priors, par, n_pops=1):
     with np.errstate(divide="ignore"):
         v = logsumexp(np.stack([np.log1p(-pm) + log_fs, np.log(pm) + ll]), axis=0)
     return lp + v.sum(), v
+
+
+def marg_perstar(pack_d, cl, par, K, Q, pop=0):
+    """Brute-force numpy statement of the marginalised per-star log-likelihood (MS/RGB-stage stars
+    only): log sum over primary nodes (K sub-steps per EEP interval, left endpoints) and mass ratios
+    j/Q of  prior(M1) * dM/Q * prod_f N(obs_f | combined_f, sigma_f^2).  Independent of the C oracle."""
+    first, imass, imags = synth.derive_isochrone(pack_d, par[abi.P_LOGAGE], par[abi.P_FEH], par[abi.P_Y2 if pop else abi.P_Y])
+    m_nodes, w_nodes = [], []
+    for e in range(len(imass) - 1):
+        d = imass[e + 1] - imass[e]
+        if not d > 0:
+            continue
+        for s in range(K):
+            m_nodes.append(imass[e] + s * (d / K))
+            w_nodes.append(d / K / Q)
+    m_nodes, w_nodes = np.array(m_nodes), np.array(w_nodes)
+    n = len(cl["mass1"])
+    sig = np.asarray(cl["sigma"]); used = sig > 0
+    var = np.where(used, sig ** 2, 1.0)
+    out = np.full(n, -np.inf)
+    lpm = log_prior_mass(m_nodes, pack_d["m_wd_up"]) + np.log(w_nodes)
+    terms = []
+    for j in range(Q):
+        q = np.full(len(m_nodes), j / Q)
+        pred = synth.forward_mags(pack_d, par, m_nodes, q, np.zeros(len(m_nodes), int), pop=pop)      # [nodes, nf]
+        terms.append(pred)
+    for i in range(n):
+        acc = []
+        for pred in terms:
+            g = np.where(used[i], -0.5 * (np.log(2 * np.pi * var[i]) + (pred - cl["obs"][i]) ** 2 / var[i]), 0.0).sum(axis=1)
+            acc.append(lpm + g)
+        out[i] = logsumexp(np.concatenate(acc))
+    return out

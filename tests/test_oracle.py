@@ -165,3 +165,18 @@ def test_priors():
     dens = np.exp([lib.b9o_log_prior_mass(lib.b9o_log_mass_norm(8.0), float(x)) for x in m[::400]])
     from scipy.integrate import simpson
     assert abs(simpson(dens, x=m[::400]) - 1.0) < 2e-3
+
+
+def test_marginalised_mode_matches_numpy_brute_force():
+    """Third opinion on the marginalised integral (MS/RGB-stage stars): numpy brute force vs the oracle."""
+    pack_d, cl, pack, stars, priors, _ = build_problem("parsec", 5, n_stars=12, n_feh=3, n_age=4, n_eep=25)
+    K, Q = 2, 3
+    orc = oracle.Oracle(pack, stars, priors, abi.make_options(abi.MODE_MARGINALISED, 1, K, Q))
+    par = cl["truth"]
+    lp, ps = orc.logpost(par[None, :], perstar=True)
+    ll = numpy_ref.marg_perstar(pack_d, cl, par, K, Q)
+    log_fs = -np.sum(np.log(cl["filter_prior_max"] - cl["filter_prior_min"]))
+    pm = cl["clust_prior"]
+    from scipy.special import logsumexp
+    want = logsumexp(np.stack([np.log1p(-pm) + log_fs, np.log(pm) + ll]), axis=0)
+    np.testing.assert_allclose(ps[0], want, rtol=1e-9, atol=1e-8)
