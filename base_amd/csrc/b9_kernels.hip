@@ -899,7 +899,11 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         }
         STAMP(5);
         if (binary) {
+#ifdef B9_COMBINE_UNROLL
+#pragma unroll B9_COMBINE_UNROLL
+#else
 #pragma unroll
+#endif
             for (int j = 0; j < NFP / 2; ++j) {
                 const double s0 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].x, a2[NFP / 2 + j].x, t2);
                 const double s1 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].y, a2[NFP / 2 + j].y, t2);
