@@ -158,18 +158,26 @@ class WalkerSampler:
         self.step = 0
         self.accepted = 0
         self._gather = all_gather
+        self._pending = None                          # (gather in flight, its block length)
         # pooled running sums over all walkers and all blocks, about the common origin x0
         self.x0 = start[:, self.free].mean(axis=0)
         self.n_mom, self.s1, self.s2 = 0.0, np.zeros(self.d), np.zeros((self.d, self.d))
 
     # -- collectives ------------------------------------------------------------------------
     def gather_rows(self, rows: np.ndarray) -> np.ndarray:
-        """rows[per, k] on every rank -> [n_walkers, k] in walker order."""
+        """rows[per, k] on every rank -> [n_walkers, k] in walker order (blocking)."""
+        return self._finish_gather(self._start_gather(rows))
+
+    def _start_gather(self, rows: np.ndarray):
         if self._gather is None:
             if self.world != 1:
                 raise ValueError("more than one rank needs an all_gather")
             return rows.copy()
-        return self._gather(rows)
+        start = getattr(self._gather, "start", None)
+        return start(rows) if start else self._gather(rows)
+
+    def _finish_gather(self, pending) -> np.ndarray:
+        return pending.wait() if hasattr(pending, "wait") else pending
 
     # -- driver -----------------------------------------------------------------------------
     def initialise(self, evaluate: Callable[[np.ndarray], np.ndarray]) -> None:
@@ -191,7 +199,17 @@ class WalkerSampler:
         row = np.concatenate([self.logpost[:, None], self.params, moved[:, None].astype(np.float64),
                               np.full((self.per, 1), float(n)), x.sum(axis=0),
                               np.einsum("swi,swj->wij", x, x).reshape(self.per, -1)], axis=1)
-        rows = self.gather_rows(row)                              # THE collective of the block
+        # THE collective of the block is started now and consumed after the NEXT block has run, so its
+        # latency hides behind that block's GPU work: the proposal of block b+1 is adapted from the rows
+        # of blocks <= b-1.  The lag is the same for every rank count (also for one rank), so chains
+        # stay bit-identical however the walkers are sharded.
+        previous, self._pending = self._pending, (self._start_gather(row), n)
+        if previous is not None:
+            self._consume(*previous)
+        return samples, lps
+
+    def _consume(self, pending, n: int) -> None:
+        rows = self._finish_gather(pending)
         self.all_logpost = rows[:, 0].copy()
         self.all_params = rows[:, 1:1 + abi.B9_NPARAM].copy()
         if self.adapt:
@@ -200,7 +218,12 @@ class WalkerSampler:
             if n > 4:
                 self.scale *= 0.5 if rate < 0.10 else (0.8 if rate < 0.20 else (1.5 if rate > 0.50 else (1.2 if rate > 0.35 else 1.0)))
             self._adapt(rows[:, 2 + abi.B9_NPARAM:])
-        return samples, lps
+
+    def flush(self) -> None:
+        """Consume the outstanding gather (end of a run): brings all_params / all_logpost up to date."""
+        if self._pending is not None:
+            previous, self._pending = self._pending, None
+            self._consume(*previous)
 
     def _adapt(self, mom: np.ndarray) -> None:
         """Pool the block's per-walker sums (every rank sees the same gathered rows in the same
@@ -228,24 +251,59 @@ class WalkerSampler:
             if record is not None:
                 record.append((samples, lps))
             done += n
+        self.flush()
 
 
 # ------------------------------------------------------------------------------------------
 # torch.distributed plumbing
 # ------------------------------------------------------------------------------------------
+class _PendingGather:
+    def __init__(self, work, out, host=None):
+        self.work, self.out, self.host = work, out, host
+
+    def wait(self) -> np.ndarray:
+        self.work.wait()
+        if self.host is None:
+            return self.out.cpu().numpy()
+        self.host.copy_(self.out, non_blocking=True)      # pinned: no staging copy, one stream sync
+        import torch
+        torch.cuda.current_stream().synchronize()
+        return self.host.numpy().copy()
+
+
 def torch_all_gather(device: Optional[str] = None) -> Callable[[np.ndarray], np.ndarray]:
     """all-gather of equally shaped float64 rows through torch.distributed (nccl = RCCL on a
-    GPU build, gloo on CPU).  With `device` the rows travel through a device tensor."""
+    GPU build, gloo on CPU).  With `device` the rows travel through a device tensor (pinned host
+    staging and device buffers are allocated once per row shape).  The returned callable is
+    blocking; its `.start(rows)` attribute launches the collective asynchronously and returns an
+    object whose `.wait()` yields the gathered array."""
     import torch
     import torch.distributed as dist
+    bufs = {}
+
+    def start(rows: np.ndarray) -> _PendingGather:
+        world = dist.get_world_size()
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        if not device:
+            t = torch.from_numpy(rows)
+            out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype)
+            return _PendingGather(dist.all_gather_into_tensor(out, t, async_op=True), out)
+        key = rows.shape
+        if key not in bufs:      # two sets: a gather may still be in flight when the next one starts
+            bufs[key] = [dict(h_in=torch.empty(key, dtype=torch.float64).pin_memory(),
+                              d_in=torch.empty(key, dtype=torch.float64, device=device),
+                              d_out=torch.empty((world * key[0], key[1]), dtype=torch.float64, device=device),
+                              h_out=torch.empty((world * key[0], key[1]), dtype=torch.float64).pin_memory())
+                         for _ in range(2)] + [0]
+        sets = bufs[key]
+        b = sets[sets[2]]
+        sets[2] ^= 1
+        b["h_in"].numpy()[:] = rows
+        b["d_in"].copy_(b["h_in"], non_blocking=True)
+        return _PendingGather(dist.all_gather_into_tensor(b["d_out"], b["d_in"], async_op=True), b["d_out"], b["h_out"])
 
     def gather(rows: np.ndarray) -> np.ndarray:
-        world = dist.get_world_size()
-        t = torch.from_numpy(np.ascontiguousarray(rows))
-        if device:
-            t = t.to(device)
-        out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy()
+        return start(rows).wait()
 
+    gather.start = start
     return gather
