@@ -469,6 +469,20 @@ const char *param_name(int idx)
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// multiplicative update of the global step scale from a block's acceptance rate (target 0.2-0.35;
+// far from it the correction is strong, so a badly scaled start is repaired within a few blocks)
+double step_scale_factor(double rate)
+{
+    if (rate < 0.02) return 0.2;
+    if (rate < 0.10) return 0.5;
+    if (rate < 0.20) return 0.8;
+    if (rate > 0.90) return 4.0;
+    if (rate > 0.70) return 2.0;
+    if (rate > 0.50) return 1.5;
+    if (rate > 0.35) return 1.2;
+    return 1.0;
+}
+
 bool cholesky(std::vector<double> &a, int d)      // in place, lower; false if not positive definite
 {
     for (int j = 0; j < d; ++j) {
@@ -502,6 +516,8 @@ McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double
     std::vector<int32_t> ids(W);
     for (int w = 0; w < W; ++w) ids[w] = w;
     double scale = 1.0, n_mom = 0.0;
+    bool shaped = false;
+    constexpr double kForget = 0.9;
     std::vector<double> mean(d, 0.0), m2((size_t)d * d, 0.0);
     McmcResult res;
     const long total = cfg.burn_iter + cfg.run_iter;
@@ -532,6 +548,10 @@ McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double
             }
         // adaptation (burn-in only, as the reference freezes the proposal for the main run [RECALL])
         if (burning) {
+            // exponentially forgotten moments (window ~ 1/(1-kForget) blocks): the start-up transient and the
+            // part of a degeneracy ridge the chain has already left stop shaping the proposal
+            n_mom *= kForget;
+            for (double &v : m2) v *= kForget;
             for (int s = 0; s < n; ++s) for (int w = 0; w < W; ++w) {
                 const double *x = &samples[((size_t)s * W + w) * d];
                 n_mom += 1.0;
@@ -540,12 +560,33 @@ McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double
                 for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) m2[i * d + j] += dl[i] * (x[j] - mean[j]);
             }
             const double rate = (double)blk.n_accept / ((double)n * W);
-            scale *= rate < 0.10 ? 0.5 : (rate < 0.20 ? 0.8 : (rate > 0.50 ? 1.5 : (rate > 0.35 ? 1.2 : 1.0)));
+            scale *= step_scale_factor(rate);
             if (n_mom > 20.0 * d) {
                 std::vector<double> cov((size_t)d * d);
                 for (int i = 0; i < d * d; ++i) cov[i] = m2[i] / (n_mom - 1.0) * (2.38 * 2.38 / d);
-                for (int i = 0; i < d; ++i) { double sd = std::sqrt(std::max(cov[i * d + i], 1e-300)); cov[i * d + i] += 1e-12 * sd * sd + 1e-300; }
-                if (cholesky(cov, d)) chol = cov;
+                // A chain that has hardly moved yet (bad starting scale) has a collapsed sample covariance:
+                // adopting it would freeze the sampler.  Only take it once no direction is more than
+                // 100x narrower than the current (scaled) proposal already is.
+                bool usable = true;
+                for (int i = 0; i < d; ++i) {
+                    double cur = 0.0;
+                    for (int j = 0; j <= i; ++j) cur += chol[i * d + j] * chol[i * d + j];
+                    if (!(cov[i * d + i] > 1e-4 * scale * scale * cur)) usable = false;
+                }
+                if (usable) {
+                    for (int i = 0; i < d; ++i) cov[i * d + i] *= 1.0 + 1e-9;
+                    if (cholesky(cov, d)) {
+                        if (!shaped) {
+                            // first switch from the diagonal start-up steps to a learnt shape: keep the volume of
+                            // the scaled proposal (the acceptance-tuned size carries over, only the shape changes)
+                            double lr = 0.0;
+                            for (int i = 0; i < d; ++i) lr += std::log(chol[i * d + i]) - std::log(cov[i * d + i]);
+                            scale *= std::exp(lr / d);
+                            shaped = true;
+                        }
+                        chol = cov;                          // `scale` keeps multiplying it and keeps adapting
+                    }
+                }
             }
         }
         done += n;

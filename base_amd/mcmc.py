@@ -129,6 +129,9 @@ class DeviceBlockRunner:
         return self.engine.mcmc_run_block(params, logpost, walker_ids, free, chol, seed, step0, n_steps, self.record)
 
 
+FORGET = 0.9          # per-block forgetting factor of the pooled adaptation moments
+
+
 class WalkerSampler:
     """W walkers sharded over `world` ranks; one all-gather per adaptation block."""
 
@@ -162,6 +165,7 @@ class WalkerSampler:
         # pooled running sums over all walkers and all blocks, about the common origin x0
         self.x0 = start[:, self.free].mean(axis=0)
         self.n_mom, self.s1, self.s2 = 0.0, np.zeros(self.d), np.zeros((self.d, self.d))
+        self._shaped = False                          # True once a learnt covariance has replaced the diagonal steps
 
     # -- collectives ------------------------------------------------------------------------
     def gather_rows(self, rows: np.ndarray) -> np.ndarray:
@@ -216,7 +220,7 @@ class WalkerSampler:
             # pooled fraction of steps (after the block's first) on which a walker moved
             rate = rows[:, 1 + abi.B9_NPARAM].sum() / max(1.0, self.n_walkers * (n - 1.0))
             if n > 4:
-                self.scale *= 0.5 if rate < 0.10 else (0.8 if rate < 0.20 else (1.5 if rate > 0.50 else (1.2 if rate > 0.35 else 1.0)))
+                self.scale *= step_scale_factor(rate)
             self._adapt(rows[:, 2 + abi.B9_NPARAM:])
 
     def flush(self) -> None:
@@ -230,18 +234,29 @@ class WalkerSampler:
         order, so every rank derives the same proposal factor).  O(1) numpy calls per block,
         whatever the number of walkers."""
         d = self.d
-        self.n_mom += float(mom[:, 0].sum())
-        self.s1 += mom[:, 1:1 + d].sum(axis=0)
-        self.s2 += mom[:, 1 + d:].sum(axis=0).reshape(d, d)
+        # exponentially forgotten sums (window ~ 1/(1-FORGET) blocks): the start-up transient and the part
+        # of a degeneracy ridge the ensemble has already left stop shaping the proposal
+        self.n_mom = FORGET * self.n_mom + float(mom[:, 0].sum())
+        self.s1 = FORGET * self.s1 + mom[:, 1:1 + d].sum(axis=0)
+        self.s2 = FORGET * self.s2 + mom[:, 1 + d:].sum(axis=0).reshape(d, d)
         if self.n_mom > 20 * d:
             mean = self.s1 / self.n_mom
             cov = (self.s2 - self.n_mom * np.outer(mean, mean)) / (self.n_mom - 1) * (2.38 ** 2 / d)
-            scale = np.sqrt(np.maximum(np.diag(cov), 1e-300))
-            cov = cov + np.diag((1e-6 * scale) ** 2)              # keep it positive definite
-            try:
-                self.chol = np.linalg.cholesky(cov)
-            except np.linalg.LinAlgError:
-                pass
+            # A chain that has hardly moved yet (bad starting scale) has a collapsed sample covariance:
+            # adopting it would freeze the sampler.  Only take it once no direction is more than 100x
+            # narrower than the current (scaled) proposal already is.  Same rule as the C++ driver.
+            cur = self.scale ** 2 * np.einsum("ij,ij->i", self.chol, self.chol)
+            if np.all(np.diag(cov) > 1e-4 * cur):
+                try:
+                    new = np.linalg.cholesky(cov * (1.0 + 1e-9 * np.eye(d)))
+                except np.linalg.LinAlgError:
+                    return
+                if not self._shaped:
+                    # first switch from the diagonal start-up steps to a learnt shape: keep the volume of
+                    # the scaled proposal (the acceptance-tuned size carries over, only the shape changes)
+                    self.scale *= float(np.exp(np.mean(np.log(np.diag(self.chol)) - np.log(np.diag(new)))))
+                    self._shaped = True
+                self.chol = new                                      # `scale` keeps multiplying it
 
     def run(self, n_steps: int, record: Optional[List] = None) -> None:
         done = 0
@@ -257,6 +272,19 @@ class WalkerSampler:
 # ------------------------------------------------------------------------------------------
 # torch.distributed plumbing
 # ------------------------------------------------------------------------------------------
+def step_scale_factor(rate: float) -> float:
+    """Multiplicative update of the global step scale from a block's acceptance rate (target
+    0.2-0.35; far from it the correction is strong).  Same rule as the C++ driver (b9host.cpp)."""
+    if rate < 0.02: return 0.2
+    if rate < 0.10: return 0.5
+    if rate < 0.20: return 0.8
+    if rate > 0.90: return 4.0
+    if rate > 0.70: return 2.0
+    if rate > 0.50: return 1.5
+    if rate > 0.35: return 1.2
+    return 1.0
+
+
 class _PendingGather:
     def __init__(self, work, out, host=None):
         self.work, self.out, self.host = work, out, host
