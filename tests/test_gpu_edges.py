@@ -129,3 +129,42 @@ def test_mcmc_block_argument_errors_and_zero_steps():
     one = eng.mcmc_run_block(start, lp, np.arange(2), np.array([0, 2]), np.eye(2) * 1e-3, 1, 0, 1)
     two = eng.mcmc_run_block(start, lp, np.arange(2), np.array([0, 2]), np.eye(2) * 1e-3, 1, 0, 2)
     np.testing.assert_array_equal(one[2][0], two[2][0])        # the first step does not depend on the block length
+
+
+@pytest.mark.parametrize("name,n_filt,n_y,n_pops", [("girardi", 3, 1, 1), ("dsed", 5, 3, 2)])
+def test_parameters_exactly_on_grid_nodes_and_edges(name, n_filt, n_y, n_pops):
+    """Bracket conventions bite when a cluster parameter equals a grid node (first, interior, last) or a
+    star's mass equals an isochrone node: the HIP path must agree with the oracle there too, including
+    on which side of the support (-inf) each edge falls."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem(name, n_filt, n_stars=200, wd_frac=0.1, n_y=n_y, n_pops=n_pops, seed=8)
+    la, fe, yy = pack_d["log_age"], pack_d["feh"], pack_d["y"]
+    rows = []
+    for a in (la[0], la[1], la[len(la) // 2], la[-2], la[-1], np.nextafter(la[-1], 0), np.nextafter(la[0], 99),
+              np.nextafter(la[-1], 99), np.nextafter(la[0], 0)):
+        for f in (fe[0], fe[1], fe[-1], np.nextafter(fe[-1], -99), np.nextafter(fe[0], 99), np.nextafter(fe[-1], 99), np.nextafter(fe[0], -99)):
+            for y in (yy[0], yy[-1], yy[len(yy) // 2]):
+                p = cl["truth"].copy()
+                p[abi.P_LOGAGE], p[abi.P_FEH], p[abi.P_Y], p[abi.P_Y2] = a, f, y, yy[-1 if n_pops == 2 else 0]
+                rows.append(p)
+    params = np.array(rows)
+    pr = abi.make_priors(log_age_min=la[0] - 1.0, log_age_max=la[-1] + 1.0)        # let the GRID decide the support
+    eng = engine.Engine(pack, stars, pr, options)
+    orc = oracle.Oracle(pack, stars, pr, options)
+    got, want = eng.logpost(params, perstar=True), orc.logpost(params, perstar=True)
+    assert np.array_equal(np.isfinite(got[0]), np.isfinite(want[0]))
+    assert np.isfinite(want[0]).sum() >= len(rows) // 3 and (~np.isfinite(want[0])).sum() >= 1
+    assert _err(got[1], want[1]) <= 1e-9 and _err(got[0], want[0]) <= 1e-9
+    # masses exactly on isochrone nodes (and on its two ends)
+    p = cl["truth"].copy()
+    first, mass, _, tip = orc.derive_isochrone(p)
+    cl2 = dict(cl)
+    m = np.asarray(cl["mass1"]).copy()
+    k = min(len(m), len(mass))
+    m[:k] = mass[np.linspace(0, len(mass) - 1, k).astype(int)]
+    cl2["mass1"] = m
+    st2 = abi.make_stars(cl2)
+    eng2 = engine.Engine(pack, st2, priors, options)
+    got = eng2.logpost(p[None, :], perstar=True)
+    want = oracle.Oracle(pack, st2, priors, options).logpost(p[None, :], perstar=True)
+    assert _err(got[1], want[1]) <= 1e-9 and _err(got[0], want[0]) <= 1e-9
