@@ -58,11 +58,16 @@ struct b9_ctx {
     double *d_params = nullptr, *d_logpost = nullptr, *d_perstar = nullptr;
     size_t perstar_cap = 0;
     void *d_mcmc = nullptr;          // device state of b9_mcmc_run_block
-    size_t mcmc_cap = 0;
+    void *h_stage = nullptr;         // its pinned host mirror (fused sampler step: one upload, one download per block)
+    size_t mcmc_cap = 0, stage_cap = 0;
 
     // launch plan
     int tiles_per_block = 0;   // 0 = auto
     int walkers_per_lane = 1;  // WB template parameter of k_star_like (1 or 2)
+    int derive_parts = 0;      // fused sampler step: workgroups per candidate isochrone (0 = one value per thread)
+    int derive_order = 0;      // fused sampler step: >= 0 derivation workgroups lead the grid, < 0 they trail it (B9_DERIVE_ORDER)
+    int dbg_step = 0;          // B9_DBG_STEP: timing experiments on the fused step (bit 0: no decision, bit 1: no derivation)
+    bool two_launch_steps = false;   // B9_TWO_LAUNCH_STEPS=1: the derive + star launch pair per step also in given-mass mode
 
     // timing of the dominant kernel
     int timing = 0;            // 0 off, n > 0: bracket every n-th launch of the dominant kernel with events
@@ -233,11 +238,11 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
         int cw = std::max(n_walkers, ctx->cap_walkers), cp = std::max(n_pops, ctx->cap_pops);
         ctx->mass_cap = (ctx->pk.max_eep + 1) & ~1;
         ctx->iso_stride = (long long)ctx->mass_cap * (ctx->pk.nfp + 1);
-        // two sets (ping-pong): the device sampler's k_derive_iso of step t+1 writes that step's proposal
-        // and isochrones while it still reads step t's headers and proposal to finish step t
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_hdr, sizeof(IsoHdr) * cw * cp * 2));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_iso, sizeof(double) * (size_t)ctx->iso_stride * cw * cp * 2));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_params, sizeof(double) * B9_NPARAM * cw * 2));
+        // four sets: the two-launch sampler (marginalised mode) ping-pongs between sets 0 and 1; the fused
+        // sampler step (given-mass mode) keeps two candidates for each of two step parities (StepDev)
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_hdr, sizeof(IsoHdr) * cw * cp * 4));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_iso, sizeof(double) * (size_t)ctx->iso_stride * cw * cp * 4));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_params, sizeof(double) * B9_NPARAM * cw * 4));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_logpost, sizeof(double) * cw));
         ctx->cap_walkers = cw; ctx->cap_pops = cp;
     }
@@ -259,6 +264,8 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
     return B9_OK;
 }
 
+#define B9_HEAVY_PARTS 4        // workgroups per walker for the stars above the AGB tip
+
 struct Plan { int tiles_per_block, n_groups; };
 
 Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
@@ -277,6 +284,39 @@ Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
     p.tiles_per_block = tpb;
     p.n_groups = (n_tiles + tpb - 1) / tpb;
     return p;
+}
+
+// Launch plan of the fused sampler step.  The launch has three kinds of workgroups (heavy-star, candidate
+// derivation, hot); it is fastest when ALL of them are resident at once -- one occupancy round, every
+// workgroup takes the previous step's decision exactly once -- so tiles_per_block is the smallest value
+// that lets the hot workgroups fill <= 70 % of the slots, and the derivation is cut into as many
+// parts as the remaining slots allow (measured on the 50k x 8 x 8 bench shape: 3 tiles per workgroup and 8
+// parts give 21.8 us per step; 1 tile / 15 parts 26.0 us; 4 tiles 25.6 us).
+struct StepPlan { Plan plan; int derive_parts; };
+
+StepPlan make_step_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
+{
+    StepPlan sp;
+    const int n_tiles = ctx->st.n_pad / 256;
+    const int full_parts = (ctx->mass_cap * (ctx->pk.nfp + 1) + 255) / 256;
+    const int slots = 256 * (n_pops == 2 ? 2 : 3);              // workgroups resident on 256 CUs (k_mcmc_step's launch bounds)
+    int tpb = ctx->tiles_per_block;
+    if (tpb <= 0) {
+        tpb = 1;
+        while (tpb < 8 && (long long)((n_tiles + tpb - 1) / tpb) * n_walkers > (long long)(0.7 * slots)) ++tpb;
+        if ((long long)((n_tiles + tpb - 1) / tpb) * n_walkers > slots)       // several rounds anyway: the plain rule
+            tpb = (int)std::max<long long>(1, std::min<long long>(8, (long long)n_tiles * n_walkers / 4096));
+    }
+    tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
+    sp.plan.tiles_per_block = tpb;
+    sp.plan.n_groups = (n_tiles + tpb - 1) / tpb;
+    int parts = ctx->derive_parts;
+    if (parts <= 0) {
+        const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_groups * n_walkers - (long long)n_walkers * B9_HEAVY_PARTS;
+        parts = (int)std::max<long long>(2, room / ((long long)n_walkers * 2 * n_pops));
+    }
+    sp.derive_parts = std::max(1, std::min(parts, full_parts));
+    return sp;
 }
 
 }  // namespace
@@ -310,6 +350,10 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     ctx->pr.log_age_min = -INFINITY; ctx->pr.log_age_max = INFINITY;
     if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
     if (const char *s = getenv("B9_WALKERS_PER_LANE")) ctx->walkers_per_lane = atoi(s) >= 2 ? 2 : 1;
+    if (const char *s = getenv("B9_DERIVE_PARTS")) ctx->derive_parts = atoi(s);
+    if (const char *s = getenv("B9_DERIVE_ORDER")) ctx->derive_order = atoi(s);
+    if (const char *s = getenv("B9_DBG_STEP")) ctx->dbg_step = atoi(s);
+    if (const char *s = getenv("B9_TWO_LAUNCH_STEPS")) ctx->two_launch_steps = atoi(s) != 0;
     *out = ctx;
     return B9_OK;
 }
@@ -323,6 +367,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
     free_all(ctx->star_allocs);
     void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_mcmc};
     for (void *p : bufs) if (p) (void)hipFree(p);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -458,8 +503,6 @@ int b9_set_options(b9_ctx *ctx, const b9_options *o)
     return B9_OK;
 }
 
-#define B9_HEAVY_PARTS 4        // workgroups per walker for the stars above the AGB tip
-
 struct Bufs { double *params; IsoHdr *hdr; double *iso; };
 
 // ping-pong work-buffer set (0 / 1)
@@ -548,6 +591,139 @@ int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, do
     return launch_logpost(ctx, const_cast<double *>(d_params), n_walkers, d_logpost, d_perstar, stream);
 }
 
+// event bracket of the dominant kernel's launch, every ctx->timing-th launch
+static int timing_begin(b9_ctx *ctx, hipStream_t stream, long *slot)
+{
+    *slot = -1;
+    if (!(ctx->timing > 0 && (ctx->launch_no++ % (unsigned)ctx->timing) == 0)) return B9_OK;
+    if (ctx->ev_used == ctx->ev_start.size()) {
+        hipEvent_t a, b;
+        HIPCHK(ctx, hipEventCreate(&a));
+        HIPCHK(ctx, hipEventCreate(&b));
+        ctx->ev_start.push_back(a); ctx->ev_stop.push_back(b);
+    }
+    *slot = (long)ctx->ev_used++;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_start[*slot], stream));
+    return B9_OK;
+}
+
+static int timing_end(b9_ctx *ctx, hipStream_t stream, long slot)
+{
+    if (slot >= 0) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
+    return B9_OK;
+}
+
+/* Device-resident Metropolis block, given-mass mode: ONE launch per step (StepDev in b9_device.h).
+ * Launch sequence for S steps:  D0  K(0) K(1) ... K(S-1)  F
+ *   D0   = k_derive_iso: draws step 0's proposal from the starting state and derives its isochrones
+ *   K(t) = k_mcmc_step: decision of step t-1, star likelihood of step t's proposal, and -- on a few
+ *          extra workgroups -- both candidate isochrone sets of step t+1
+ *   F    = k_mcmc_finish: decision of step S-1. */
+static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
+{
+    const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps, n_pops = ctx->opt.n_pops;
+    const StepPlan sp = make_step_plan(ctx, W, n_pops);
+    const Plan &plan = sp.plan;
+    const int derive_parts = sp.derive_parts;
+    const size_t n_state = (size_t)W * B9_STATE_STRIDE, n_cur = (size_t)W * B9_NPARAM,
+                 n_samp = blk->samples ? (size_t)S * W * d : 0, n_lps = blk->lps ? (size_t)S * W : 0;
+    // One device allocation, laid out so that the block needs ONE upload and ONE download (each small
+    // pageable copy costs 10-20 us of host time, a block used to make six + four of them):
+    //   [cur0][lp0][chol][decided][free, ids][n_acc][state 0] | [state 1][samples][lps]
+    //   upload   = cur0 .. state 0        (starting state, proposal factor, RNG streams, cleared counters)
+    //   download = n_acc .. lps           (acceptance count, both state parities, chain record)
+    const size_t n_int = ((size_t)(d + W) + 1) / 2;                       // ints, in units of 8 bytes
+    const size_t o_cur0 = 0, o_lp0 = o_cur0 + n_cur, o_chol = o_lp0 + W, o_dec = o_chol + (size_t)d * d,
+                 o_int = o_dec + W, o_nacc = o_int + n_int, o_st0 = o_nacc + 1, o_st1 = o_st0 + n_state,
+                 o_samp = o_st1 + n_state, o_lps = o_samp + n_samp, n_total = o_lps + n_lps;
+    const size_t up_words = o_st1, down_words = n_total - o_nacc;
+    if (n_total * 8 > ctx->mcmc_cap) {
+        if (ctx->d_mcmc) (void)hipFree(ctx->d_mcmc);
+        ctx->d_mcmc = nullptr; ctx->mcmc_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_mcmc, n_total * 8));
+        ctx->mcmc_cap = n_total * 8;
+    }
+    if (n_total * 8 > ctx->stage_cap) {
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr; ctx->stage_cap = 0;
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, n_total * 8, hipHostMallocDefault));    // pinned staging mirror
+        ctx->stage_cap = n_total * 8;
+    }
+    double *const dev = static_cast<double *>(ctx->d_mcmc), *const stage = static_cast<double *>(ctx->h_stage);
+    double *d_state = dev + o_st0;                   // [2][W][stride]; the block's first launch has parity 1 and reads parity 0
+    double *d_cur0 = dev + o_cur0, *d_lp0 = dev + o_lp0, *d_chol = dev + o_chol;
+    unsigned long long *d_decided = reinterpret_cast<unsigned long long *>(dev + o_dec);
+    int *d_free = reinterpret_cast<int *>(dev + o_int), *d_ids = d_free + d;
+    unsigned long long *d_nacc = reinterpret_cast<unsigned long long *>(dev + o_nacc);
+    double *d_samples = n_samp ? dev + o_samp : nullptr, *d_lps = n_lps ? dev + o_lps : nullptr;
+    hipStream_t s = ctx->stream;
+    {
+        std::memcpy(stage + o_cur0, blk->params, n_cur * 8);
+        std::memcpy(stage + o_lp0, blk->logpost, (size_t)W * 8);
+        std::memcpy(stage + o_chol, blk->chol, (size_t)d * d * 8);
+        std::memset(stage + o_dec, 0xFF, (size_t)W * 8);                 // no step published yet
+        int *hi = reinterpret_cast<int *>(stage + o_int);
+        std::memcpy(hi, blk->free_idx, d * sizeof(int));
+        std::memcpy(hi + d, blk->walker_ids, W * sizeof(int));
+        std::memset(stage + o_nacc, 0, 8);
+        double *st1 = stage + o_st0;                                      // starting state -> parity 0, which K(0) (parity 1) reads
+        std::memset(st1, 0, n_state * 8);
+        for (int w = 0; w < W; ++w) {
+            std::memcpy(st1 + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, blk->params + (size_t)w * B9_NPARAM, sizeof(double) * B9_NPARAM);
+            st1[(size_t)w * B9_STATE_STRIDE + B9_ST_LP] = blk->logpost[w];
+            st1[(size_t)w * B9_STATE_STRIDE + B9_ST_LPRIOR] = -INFINITY;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(dev, stage, up_words * 8, hipMemcpyHostToDevice, s));
+    }
+    StepDev sd{};
+    sd.d = d; sd.n_walkers = W; sd.n_pops = n_pops;
+    sd.n_partial = partial_count(ctx, plan); sd.mass_cap = ctx->mass_cap;
+    sd.k0 = (unsigned)(blk->seed & 0xFFFFFFFFull); sd.k1 = (unsigned)(blk->seed >> 32);
+    sd.partial_stride = ctx->st.n_pad; sd.iso_stride = ctx->iso_stride;
+    sd.state = d_state; sd.partial = ctx->d_partial;
+    sd.cand_par = ctx->d_params; sd.cand_hdr = ctx->d_hdr; sd.cand_iso = ctx->d_iso;
+    sd.chol = d_chol; sd.free_idx = d_free; sd.walker_ids = d_ids;
+    sd.samples = d_samples; sd.lps = d_lps; sd.n_acc = d_nacc; sd.decided = d_decided;
+    if (2 * (long long)sd.n_partial > sd.partial_stride) return fail(ctx, B9_ERR_CAPACITY, "partial buffer too small for two parities");
+    {   // D0: proposal of step 0 and its isochrones -> candidate 0 of parity 1 (K(t) has parity (t + 1) & 1)
+        McmcDev mc{};
+        mc.enabled = 1; mc.d = d; mc.n_walkers = W; mc.has_prev = 0; mc.pin = 0; mc.row = 0;
+        mc.cur = d_cur0; mc.lp_cur = d_lp0; mc.chol = d_chol; mc.free_idx = d_free; mc.walker_ids = d_ids;
+        mc.k0 = sd.k0; mc.k1 = sd.k1; mc.step = (unsigned long long)blk->step0; mc.n_acc = d_nacc;
+        const size_t rows = (size_t)W * n_pops, c10 = 2;     // (parity 1, candidate 0)
+        HIPCHK(ctx, b9k_derive_iso(ctx->pk, sd.cand_par + c10 * W * B9_NPARAM, W, n_pops, sd.cand_hdr + c10 * rows,
+                                   sd.cand_iso + c10 * rows * ctx->iso_stride, ctx->iso_stride, ctx->mass_cap,
+                                   mc, ctx->pr, B9Prev{nullptr, 0, 0, nullptr, nullptr}, s));
+    }
+    for (int t = 0; t < S; ++t) {
+        sd.set = (t + 1) & 1; sd.has_prev = t > 0; sd.derive_next = t + 1 < S; sd.row = t - 1;
+        sd.step = (unsigned long long)(blk->step0 + t);
+        if (ctx->dbg_step & 1) sd.has_prev = 0;            // timing experiments only (the chain is then wrong)
+        if (ctx->dbg_step & 2) sd.derive_next = 0;
+        long slot;
+        int rc = timing_begin(ctx, s, &slot);
+        if (rc) return rc;
+        HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, plan.tiles_per_block, plan.n_groups, B9_HEAVY_PARTS, derive_parts, ctx->derive_order, s));
+        if ((rc = timing_end(ctx, s, slot))) return rc;
+    }
+    sd.set = (S + 1) & 1; sd.has_prev = 1; sd.derive_next = 0; sd.row = S - 1;
+    sd.step = (unsigned long long)(blk->step0 + S);
+    HIPCHK(ctx, b9k_mcmc_finish(ctx->pk, sd, ctx->pr, s));
+    HIPCHK(ctx, hipMemcpyAsync(stage + o_nacc, dev + o_nacc, down_words * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    const double *fin = stage + (((S + 1) & 1) ? o_st1 : o_st0);
+    for (int w = 0; w < W; ++w) {
+        std::memcpy(blk->params + (size_t)w * B9_NPARAM, fin + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, sizeof(double) * B9_NPARAM);
+        blk->logpost[w] = fin[(size_t)w * B9_STATE_STRIDE + B9_ST_LP];
+    }
+    if (n_samp) std::memcpy(blk->samples, stage + o_samp, n_samp * 8);
+    if (n_lps) std::memcpy(blk->lps, stage + o_lps, n_lps * 8);
+    unsigned long long n_acc;
+    std::memcpy(&n_acc, stage + o_nacc, 8);
+    blk->n_accept = (int64_t)n_acc;
+    return B9_OK;
+}
+
 /* Device-resident Metropolis block (the caller of the hot path).
  * Launch sequence for S steps:  D(0) L(0)  D(1) L(1)  ...  D(S-1) L(S-1)  F
  *   D(t) = k_derive_iso: finishes step t-1 (sum + prior + accept; t > 0), proposes step t, derives
@@ -567,6 +743,8 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     const Plan plan = make_plan(ctx, W, n_pops);
     rc = ensure_capacity(ctx, W, n_pops, (size_t)ctx->st.n_pad * W, false);
     if (rc) return rc;
+    if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) return run_block_fused(ctx, blk);
+    // marginalised mode (and B9_TWO_LAUNCH_STEPS=1): two launches per step
     // one device allocation for the block's state
     const size_t n_cur = (size_t)W * B9_NPARAM, n_samp = blk->samples ? (size_t)S * W * d : 0,
                  n_lps = blk->lps ? (size_t)S * W : 0;

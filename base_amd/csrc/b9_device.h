@@ -83,3 +83,54 @@ struct McmcDev {
     double *lps;                     // [n_steps][W] or null
     unsigned long long *n_acc;       // accepted proposals
 };
+
+// ------------------------------------------------------------------------------------------
+// Fused sampler step (given-mass mode): ONE launch per MCMC step.
+//
+// Launch K(t) evaluates the proposal of step t.  Every workgroup first takes -- redundantly, with
+// identical bits -- the accept/reject decision of step t-1 from that step's partial sums; the star
+// workgroups then evaluate step t's proposal, and a few extra workgroups derive, speculatively,
+// BOTH candidate isochrone sets of step t+1 (proposal drawn from the state if step t is rejected /
+// from step t's proposal if it is accepted; the normals of step t+1 do not depend on the outcome).
+// K(t+1) picks the candidate that matches its own decision.  The chain is the one the sequential
+// algorithm produces (same draws, same sums, same comparisons).
+//
+// Everything ping-pongs on the step's parity `set` = t & 1:
+//   state[set]    written by K(t):   cur_t, lp_t, proposal p_t, its log-prior, which candidate it was
+//   partial[set]  written by K(t):   per-wave partial sums of p_t's star likelihoods
+//   cand[set]     read by K(t):      two candidate (params, headers, isochrones) per walker
+//   cand[set ^ 1] written by K(t):   the candidates of step t+1
+// and K(t) reads state[set ^ 1] / partial[set ^ 1] (step t-1) for its decision.
+// ------------------------------------------------------------------------------------------
+#define B9_STATE_STRIDE 32       // doubles per walker and parity:
+#define B9_ST_CUR 0              //   [0..11]  position after the last finished step
+#define B9_ST_LP 12              //   [12]     its log-posterior
+#define B9_ST_PROP 13            //   [13..24] the proposal the writing launch evaluates
+#define B9_ST_LPRIOR 25          //   [25]     log-prior of that proposal; -inf = outside the grid or the prior's support
+#define B9_ST_SEL 26             //   [26]     0 / 1: which candidate that proposal was
+#define B9_ST_LOGU 27            //   [27]     log u of that proposal's accept test (drawn by the writer, so no other workgroup has to)
+
+struct StepDev {
+    int d, n_walkers, n_pops;
+    int has_prev;                    // 0 for the first launch of a block: no decision to take, candidate 0
+    int derive_next;                 // 0 for the launch that only finishes the block's last step
+    int set;                         // parity of the step this launch evaluates
+    int row;                         // chain row the decision of this launch appends (step t-1)
+    int n_partial, mass_cap;
+    unsigned k0, k1;                 // Philox key
+    unsigned long long step;         // global index of the step this launch evaluates
+    long long partial_stride;        // doubles between walkers; the two parities sit partial_stride / 2 apart
+    long long iso_stride;
+    double *state;                   // [2][W][B9_STATE_STRIDE]
+    double *partial;                 // [W][partial_stride]
+    double *cand_par;                // [2 sets][2 candidates][W][12]
+    IsoHdr *cand_hdr;                // [2][2][W * pops]
+    double *cand_iso;                // [2][2][W * pops][iso_stride]
+    const double *chol;              // [d][d]
+    const int *free_idx;             // [d]
+    const int *walker_ids;           // [W]
+    double *samples;                 // [n_steps][W][d] or null
+    double *lps;                     // [n_steps][W] or null
+    unsigned long long *n_acc;
+    unsigned long long *decided;     // [W]: (step << 1 | sel) once this launch's writer has taken walker w's decision
+};

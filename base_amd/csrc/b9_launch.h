@@ -29,5 +29,12 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
                          double *vals, double *perstar, int K, int Q, hipStream_t stream);
 
+// fused sampler step (given-mass mode): decision of step t-1 + stars of step t + candidates of step t+1
+hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr,
+                         int tiles_per_block, int n_groups, int heavy_parts, int derive_parts,
+                         int derive_order /* >= 0: derivation workgroups lead the grid, < 0: they trail it */, hipStream_t stream);
+// the block's last decision only (one workgroup per walker)
+hipError_t b9k_mcmc_finish(const DevPack &pk, const StepDev &sd, const DevPriors &pr, hipStream_t stream);
+
 hipError_t b9k_noop(hipStream_t stream);
 hipError_t b9k_spin(double microseconds, hipStream_t stream);
