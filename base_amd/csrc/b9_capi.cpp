@@ -3,7 +3,7 @@
 // Host side of the hot path: validates and stages the model pack and the stars to HBM once,
 // then turns each b9_logpost call into three stream-ordered launches
 // (k_derive_iso -> k_star_like / k_star_marg -> k_finalize) and each step of b9_mcmc_run_block into
-// two (k_derive_iso, which also finishes the previous step, -> k_star_like).  No CPU fallback
+// ONE (k_mcmc_step, given-mass mode) or two (k_derive_iso -> k_star_marg, marginalised mode).  No CPU fallback
 // exists: without a HIP device b9_ctx_create fails.  See DESIGN.md for the data layout.
 #include "../../include/base9_hip.h"
 #include "b9_device.h"
@@ -724,7 +724,9 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     return B9_OK;
 }
 
-/* Device-resident Metropolis block (the caller of the hot path).
+/* Device-resident Metropolis block (the caller of the hot path).  Given-mass mode
+ * runs the fused one-launch step (run_block_fused above); what follows is the two-launch step of the
+ * marginalised mode.
  * Launch sequence for S steps:  D(0) L(0)  D(1) L(1)  ...  D(S-1) L(S-1)  F
  *   D(t) = k_derive_iso: finishes step t-1 (sum + prior + accept; t > 0), proposes step t, derives
  *   L(t) = star likelihood of step t's proposals;   F = k_finalize: finishes the last step.

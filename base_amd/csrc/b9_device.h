@@ -59,7 +59,8 @@ struct DevPriors {
     double log_age_min, log_age_max;
 };
 
-// Device-resident Metropolis state of the local walkers (b9_mcmc_run_block).  Passed by value;
+// Device-resident Metropolis state of the local walkers (b9_mcmc_run_block), TWO-LAUNCH step (marginalised
+// mode; given-mass mode uses the fused step, StepDev below).  Passed by value;
 // enabled == 0 makes the kernels behave as the plain log-posterior path.
 //
 // State is kept twice (ping-pong): the derive kernel of step t first FINISHES step t-1 -- every

@@ -118,9 +118,9 @@ class HostBlockRunner:
 
 
 class DeviceBlockRunner:
-    """The whole block on the GPU (b9_mcmc_run_block): per step two launches -- [finish the previous
-    step: sum + prior + accept; propose; derive the isochrones] and [star likelihood] -- and no host
-    round trip until the block ends."""
+    """The whole block on the GPU (b9_mcmc_run_block): one launch per step in given-mass mode (the
+    fused step: previous step's accept/reject + this step's star likelihood + both candidate
+    isochrone sets of the next step), two in marginalised mode; no host round trip until the block ends."""
 
     def __init__(self, engine, record: bool = True):
         self.engine, self.record = engine, record

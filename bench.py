@@ -7,13 +7,14 @@ Workload (BASELINE.json metric: "star-likelihood evals/sec ... on synthetic 50k-
 clusters at 1 GPU, with 1/2/4/8-GPU walker-parallel throughput"; configs[2] sharded 8 ways):
 50 000 stars x 8 filters, PARSEC-shaped synthetic pack, 8 walkers per GPU (weak scaling: 64
 walkers at 8 GPUs).  One "step" is one adaptive-Metropolis step of every walker: propose ->
-log-posterior of the rank's walkers -> accept/reject, all on the GPU (two HIP launches per step behind
+log-posterior of the rank's walkers -> accept/reject, all on the GPU (one HIP launch per step behind
 the C ABI, b9_mcmc_run_block); every 100 steps the ranks exchange one RCCL all-gather of
 per-walker rows and re-derive the pooled proposal covariance.  Star data and model tables are
 resident in HBM before the timed region starts.
 
 value     = n_stars x total walkers x K / max-over-ranks wall time   (whole job, all GPUs)
-roofline  = the dominant kernel (k_star_like): algorithmic bytes per launch / its mean launch
+roofline  = the dominant kernel (k_mcmc_step, the fused sampler step: star likelihood of the step's
+            proposal + the previous step's accept/reject + the next step's candidate isochrones): algorithmic bytes per launch / its mean launch
             duration, measured with HIP events on the launch stream inside this run
 cpu_baseline = the CPU oracle ("port"; the reference itself is not mounted)
             timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1)
@@ -104,7 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the HIP-event bracketing of k_star_like")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the HIP-event bracketing of k_mcmc_step")
     args = ap.parse_args()
 
     import torch
@@ -184,7 +185,7 @@ def main():
             if os.path.exists(pth):
                 pm = json.load(open(pth)).get("pmc", {})
                 for kname, c in pm.items():
-                    if kname.startswith("k_star_like") and "hbm_bytes_per_launch" in c:
+                    if kname.startswith("k_mcmc_step") and "hbm_bytes_per_launch" in c:
                         traffic = c["hbm_bytes_per_launch"]
         out = {
             "metric": "star-likelihood evals/sec", "value": evals / dt, "unit": "star-likelihood evals/s",
@@ -200,7 +201,7 @@ def main():
                        "collective": "one all_gather of [logpost, position, moments] rows per 100-step block" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_star_like", "launches_timed": k_n, "timed_every": TIMING_EVERY,
+                         "kernel": "k_mcmc_step", "launches_timed": k_n, "timed_every": TIMING_EVERY,
                          "avg_launch_us": 1e6 * k_avg_s, "empty_kernel_bracket_us": 1e3 * bracket_ms,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_star_eval": bytes_eval},
             "accept_rate": (sampler.accepted - acc0) / float(WALKERS_PER_GPU * args.steps),

@@ -36,6 +36,9 @@ t0 = t[:, 0].min()
 life = t[:, 8] - t[:, 0]
 print(f"{which}: hot waves {len(t)}  span {t[:,8].max()-t0} cycles")
 print("  lifetime mean %.0f p5 %.0f p50 %.0f p95 %.0f" % (life.mean(), *np.percentile(life, [5, 50, 95])))
+if which == "step" and (t[:, 3] > 0).all():
+    for a, b, nm in ((0, 1, "entry -> loads issued (+wait)"), (1, 2, "decision"), (2, 3, "LDS fill + barrier"), (3, 8, "tiles + reduce")):
+        x = t[:, b] - t[:, a]; print(f"    {nm:30s} mean {x.mean():8.0f} p50 {np.median(x):8.0f} p95 {np.percentile(x,95):8.0f}")
 print("  start offsets p5/p25/p50/p75/p95/max", np.percentile(t[:, 0] - t0, [5, 25, 50, 75, 95, 100]).astype(int))
 print("  end   offsets p5/p25/p50/p75/p95/max", np.percentile(t[:, 8] - t0, [5, 25, 50, 75, 95, 100]).astype(int))
 early = t[:, 0] - t0 < np.percentile(t[:, 0] - t0, 40)
