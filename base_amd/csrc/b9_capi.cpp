@@ -304,8 +304,8 @@ StepPlan make_step_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
     if (tpb <= 0) {
         tpb = 1;
         while (tpb < 8 && (long long)((n_tiles + tpb - 1) / tpb) * n_walkers > (long long)(0.7 * slots)) ++tpb;
-        if ((long long)((n_tiles + tpb - 1) / tpb) * n_walkers > slots)       // several rounds anyway: the plain rule
-            tpb = (int)std::max<long long>(1, std::min<long long>(8, (long long)n_tiles * n_walkers / 4096));
+        // (more walkers than one round can hold: 8 tiles per workgroup stays best -- every workgroup pays the
+        //  decision prologue once; measured 44.6 vs 60.2 us at 32 walkers, 83.3 vs 91.4 at 64)
     }
     tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
     sp.plan.tiles_per_block = tpb;
