@@ -292,7 +292,7 @@ Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
 // that lets the hot workgroups fill <= 70 % of the slots, and the derivation is cut into as many
 // parts as the remaining slots allow (measured on the 50k x 8 x 8 bench shape: 3 tiles per workgroup and 8
 // parts give 21.8 us per step; 1 tile / 15 parts 26.0 us; 4 tiles 25.6 us).
-struct StepPlan { Plan plan; int derive_parts; };
+struct StepPlan { Plan plan; int derive_parts; bool strided; };
 
 StepPlan make_step_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
 {
@@ -316,6 +316,8 @@ StepPlan make_step_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
         parts = (int)std::max<long long>(2, room / ((long long)n_walkers * 2 * n_pops));
     }
     sp.derive_parts = std::max(1, std::min(parts, full_parts));
+    // one round: a workgroup's tiles are strided over the slot order (binary and single-star tiles mixed)
+    sp.strided = (long long)sp.plan.n_groups * n_walkers <= slots && !getenv("B9_CONTIGUOUS_TILES");
     return sp;
 }
 
@@ -703,7 +705,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
         long slot;
         int rc = timing_begin(ctx, s, &slot);
         if (rc) return rc;
-        HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, plan.tiles_per_block, plan.n_groups, B9_HEAVY_PARTS, derive_parts, ctx->derive_order, s));
+        HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, sp.strided ? -plan.tiles_per_block : plan.tiles_per_block, plan.n_groups, B9_HEAVY_PARTS, derive_parts, ctx->derive_order, s));
         if ((rc = timing_end(ctx, s, slot))) return rc;
     }
     sd.set = (S + 1) & 1; sd.has_prev = 1; sd.derive_next = 0; sd.row = S - 1;

@@ -1264,7 +1264,14 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     const int w = s % W;
     const int group = (s / W) * 8 + xcd;                 // tile group = tiles_per_block consecutive tiles
     if (group >= n_groups) return;
-    const int tile0 = group * tiles_per_block;
+    // A workgroup's tiles are STRIDED over the slot order (group, group + n_groups, ...): binaries lead that
+    // order, so consecutive tiles would give some workgroups only expensive (binary) tiles and others only
+    // cheap ones; strided, every workgroup gets its share of both and they finish together.
+    // (Only when the launch is a single occupancy round; with several rounds the slots never idle and
+    //  contiguous tiles are faster -- measured 84 vs 94 us at 64 walkers.)
+    const bool strided = tiles_per_block < 0;
+    if (strided) tiles_per_block = -tiles_per_block;
+    const int tile0 = strided ? group : group * tiles_per_block, tile_step = strided ? n_groups : 1;
     STAMP(0);
     int i = tile0 * 256 + tid;
     int il = i < st.n_pad ? i : st.n_pad - 1;
@@ -1329,16 +1336,27 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     MixAcc acc;
     acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;         // = 1.0
     for (int t = 0; t < tiles_per_block; ++t) {
-        if ((tile0 + t) * 256 >= st.n_pad) break;
+        if ((tile0 + t * tile_step) * 256 >= st.n_pad) break;
+#ifndef B9_NO_TILE_PREFETCH
+        // the NEXT tile's star scalars are requested before this tile's arithmetic: one memory round
+        // trip less on every tile after the first, for 6 VGPRs
+        const int i_n = (tile0 + (t + 1) * tile_step) * 256 + tid;
+        const int il_n = i_n < st.n_pad ? i_n : st.n_pad - 1;
+        const double m1_n = st.mass1[il_n], q_n = st.q[il_n], ea_n = st.ea[il_n];
+#else
         if (t > 0) {
-            i = (tile0 + t) * 256 + tid;
+            i = (tile0 + t * tile_step) * 256 + tid;
             il = i < st.n_pad ? i : st.n_pad - 1;
             m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
         }
+#endif
         if (valid && i < st.n_pad && !(m1 > tip_min)) {   // empty slots hold m1 = +inf
             const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, il, log_lam, log_1ml);
             mix_add(acc, ea, l);
         }
+#ifndef B9_NO_TILE_PREFETCH
+        i = i_n; il = il_n; m1 = m1_n; q = q_n; ea = ea_n;
+#endif
     }
     STAMP(7);
     const double tot = mix_wave_total(acc);

@@ -30,6 +30,7 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
                          double *vals, double *perstar, int K, int Q, hipStream_t stream);
 
 // fused sampler step (given-mass mode): decision of step t-1 + stars of step t + candidates of step t+1
+// (tiles_per_block < 0: a workgroup's |tiles_per_block| tiles are strided n_groups apart instead of consecutive)
 hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr,
                          int tiles_per_block, int n_groups, int heavy_parts, int derive_parts,
                          int derive_order /* >= 0: derivation workgroups lead the grid, < 0: they trail it */, hipStream_t stream);
