@@ -531,7 +531,7 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
         const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
         const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
         HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, stream));
+                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, nullptr, stream));
         return B9_OK;
     }
     size_t slot = 0;
@@ -832,6 +832,51 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
                                    hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return B9_OK;
+}
+
+int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t seed, int64_t row0,
+                   double *out_mass, double *out_ratio, double *out_member, int32_t *out_pop)
+{
+    if (!ctx || !params || n_rows < 1 || !out_mass || !out_ratio || !out_member) return B9_ERR_INVALID;
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    const int n_pops = ctx->opt.n_pops, n = ctx->st.n;
+    const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
+    const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
+    const int chunk = std::min<int>(n_rows, 32);
+    rc = ensure_capacity(ctx, chunk, n_pops, (size_t)ctx->st.n_pad * chunk, false);
+    if (rc) return rc;
+    double *d_out = nullptr;
+    int *d_pop = nullptr;
+    const size_t per = (size_t)chunk * n;
+    HIPCHK(ctx, hipMalloc((void **)&d_out, sizeof(double) * per * 3));
+    if (out_pop && hipMalloc((void **)&d_pop, sizeof(int) * per) != hipSuccess) { (void)hipFree(d_out); return fail(ctx, B9_ERR_HIP, "hipMalloc failed"); }
+    hipStream_t s = ctx->stream;
+    const Bufs bf = buffer_set(ctx, 0);
+    const McmcDev off{};
+    rc = B9_OK;
+    for (int r0 = 0; r0 < n_rows && rc == B9_OK; r0 += chunk) {
+        const int m = std::min(chunk, n_rows - r0);
+        hipError_t e = hipMemcpyAsync(bf.params, params + (size_t)r0 * B9_NPARAM, sizeof(double) * B9_NPARAM * m, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(double) * per * 3, s);     // rows outside the grid write nothing
+        if (e == hipSuccess && d_pop) e = hipMemsetAsync(d_pop, 0, sizeof(int) * per, s);
+        if (e == hipSuccess) e = b9k_derive_iso(ctx->pk, bf.params, m, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, off, ctx->pr,
+                                                B9Prev{nullptr, 0, 0, nullptr, nullptr}, s);
+        B9MargSample smp{d_out, d_out + per, d_out + 2 * per, d_pop, (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), (long long)(row0 + r0)};
+        // the kernel indexes its outputs [row][n_stars] with the launch's own row count: rows are contiguous for any m
+        if (e == hipSuccess) e = b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params, m, n_pops,
+                                               ctx->d_partial, nullptr, K, Q, &smp, s);
+        const size_t cnt = (size_t)m * n, o = (size_t)r0 * n;
+        if (e == hipSuccess) e = hipMemcpyAsync(out_mass + o, d_out, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_ratio + o, d_out + per, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_member + o, d_out + 2 * per, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && d_pop) e = hipMemcpyAsync(out_pop + o, d_pop, sizeof(int) * cnt, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = fail(ctx, B9_ERR_HIP, std::string("b9_sample_mass: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_out);
+    if (d_pop) (void)hipFree(d_pop);
+    return rc;
 }
 
 int b9_derive_isochrone(b9_ctx *ctx, const double *param_row, int32_t pop, int32_t cap, double *out_mass,

@@ -1557,12 +1557,35 @@ __device__ __forceinline__ double log_prior_mass_dev(double lmn, double m)
     return lmn - 0.5 * z * z - log(m) - log(LN10);
 }
 
-template <int NFP, int NPOPS>
+// SAMPLE (b9_sample_mass, the sampleMass counterpart -- SURVEY 8f row 4): besides the marginal, every
+// star draws ONE (primary mass, mass ratio[, population]) node from its conditional posterior over the
+// same grid by the Gumbel-max rule: the node that maximises  log-term + G,  G = -log(-log u),
+// u = Philox(seed; row, star, node).  The rule is an argmax, hence independent of the order in
+// which lanes visit the nodes -- the CPU oracle, which walks them sequentially, picks the same node.
+// Nodes the pruning drops (> 40 e-folds below the maximum) draw no number: they could only win with
+// probability e^-40.
+struct MargSample {
+    double *mass, *ratio, *member;   // [rows][n_stars]
+    int *pop;                        // [rows][n_stars] or null
+    unsigned k0, k1;
+    long long row0;                  // global index of row 0 (RNG counter)
+};
+
+struct Best { double key, mass, ratio; int pop; };
+
+__device__ __forceinline__ double gumbel(unsigned k0, unsigned k1, unsigned long long row, unsigned star, unsigned long long node, unsigned pop)
+{
+    unsigned r[4];
+    philox4x32((unsigned)row, star, (unsigned)node, (unsigned)(node >> 32) * 2u + pop, k0, k1 ^ (unsigned)(row >> 32), r);
+    return -log(-log(u01(r[0], r[1])));
+}
+
+template <int NFP, int NPOPS, bool SAMPLE>
 __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                                                     const double *__restrict__ iso_data, long long iso_stride,
                                                     int mass_cap, const double *__restrict__ params,
                                                     double *__restrict__ vals, double *__restrict__ perstar,
-                                                    int K, int Q)
+                                                    int K, int Q, MargSample ms)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.y;
@@ -1604,6 +1627,16 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
     for (int f = 0; f < NFP; ++f) shift[f] = mod + pk.abs_m1[f] * av;
 
     double ll[NPOPS];
+    Best best; best.key = NEG_INF; best.mass = 0.0; best.ratio = 0.0; best.pop = 0;
+    const unsigned long long g_row = SAMPLE ? (unsigned long long)(ms.row0 + w) : 0ull;
+    double lw_pop[2] = {0.0, 0.0};                       // log weight of the population in the key
+    if (SAMPLE && NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; lw_pop[0] = log(lam); lw_pop[1] = log1p(-lam); }
+    // one candidate node: term = its log-term, id = its index in the star's node list
+#define B9_SAMPLE_NODE(term, id, m_, r_)                                                              \
+    if (SAMPLE) {                                                                                     \
+        const double key_ = (term) + lw_pop[kp] + gumbel(ms.k0, ms.k1, g_row, (unsigned)orig, (unsigned long long)(id), (unsigned)kp); \
+        if (key_ > best.key) { best.key = key_; best.mass = (m_); best.ratio = (r_); best.pop = kp; }  \
+    }
 #pragma unroll
     for (int kp = 0; kp < NPOPS; ++kp) {
         const IsoView<NFP> &is = iso[kp];
@@ -1627,7 +1660,11 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                     double chi2 = 0.0;
 #pragma unroll
                     for (int f = 0; f < NFP; ++f) { const double d = (p[f] + shift[f]) - obs[f]; chi2 = fma(wgt[f] * d, d, chi2); }
-                    if (isfinite(chi2)) lse_add(acc, (log_prior_mass_dev(pk.log_mass_norm, m1) - 0.5 * chi2) + log_w);
+                    if (isfinite(chi2)) {
+                        const double term = (log_prior_mass_dev(pk.log_mass_norm, m1) - 0.5 * chi2) + log_w;
+                        lse_add(acc, term);
+                        B9_SAMPLE_NODE(term, j, m1, 0.0)
+                    }
                 }
             }
         } else {
@@ -1701,7 +1738,10 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                 live = live && !(chi_lb > cut_ub);                           // chi0 >= chi_lb
                 if (__ballot(live) == 0ull) continue;
                 const double base = live ? log_prior_mass_dev(pk.log_mass_norm, m1) + log(dM / Q) : NEG_INF;
-                if (live && isfinite(chi0)) lse_add(acc, base - 0.5 * chi0);
+                if (live && isfinite(chi0)) {
+                    lse_add(acc, base - 0.5 * chi0);
+                    B9_SAMPLE_NODE(base - 0.5 * chi0, (long long)pnode * Q, m1, 0.0)
+                }
                 const double cut = 2.0 * ((base - wmx) + B9_MARG_CUT);       // chi^2 beyond this is negligible
                 bool want = live && !(chi_lb > cut);
                 if (__ballot(want) == 0ull) continue;                        // (A) for the whole wave
@@ -1723,7 +1763,10 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                             done = (__ballot(chi2 <= cut) == 0ull);          // (B): uniform across the wave
                         }
                     }
-                    if (want && !done && isfinite(chi2) && chi2 <= cut) lse_add(acc, base - 0.5 * chi2);
+                    if (want && !done && isfinite(chi2) && chi2 <= cut) {
+                        lse_add(acc, base - 0.5 * chi2);
+                        B9_SAMPLE_NODE(base - 0.5 * chi2, (long long)pnode * Q + j, m1, (double)j / (double)Q)
+                    }
                 }
             }
         }
@@ -1735,12 +1778,29 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
         }
         ll[kp] = (acc.mx == NEG_INF) ? NEG_INF : c0m + (acc.mx + log(acc.sm));
     }
+#undef B9_SAMPLE_NODE
+    if (SAMPLE) {      // wave argmax of the keys (ties keep the lower lane)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            Best b; b.key = __shfl_down(best.key, o, 64); b.mass = __shfl_down(best.mass, o, 64);
+            b.ratio = __shfl_down(best.ratio, o, 64); b.pop = __shfl_down(best.pop, o, 64);
+            if (b.key > best.key) best = b;
+        }
+    }
     if (lane == 0) {
         double l = ll[0];
         if (NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; l = logaddexp(log(lam) + ll[0], log1p(-lam) + ll[NPOPS - 1]); }
         const double v = logaddexp(la, l);
         vals[(size_t)w * st.n_pad + slot] = v;
         if (perstar) perstar[(size_t)w * st.n + orig] = v;
+        if (SAMPLE) {
+            const size_t o = (size_t)w * st.n + orig;
+            const bool any = best.key != NEG_INF;
+            ms.mass[o] = any ? best.mass : 0.0;
+            ms.ratio[o] = any ? best.ratio : 0.0;
+            ms.member[o] = (l == NEG_INF) ? 0.0 : exp(l - v);       // p L_cluster / (p L_cluster + (1 - p) L_field)
+            if (ms.pop) ms.pop[o] = any ? best.pop : 0;
+        }
     }
 }
 
@@ -1846,28 +1906,39 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
     return hipGetLastError();
 }
 
-template <int NFP, int NPOPS>
-static hipError_t launch_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
-                                   long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                   double *vals, double *perstar, int K, int Q, hipStream_t stream)
+template <int NFP, int NPOPS, bool SAMPLE>
+static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
+                                     long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
+                                     double *vals, double *perstar, int K, int Q, const B9MargSample *smp, hipStream_t stream)
 {
     const size_t lds = sizeof(double) * (size_t)NPOPS * mass_cap * (NFP + 1);
-    auto kern = k_star_marg<NFP, NPOPS>;
+    auto kern = k_star_marg<NFP, NPOPS, SAMPLE>;
+    MargSample ms{};
+    if (SAMPLE) { ms.mass = smp->mass; ms.ratio = smp->ratio; ms.member = smp->member; ms.pop = smp->pop; ms.k0 = smp->k0; ms.k1 = smp->k1; ms.row0 = smp->row0; }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((st.n_pad + 3) / 4, n_walkers), dim3(256), lds, stream, pk, st, hdr, iso_data, iso_stride,
-                       mass_cap, d_params, vals, perstar, K, Q);
+                       mass_cap, d_params, vals, perstar, K, Q, ms);
     return hipGetLastError();
+}
+
+template <int NFP, int NPOPS>
+static hipError_t launch_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
+                                   long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
+                                   double *vals, double *perstar, int K, int Q, const B9MargSample *smp, hipStream_t stream)
+{
+    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, stream)
+               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, stream);
 }
 
 hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
-                         double *vals, double *perstar, int K, int Q, hipStream_t stream)
+                         double *vals, double *perstar, int K, int Q, const B9MargSample *smp, hipStream_t stream)
 {
-#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, stream
+#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, stream
 #define SM2(NFP) launch_star_marg<NFP, 2>(SM_ARGS)
 #define SM1(NFP) launch_star_marg<NFP, 1>(SM_ARGS)
     B9_SWITCH_NFP(SM2, SM1)

@@ -118,6 +118,18 @@ class Engine:
         self._check(self.lib.b9_mcmc_run_block(self._ctx, C.byref(blk)))
         return params, logpost, samples, lps, int(blk.n_accept)
 
+    def sample_mass(self, params: np.ndarray, seed: int = 1, row0: int = 0):
+        """b9_sample_mass: per (row, star) one Gumbel-max draw of (primary mass, mass ratio, population) on the
+        marginalisation grid + the membership probability.  Returns (mass, ratio, member, pop), each [rows, n_stars]."""
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, abi.B9_NPARAM)
+        nr = params.shape[0]
+        mass, ratio, member = (np.empty((nr, self.n_stars)) for _ in range(3))
+        pop = np.empty((nr, self.n_stars), dtype=np.int32)
+        self._check(self.lib.b9_sample_mass(self._ctx, params.ctypes.data_as(_dp), nr, int(seed), int(row0),
+                                            mass.ctypes.data_as(_dp), ratio.ctypes.data_as(_dp), member.ctypes.data_as(_dp),
+                                            pop.ctypes.data_as(C.POINTER(C.c_int32))))
+        return mass, ratio, member, pop
+
     def derive_isochrone(self, param_row: np.ndarray, pop: int = 0, cap: int = 4096) -> Tuple[int, np.ndarray, np.ndarray, float]:
         row = np.ascontiguousarray(param_row, dtype=np.float64)
         mass = np.empty(cap)

@@ -123,6 +123,7 @@ const std::map<std::string, std::string> &Settings::flag_map()
         {"runIter", "singlePopMcmc.runIter"}, {"thin", "singlePopMcmc.thin"},
         {"seed", "general.seed"}, {"verbose", "general.verbose"},
         {"walkers", "gpu.walkers"}, {"device", "gpu.device"}, {"block", "gpu.block"},
+        {"margIsoIncrem", "sampleMass.margIsoIncrem"}, {"nMassRatios", "sampleMass.nMassRatios"},
     };
     return m;
 }

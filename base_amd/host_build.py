@@ -1,5 +1,5 @@
 """Builds the C++ host programs (base_amd/host/): libbase9host.so + singlePopMcmc, multiPopMcmc,
-makeCMD.  Plain g++ against the C ABI; they link libbase9hip.so by rpath."""
+makeCMD, sampleMass.  Plain g++ against the C ABI; they link libbase9hip.so by rpath."""
 from __future__ import annotations
 
 import os
@@ -34,7 +34,7 @@ def build_host(force: bool = False) -> None:
     if force or _stale(lib, lib_src + hdrs):
         _run(CXX + ["-shared", "-o", lib] + lib_src + link)
     progs = {"singlePopMcmc": ("mcmc_main.cpp", ["-DB9_N_POPS=1"]), "multiPopMcmc": ("mcmc_main.cpp", ["-DB9_N_POPS=2"]),
-             "makeCMD": ("makecmd_main.cpp", [])}
+             "makeCMD": ("makecmd_main.cpp", []), "sampleMass": ("samplemass_main.cpp", [])}
     for name, (src, defs) in progs.items():
         exe = os.path.join(BIN, name)
         srcp = os.path.join(HOST, src)

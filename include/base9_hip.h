@@ -214,6 +214,26 @@ typedef struct b9_mcmc_block {
 int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk);
 
 /*
+ * Per-star mass posterior draws (the sampleMass counterpart; [RECALL] sampleMass
+ * re-reads the cluster chain and, for every saved row and every star, draws the primary mass and the
+ * mass ratio from the star's conditional posterior on a grid, and reports the membership
+ * probability).  The grid is the one of the marginalised mode (b9_options.marg_iso_increm sub-steps
+ * per EEP interval x marg_n_q mass ratios; WD-stage stars: 8 * marg_iso_increm steps above the AGB
+ * tip), whatever b9_options.mode says.  For row r (a full parameter row, as in b9_logpost) and star
+ * i ONE node is drawn by the Gumbel-max rule: argmax over nodes of
+ *     log( prior(M1) dM / n_q * like_i(M1, q) [* lambda_k] )  -  log(-log u),
+ *     u = Philox4x32-10(key = (seed lo, seed hi ^ row hi), counter = (row lo, i, node lo, 2 * node hi + k)),
+ * node = (EEP interval * marg_iso_increm + sub-step) * n_q + j for main-sequence/giant nodes and the
+ * step number for WD nodes, k = population; row = row0 + r.  An argmax does not depend on the order
+ * in which nodes are visited, so any implementation picks the same node.
+ * Outputs, host, [n_rows][n_stars] in the caller's star order: out_mass (primary mass of the node),
+ * out_ratio (j / n_q; 0 for WD nodes), out_member = p_i L_i / (p_i L_i + (1 - p_i) fieldLike),
+ * out_pop (0 / 1; may be NULL).  A row outside the grid gives mass = ratio = member = 0.
+ */
+int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t seed, int64_t row0,
+                   double *out_mass, double *out_ratio, double *out_member, int32_t *out_pop);
+
+/*
  * Derive the isochrone for one parameter row ([RECALL]
  * MsRgbModel::deriveIsochrone; this is all that makeCMD needs).  Outputs, host:
  * out_mass[cap], out_mags[cap*n_filt] (absolute magnitudes, no modulus/absorption),

@@ -43,6 +43,11 @@ def load(native: bool = False) -> C.CDLL:
     lib.b9o_log_prior_mass.restype = C.c_double
     lib.b9o_log_prior_cluster.argtypes = [C.POINTER(abi.b9_priors), _dp, C.c_int]
     lib.b9o_log_prior_cluster.restype = C.c_double
+    lib.b9o_sample_mass.argtypes = [C.POINTER(abi.b9_pack), C.POINTER(abi.b9_stars), C.POINTER(abi.b9_options), _dp, C.c_int,
+                                    C.c_uint64, C.c_int64, _dp, _dp, _dp, _ip, _dp]
+    lib.b9o_sample_mass.restype = C.c_int
+    lib.b9o_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.b9o_philox4x32.restype = None
     lib.b9o_max_threads.restype = C.c_int
     lib.b9o_set_threads.argtypes = [C.c_int]
     lib.b9o_set_threads.restype = None
@@ -68,6 +73,20 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"b9o_logpost failed: {rc}")
         return (out, ps) if perstar else out
+
+    def sample_mass(self, params: np.ndarray, seed: int = 1, row0: int = 0):
+        """Restatement of b9_sample_mass.  Returns (mass, ratio, member, pop, margin); margin = best key minus
+        second-best key of each draw."""
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, abi.B9_NPARAM)
+        nr, n = params.shape[0], self.stars.struct.n_stars
+        mass, ratio, member, margin = (np.empty((nr, n)) for _ in range(4))
+        pop = np.empty((nr, n), dtype=np.int32)
+        rc = self.lib.b9o_sample_mass(self.pack.byref(), self.stars.byref(), C.byref(self.options), params.ctypes.data_as(_dp), nr,
+                                      int(seed), int(row0), mass.ctypes.data_as(_dp), ratio.ctypes.data_as(_dp),
+                                      member.ctypes.data_as(_dp), pop.ctypes.data_as(_ip), margin.ctypes.data_as(_dp))
+        if rc != 0:
+            raise RuntimeError(f"b9o_sample_mass failed: {rc}")
+        return mass, ratio, member, pop, margin
 
     def derive_isochrone(self, param_row: np.ndarray, pop: int = 0, cap: int = 4096):
         return derive_isochrone(self.lib, self.pack, param_row, pop, cap)

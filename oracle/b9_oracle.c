@@ -473,6 +473,119 @@ int b9o_logpost(const b9_pack *p, const b9_stars *s, const b9_priors *pr, const 
     return B9_OK;
 }
 
+/* ---- per-star mass draws (the sampleMass counterpart) -----------------------
+ * Restates include/base9_hip.h :: b9_sample_mass: the Gumbel-max draw over the marginalisation grid,
+ * nodes visited sequentially (the rule is an argmax, so the order is immaterial).  Philox4x32-10 as
+ * published (Salmon et al. 2011); tests/test_mcmc.py pins the numpy twin to the Random123 vectors
+ * and tests/test_oracle.py pins this one to the twin. */
+static void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)c0 * 0xD2511F53ull, p1 = (uint64_t)c2 * 0xCD9E8D57ull;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void b9o_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    philox4x32(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+static double gumbel(uint64_t seed, uint64_t row, uint32_t star, uint64_t node, uint32_t pop)
+{
+    uint32_t r[4];
+    philox4x32((uint32_t)row, star, (uint32_t)node, (uint32_t)(node >> 32) * 2u + pop,
+               (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32) ^ (uint32_t)(row >> 32), r);
+    uint64_t x = ((uint64_t)(r[0] >> 5) << 26) + (uint64_t)(r[1] >> 6);
+    double u = ((double)x + 0.5) * (1.0 / 9007199254740992.0);
+    return -log(-log(u));
+}
+
+/* out_margin (nullable): best key minus second-best key of every draw -- lets a test skip the draws
+ * that another implementation's last-bit differences could legitimately flip. */
+int b9o_sample_mass(const b9_pack *p, const b9_stars *s, const b9_options *opt, const double *params,
+                    int n_rows, uint64_t seed, int64_t row0, double *out_mass, double *out_ratio,
+                    double *out_member, int32_t *out_pop, double *out_margin)
+{
+    if (p->n_filt > 64 || p->n_filt != s->n_filt) return B9_ERR_INVALID;
+    const int n_pops = opt->n_pops == 2 ? 2 : 1;
+    const int K = opt->marg_iso_increm > 0 ? opt->marg_iso_increm : 1;
+    const int Q = opt->marg_n_q > 0 ? opt->marg_n_q : 1;
+    const double lmn = b9o_log_mass_norm(p->m_wd_up);
+    const double log_fs = b9o_log_field_like(s);
+    const int n = s->n_stars;
+    for (int r = 0; r < n_rows; ++r) {
+        const double *par = params + (size_t)r * B9_NPARAM;
+        const uint64_t row = (uint64_t)(row0 + r);
+        b9o_iso iso[2];
+        int ok = 1, built = 0;
+        for (int k = 0; ok && k < n_pops; ++k) {
+            ok = b9o_derive_isochrone(p, par[B9_P_LOGAGE], par[B9_P_FEH], k ? par[B9_P_Y2] : par[B9_P_Y], &iso[k]);
+            built = k + 1;
+        }
+        for (int i = 0; i < n; ++i) {
+            const size_t o = (size_t)r * n + i;
+            out_mass[o] = out_ratio[o] = out_member[o] = 0.0;
+            if (out_pop) out_pop[o] = 0;
+            if (out_margin) out_margin[o] = INFINITY;
+            if (!ok) continue;
+            double best = -INFINITY, second = -INFINITY, bm = 0.0, bq = 0.0, ll[2] = {-INFINITY, -INFINITY};
+            int bp = 0;
+            for (int k = 0; k < n_pops; ++k) {
+                const double lw = n_pops == 2 ? (k ? log1p(-par[B9_P_LAMBDA]) : log(par[B9_P_LAMBDA])) : 0.0;
+                double acc = -INFINITY;
+#define B9O_NODE(term_, id_, m_, q_)                                                               \
+    do {                                                                                           \
+        double term = (term_);                                                                     \
+        if (term > -INFINITY) {                                                                    \
+            acc = logaddexp(acc, term);                                                            \
+            double key = term + lw + gumbel(seed, row, (uint32_t)i, (uint64_t)(id_), (uint32_t)k); \
+            if (key > best) { second = best; best = key; bm = (m_); bq = (q_); bp = k; }            \
+            else if (key > second) second = key;                                                   \
+        }                                                                                          \
+    } while (0)
+                if (s->stage[i] == B9_STAGE_WD) {
+                    const int steps = 8 * K;
+                    double dM = (p->m_wd_up - iso[k].agb_tip) / steps;
+                    if (dM > 0.0)
+                        for (int j = 1; j <= steps; ++j) {
+                            double m1 = iso[k].agb_tip + dM * j;
+                            B9O_NODE(star_loglike(p, s, &iso[k], par, lmn, i, m1, 0.0) + log(dM), j, m1, 0.0);
+                        }
+                } else {
+                    for (int e = 0; e + 1 < iso[k].n; ++e) {
+                        double d = iso[k].mass[e + 1] - iso[k].mass[e];
+                        if (!(d > 0.0)) continue;
+                        double dM = d / K;
+                        for (int kk = 0; kk < K; ++kk) {
+                            double m1 = fma((double)kk, dM, iso[k].mass[e]);
+                            for (int j = 0; j < Q; ++j) {
+                                double q = (double)j / (double)Q;
+                                B9O_NODE(star_loglike(p, s, &iso[k], par, lmn, i, m1, q) + log(dM / Q),
+                                         ((int64_t)e * K + kk) * Q + j, m1, q);
+                            }
+                        }
+                    }
+                }
+#undef B9O_NODE
+                ll[k] = acc;
+            }
+            double l = ll[0];
+            if (n_pops == 2) l = logaddexp(log(par[B9_P_LAMBDA]) + ll[0], log1p(-par[B9_P_LAMBDA]) + ll[1]);
+            double pm = s->clust_prior[i];
+            double v = logaddexp(log1p(-pm) + log_fs, log(pm) + l);
+            if (best > -INFINITY) { out_mass[o] = bm; out_ratio[o] = bq; if (out_pop) out_pop[o] = bp; }
+            out_member[o] = (l > -INFINITY) ? exp(log(pm) + l - v) : 0.0;
+            if (out_margin) out_margin[o] = best - second;
+        }
+        for (int k = 0; k < built; ++k) b9o_iso_free(&iso[k]);
+    }
+    return B9_OK;
+}
+
 /* Convenience for tests/makeCMD parity: derive into caller buffers. */
 int b9o_derive_isochrone_flat(const b9_pack *p, const double *par, int pop, int cap,
                               double *out_mass, double *out_mags, int *out_first_eep, int *out_n,

@@ -188,3 +188,43 @@ def test_mcmc_cli_runs_and_recovers_truth(hostlib, tmp_path, prog, n_pops, n_y):
     assert lp_start < lp_truth - 50.0, (lp_start, lp_truth)
     assert main[:, -2].mean() > lp_truth - (6.0 + 0.5 * (len(head) - 2)), (main[:, -2].mean(), lp_truth)
     assert np.linalg.norm(main[:, col["logAge"]].mean() - truth[abi.P_LOGAGE]) < abs(start[abi.P_LOGAGE] - truth[abi.P_LOGAGE])
+
+
+@pytest.mark.gpu
+def test_samplemass_cli_matches_oracle(hostlib, tmp_path):
+    """singlePopMcmc -> sampleMass: the .massSamples / .membership rows are the oracle's draws for the chain's
+    main-run rows (row index = position among them, seed = general.seed)."""
+    pack_d = synth.make_pack("parsec", 4, n_feh=4, n_age=6, n_eep=60)
+    truth = synth.default_params(pack_d)
+    cl = synth.make_cluster(pack_d, 120, seed=5, truth=truth, wd_frac=0.05)
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    phot = synth.write_phot(cl, pack_d["filters"], str(tmp_path / "c.phot"))
+    y = synth.write_yaml(str(tmp_path / "base9.yaml"), phot, root, str(tmp_path / "run"), truth, burn=200, run=30, walkers=2)
+    assert _cli("singlePopMcmc", "--config", y).returncode == 0
+    r = _cli("sampleMass", "--config", y, "--margIsoIncrem", "2", "--nMassRatios", "3", "--seed", "31")
+    assert r.returncode == 0, r.stderr
+    assert "star draws/s" in r.stderr
+    head = open(str(tmp_path / "run.res")).readline().split()
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
+    main = res[res[:, -1] == 3]
+    ms = np.loadtxt(str(tmp_path / "run.massSamples"), skiprows=1)
+    mb = np.loadtxt(str(tmp_path / "run.membership"), skiprows=1)
+    assert ms.shape == (len(main), 2 * 120) and mb.shape == (len(main), 120) and len(main) == 60
+    ids = open(str(tmp_path / "run.membership")).readline().split()
+    assert ids[:3] == ["1", "2", "3"]
+    rows = np.tile(truth, (len(main), 1))
+    for name, i in {n: i for i, n in enumerate(head)}.items():
+        key = {"logAge": abi.P_LOGAGE, "FeH": abi.P_FEH, "modulus": abi.P_MOD, "absorption": abi.P_ABS}.get(name)
+        if key is not None:
+            rows[:, key] = main[:, i]
+    rows[:, abi.P_IFMR_INTERCEPT], rows[:, abi.P_IFMR_SLOPE], rows[:, abi.P_IFMR_QUAD] = 0.77, 0.08, 0.0
+    cl2 = dict(cl)
+    sg = np.asarray(cl["sigma"])
+    cl2["filter_prior_min"] = np.where(sg > 0, cl["obs"], np.inf).min(axis=0)          # the reader's field-star box
+    cl2["filter_prior_max"] = np.where(sg > 0, cl["obs"], -np.inf).max(axis=0)
+    opt = abi.make_options(marg_iso_increm=2, marg_n_q=3)
+    om, oq, omem, _, margin = oracle.Oracle(abi.make_pack(pack_d), abi.make_stars(cl2), synth.default_priors(pack_d, truth), opt).sample_mass(rows, seed=31)
+    safe = margin > 1e-4                      # the .res file holds 6 decimals of each parameter: near-ties may flip
+    assert safe.mean() > 0.98
+    assert np.max(np.abs(ms[:, 0::2][safe] - om[safe])) < 2e-6 and np.max(np.abs(ms[:, 1::2][safe] - oq[safe])) < 1e-4
+    assert np.max(np.abs(mb - omem)) < 1e-4

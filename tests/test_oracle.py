@@ -180,3 +180,31 @@ def test_marginalised_mode_matches_numpy_brute_force():
     from scipy.special import logsumexp
     want = logsumexp(np.stack([np.log1p(-pm) + log_fs, np.log(pm) + ll]), axis=0)
     np.testing.assert_allclose(ps[0], want, rtol=1e-9, atol=1e-8)
+
+
+def test_sample_mass_restatement_properties():
+    """CPU-side pins of the sampleMass restatement: its Philox equals the numpy twin (itself pinned to the
+    Random123 vectors in test_mcmc.py), draws are grid nodes, membership is what the marginal implies,
+    and a row's draws depend on (seed, row index) only."""
+    import ctypes as C
+    from base_amd import mcmc
+    lib = oracle.load()
+    for ctr, key in (((0, 0, 0, 0), (0, 0)), ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2), ((1, 2, 3, 4), (5, 6))):
+        out = (C.c_uint32 * 4)()
+        lib.b9o_philox4x32((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        tw = mcmc.philox4x32(*(np.uint32(x) for x in ctr), *(np.uint32(x) for x in key))
+        assert [int(x) for x in out] == [int(x) for x in tw]
+    pack_d, cl, pack, stars, priors, _ = build_problem("parsec", 4, n_stars=40, wd_frac=0.1, seed=3)
+    opt = abi.make_options(mode=abi.MODE_MARGINALISED, marg_iso_increm=2, marg_n_q=3)
+    o = oracle.Oracle(pack, stars, priors, opt)
+    rows = np.tile(cl["truth"], (6, 1))
+    m, q, mem, pop, margin = o.sample_mass(rows, seed=7, row0=10)
+    assert set(np.unique(q)) <= {0.0, 1.0 / 3.0, 2.0 / 3.0} and np.all(pop == 0) and np.all(margin > 0)
+    assert np.all(m > 0) and np.all(m <= pack_d["m_wd_up"])
+    _, ps = o.logpost(rows[:1], perstar=True)
+    log_fs = -np.sum(np.log(cl["filter_prior_max"] - cl["filter_prior_min"]))
+    want = 1.0 - np.exp(np.log1p(-np.asarray(cl["clust_prior"])) + log_fs - ps[0])
+    np.testing.assert_allclose(mem[0], np.clip(want, 0.0, 1.0), rtol=1e-9, atol=1e-12)
+    assert not np.array_equal(m[0], m[1])                                # same parameters, other row index -> other draws
+    m2 = o.sample_mass(rows[3:], seed=7, row0=13)[0]
+    assert np.array_equal(m[3:], m2)
