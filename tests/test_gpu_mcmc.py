@@ -52,3 +52,59 @@ def test_walker_sampler_on_device_recovers_truth():
     truth = cl["truth"][list(mcmc.DEFAULT_FREE)]
     assert 0.05 < s.accepted / (1000 * 8) < 0.8
     assert np.all(np.abs(mean - truth) < 6 * sd + 1e-3), (mean, truth, sd)
+
+
+@pytest.mark.parametrize("env", [
+    {"B9_TILES_PER_BLOCK": "1", "B9_DERIVE_PARTS": "1"},                          # many workgroups, several occupancy rounds' worth of prologues
+    {"B9_TILES_PER_BLOCK": "2", "B9_DERIVE_PARTS": "3", "B9_DERIVE_ORDER": "-1"},  # derivation workgroups trail the grid
+    {"B9_TILES_PER_BLOCK": "5", "B9_CONTIGUOUS_TILES": "1"},                      # consecutive tiles, ragged last group
+    {"B9_TILES_PER_BLOCK": "7"},                                                  # strided tiles, groups without a last tile
+    {"B9_TWO_LAUNCH_STEPS": "1"},                                                 # the two-launch step (what marginalised mode runs)
+])
+@pytest.mark.parametrize("n_steps", [1, 2, 9])
+def test_fused_step_plans_all_give_the_same_chain(monkeypatch, env, n_steps):
+    """The launch plan of the fused sampler step (tiles per workgroup, derivation parts, their place in the grid,
+    strided or consecutive tiles) and the block length (1 step: no K(t) ever takes a decision; 2: one does)
+    only regroup the same work: every plan reproduces the host twin's chain."""
+    from base_amd import engine
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=3000, wd_frac=0.04, small=False, seed=77)
+    eng = engine.Engine(pack, stars, priors, options)                              # 3000 stars -> 12 tiles
+    free = np.array(mcmc.DEFAULT_FREE)
+    start = synth.walker_params(cl["truth"], 5, seed=8, scale=0.1)
+    start[4, abi.P_LOGAGE] = pack_d["log_age"][-1] - 1e-4                          # proposals of this walker leave the grid now and then
+    ids = np.array([3, 1, 4, 1, 5])                                                # two walkers share an RNG stream id: still independent state
+    chol = np.diag([3e-4, 2e-3, 8e-4, 6e-4])
+    lp0 = eng.logpost(start)
+    host = mcmc.HostBlockRunner(eng.logpost).run(start, lp0, ids, free, chol, 5, 123456789012, n_steps)
+    dev = mcmc.DeviceBlockRunner(eng).run(start, lp0, ids, free, chol, 5, 123456789012, n_steps)
+    assert dev[4] == host[4]
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
+    np.testing.assert_allclose(dev[0], host[0], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[1], host[1], rtol=1e-10)
+    # a second block continues the first (state and RNG counters carry over): 2 x n == one block of 2 n
+    two = mcmc.DeviceBlockRunner(eng).run(dev[0], dev[1], ids, free, chol, 5, 123456789012 + n_steps, n_steps)
+    one = mcmc.DeviceBlockRunner(eng).run(start, lp0, ids, free, chol, 5, 123456789012, 2 * n_steps)
+    np.testing.assert_allclose(two[0], one[0], rtol=1e-12, atol=1e-13)
+    assert dev[4] + two[4] == one[4]
+
+
+def test_fused_step_many_walkers_and_two_populations_several_rounds(monkeypatch):
+    """More walkers than one occupancy round holds at 1 tile per workgroup: later workgroups may take the
+    published decision instead of re-deriving it -- same chain."""
+    from base_amd import engine
+    monkeypatch.setenv("B9_TILES_PER_BLOCK", "1")
+    pack_d, cl, pack, stars, priors, options = build_problem("dsed", 5, n_stars=6000, wd_frac=0.02, n_y=3, n_pops=2, small=False, seed=2)
+    eng = engine.Engine(pack, stars, priors, options)
+    free = np.array([abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS, abi.P_Y, abi.P_Y2, abi.P_LAMBDA])
+    W = 40                                                                         # 24 tiles x 40 walkers = 960 hot workgroups > 512 slots
+    start = synth.walker_params(cl["truth"], W, seed=3, scale=0.1, n_pops=2)
+    chol = np.diag([2e-4, 1e-3, 5e-4, 5e-4, 3e-4, 3e-4, 2e-3])
+    lp0 = eng.logpost(start)
+    host = mcmc.HostBlockRunner(eng.logpost).run(start, lp0, np.arange(W), free, chol, 11, 0, 6)
+    dev = mcmc.DeviceBlockRunner(eng).run(start, lp0, np.arange(W), free, chol, 11, 0, 6)
+    assert dev[4] == host[4] and dev[4] > 0
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
