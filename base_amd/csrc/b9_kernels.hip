@@ -806,7 +806,7 @@ __device__ __forceinline__ void find_bracket(const double *mass, int n, double m
 #define B9_LATE_OBS 1        // measured: 20.3 us vs 22.3 us (early) on the 50k x 8 x 8 bench shape
 #endif
 #ifdef B9_LATE_OBS
-#define B9_OBS_ARGS const DevStars &st, int il
+#define B9_OBS_ARGS const DevStars &st, int il, const double *stage
 #else
 #define B9_OBS_ARGS double c0, const double (&obs)[NFP], const double (&wgt)[NFP]
 #endif
@@ -921,12 +921,23 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         // and keeping them out of the search / row / combine phases buys a wave per SIMD
         __builtin_amdgcn_sched_barrier(0);
         double obs[NFP], wgt[NFP];
+        double c0;
+        if (stage) {
+            // the fused step stages this wave's observed magnitudes, weights and c0 in LDS with asynchronous
+            // global->LDS loads issued at the START of the tile (stage_tile): by now they have landed, so
+            // this phase costs LDS reads instead of a memory round trip
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int f = 0; f < NFP; ++f) {
-            obs[f] = st.obs[(size_t)f * st.n_pad + il];
-            wgt[f] = st.w[(size_t)f * st.n_pad + il];
+            for (int f = 0; f < NFP; ++f) { obs[f] = stage[f * 64]; wgt[f] = stage[(NFP + f) * 64]; }
+            c0 = stage[2 * NFP * 64];
+        } else {
+#pragma unroll
+            for (int f = 0; f < NFP; ++f) {
+                obs[f] = st.obs[(size_t)f * st.n_pad + il];
+                wgt[f] = st.w[(size_t)f * st.n_pad + il];
+            }
+            c0 = st.c0[il];
         }
-        const double c0 = st.c0[il];
 #endif
 #pragma unroll
         for (int f = 0; f < NFP; ++f) {
@@ -1185,7 +1196,7 @@ __global__ __launch_bounds__(256, (NPOPS == 2 && B9_K1_MIN_WAVES > B9_K1_MIN_WAV
             }
             if (i < st.n_pad && !(m1 > tip_min[b])) {     // empty slots hold m1 = +inf
 #ifdef B9_LATE_OBS
-                const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, st, il, log_lam[b], log_1ml[b]);
+                const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, st, il, nullptr, log_lam[b], log_1ml[b]);
 #else
                 const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, c0, obs, wgt, log_lam[b], log_1ml[b]);
 #endif
@@ -1253,6 +1264,35 @@ __device__ __forceinline__ bool step_decide(const StepDev &sd, int w, double &lp
     return ok;
 }
 
+// Asynchronous global -> LDS staging of one wave's 64 stars of a tile: observed magnitudes, weights, c0
+// = 2 NFP + 1 arrays of 64 doubles.  Lanes 0..31 each move 16 bytes per array (global_load_lds_dwordx4:
+// the hardware places lane l's data at dst + 16 l, so the 512 bytes land in star order); no VGPR holds
+// the data and nothing waits here -- hot_star waits (vmcnt) when it needs them, a few thousand cycles later.
+template <int NFP>
+__device__ __forceinline__ void stage_tile(const DevStars &st, int slot0 /* first slot of this wave's 64 */, double *dst)
+{
+    const int lane = threadIdx.x & 63;
+    typedef const __attribute__((address_space(1))) void *gptr;
+    typedef __attribute__((address_space(3))) void *lptr;
+    if (lane < 32) {
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            __builtin_amdgcn_global_load_lds((gptr)(st.obs + (size_t)f * st.n_pad + slot0 + 2 * lane), (lptr)(dst + f * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(st.w + (size_t)f * st.n_pad + slot0 + 2 * lane), (lptr)(dst + (NFP + f) * 64), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((gptr)(st.c0 + slot0 + 2 * lane), (lptr)(dst + 2 * NFP * 64), 16, 0, 0);
+    }
+}
+
+// Measured on the bench shape: 20.4 us/step with the stage vs 19.6 without (the other waves of the SIMD already
+// hide that round trip; the stage adds 17 DMA instructions and two waits per tile).  Kept as a tested
+// compile-time option (-DB9_USE_LDS_STAGE), off.
+#ifdef B9_USE_LDS_STAGE
+#define B9_LDS_STAGE(NFP) ((NFP) <= 8)        // 16 padded filters would need 68 KB per workgroup: not worth the occupancy
+#else
+#define B9_LDS_STAGE(NFP) false
+#endif
+
 // Hot role: k_star_like's body for one walker, with the mass columns and headers of BOTH candidates
 // requested before the decision is known (same round trip as the partial sums the decision needs).
 template <int NFP, int NPOPS>
@@ -1276,6 +1316,9 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     int i = tile0 * 256 + tid;
     int il = i < st.n_pad ? i : st.n_pad - 1;
     double m1 = st.mass1[il], q = st.q[il], ea = st.ea[il];
+    // this wave's LDS stage for the tile's observations (behind the mass columns)
+    double *const stage_w = smem + (size_t)(2 * NPOPS) * mass_cap + 8 + (size_t)(tid >> 6) * ((2 * NFP + 1) * 64);
+    if (B9_LDS_STAGE(NFP) && tile0 * 256 < st.n_pad) stage_tile<NFP>(st, tile0 * 256 + (tid & ~63), stage_w);
     const size_t rows = (size_t)W * NPOPS;
     const size_t cb0 = (size_t)(sd.set * 2) * rows + (size_t)w * NPOPS;      // candidate 0; candidate 1 is `rows` further
     double *const lds_mass = smem;
@@ -1351,12 +1394,19 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
         }
 #endif
         if (valid && i < st.n_pad && !(m1 > tip_min)) {   // empty slots hold m1 = +inf
-            const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, il, log_lam, log_1ml);
+            const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, il,
+                                                  B9_LDS_STAGE(NFP) ? stage_w + (tid & 63) : nullptr, log_lam, log_1ml);
             mix_add(acc, ea, l);
         }
 #ifndef B9_NO_TILE_PREFETCH
         i = i_n; il = il_n; m1 = m1_n; q = q_n; ea = ea_n;
 #endif
+        if (B9_LDS_STAGE(NFP) && t + 1 < tiles_per_block && (tile0 + (t + 1) * tile_step) * 256 < st.n_pad) {
+            // the next tile's observations: every lane of this wave has consumed the current ones (their
+            // ds_reads have returned -- the chi^2 used them), so the stage can be overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage_tile<NFP>(st, (tile0 + (t + 1) * tile_step) * 256 + (tid & ~63), stage_w);
+        }
     }
     STAMP(7);
     const double tot = mix_wave_total(acc);
@@ -1952,7 +2002,8 @@ static hipError_t launch_mcmc_step(const DevPack &pk, const DevStars &st, const 
                                    int tiles_per_block, int n_groups, int heavy_parts, int derive_parts, int derive_order, hipStream_t stream)
 {
     // hot role: the mass columns of both candidates (+ 8: find_bracket's masked over-read)
-    const size_t lds = sizeof(double) * std::max((size_t)2 * NPOPS * sd.mass_cap + 8, heavy_lds_doubles(pk, NPOPS));
+    const size_t stage = B9_LDS_STAGE(NFP) ? (size_t)4 * (2 * NFP + 1) * 64 : 0;      // per-wave observation stage of the hot role
+    const size_t lds = sizeof(double) * std::max((size_t)2 * NPOPS * sd.mass_cap + 8 + stage, heavy_lds_doubles(pk, NPOPS));
     auto kern = k_mcmc_step<NFP, NPOPS>;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
