@@ -66,7 +66,6 @@ struct b9_ctx {
     int walkers_per_lane = 1;  // WB template parameter of k_star_like (1 or 2)
     int derive_parts = 0;      // fused sampler step: workgroups per candidate isochrone (0 = one value per thread)
     int derive_order = 0;      // fused sampler step: >= 0 derivation workgroups lead the grid, < 0 they trail it (B9_DERIVE_ORDER)
-    int dbg_step = 0;          // B9_DBG_STEP: timing experiments on the fused step (bit 0: no decision, bit 1: no derivation)
     bool two_launch_steps = false;   // B9_TWO_LAUNCH_STEPS=1: the derive + star launch pair per step also in given-mass mode
 
     // timing of the dominant kernel
@@ -354,7 +353,6 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     if (const char *s = getenv("B9_WALKERS_PER_LANE")) ctx->walkers_per_lane = atoi(s) >= 2 ? 2 : 1;
     if (const char *s = getenv("B9_DERIVE_PARTS")) ctx->derive_parts = atoi(s);
     if (const char *s = getenv("B9_DERIVE_ORDER")) ctx->derive_order = atoi(s);
-    if (const char *s = getenv("B9_DBG_STEP")) ctx->dbg_step = atoi(s);
     if (const char *s = getenv("B9_TWO_LAUNCH_STEPS")) ctx->two_launch_steps = atoi(s) != 0;
     *out = ctx;
     return B9_OK;
@@ -700,8 +698,6 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     for (int t = 0; t < S; ++t) {
         sd.set = (t + 1) & 1; sd.has_prev = t > 0; sd.derive_next = t + 1 < S; sd.row = t - 1;
         sd.step = (unsigned long long)(blk->step0 + t);
-        if (ctx->dbg_step & 1) sd.has_prev = 0;            // timing experiments only (the chain is then wrong)
-        if (ctx->dbg_step & 2) sd.derive_next = 0;
         long slot;
         int rc = timing_begin(ctx, s, &slot);
         if (rc) return rc;

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 
 import oracle  # noqa: E402
-from base_amd import abi, synth  # noqa: E402
+from base_amd import abi, mcmc, synth  # noqa: E402
 
 CASES = {
     # name: (pack, n_filt, n_stars, wd_frac, n_y, n_pops, pack kwargs)
@@ -45,7 +45,21 @@ def main():
         params[3, abi.P_FEH] = pack_d["feh"][-1] + 0.5     # one row outside the grid
         lp, ps = oracle.Oracle(pack, stars, priors, options).logpost(params, perstar=True)
         iso = oracle.derive_isochrone(oracle.load(), pack, params[0])
+        # marginalised mode (2 sub-steps x 3 mass ratios), the sampleMass draws on the same grid, and a short
+        # Metropolis chain (the host block runner over the oracle: what b9_mcmc_run_block must reproduce)
+        orc = oracle.Oracle(pack, stars, priors, options)
+        opt_m = abi.make_options(mode=abi.MODE_MARGINALISED, n_pops=npops, marg_iso_increm=2, marg_n_q=3)
+        orc_m = oracle.Oracle(pack, stars, priors, opt_m)
+        mlp, mps = orc_m.logpost(params, perstar=True)
+        sm = orc_m.sample_mass(params[:3], seed=11, row0=5)
+        free = np.array([abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS] + ([abi.P_Y, abi.P_Y2, abi.P_LAMBDA] if npops == 2 else []))
+        chol = np.diag([3e-4, 2e-3, 8e-4, 6e-4] + ([3e-4, 3e-4, 2e-3] if npops == 2 else []))
+        start = params[:3].copy()
+        chain = mcmc.HostBlockRunner(orc.logpost).run(start, orc.logpost(start), np.array([0, 1, 2]), free, chol, 2024, 40, 20)
         out = {f"pack_{k}": np.asarray(pack_d[k]) for k in PACK_KEYS}
+        out.update(marg_logpost=mlp, marg_perstar=mps, sm_mass=sm[0], sm_ratio=sm[1], sm_member=sm[2], sm_pop=sm[3], sm_margin=sm[4],
+                   chain_free=free, chain_chol=chol, chain_params=chain[0], chain_logpost=chain[1], chain_samples=chain[2],
+                   chain_lps=chain[3], chain_accepted=chain[4])
         out.update({f"star_{k}": np.asarray(cl[k]) for k in STAR_KEYS})
         out.update(pack_n_filt=nf, pack_ifmr_id=pack_d["ifmr_id"], pack_m_wd_up=pack_d["m_wd_up"], pack_n_at_type=2,
                    n_pops=npops, prior_mean=np.array(list(priors.mean)), prior_var=np.array(list(priors.var)),
