@@ -52,6 +52,18 @@ def test_long_isochrone_2000_eeps():
     m_eng = engine.Engine(pack, s6, priors, mopt)
     assert _err(m_eng.logpost(params), oracle.Oracle(pack, s6, priors, mopt).logpost(params)) <= 1e-9
 
+    # the fused sampler step on the same long isochrones: the hot role stages 2 x 2000 masses per workgroup
+    # (past the 4 x 256 elements that travel through registers) and every candidate takes 71 derivation parts
+    from base_amd import mcmc
+    free, chol = np.array(mcmc.DEFAULT_FREE), np.diag([3e-4, 2e-3, 8e-4, 6e-4])
+    start = synth.walker_params(cl["truth"], 3, seed=4, scale=0.1)
+    lp0 = eng.logpost(start)
+    host = mcmc.HostBlockRunner(eng.logpost).run(start, lp0, np.arange(3), free, chol, 9, 0, 8)
+    dev = mcmc.DeviceBlockRunner(eng).run(start, lp0, np.arange(3), free, chol, 9, 0, 8)
+    assert dev[4] == host[4]
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
+
 
 def test_call_order_and_argument_errors():
     from base_amd import engine
