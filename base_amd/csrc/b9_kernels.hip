@@ -1507,45 +1507,45 @@ void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_pe
                  int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int W = sd.n_walkers;
+    const int W = sd.n_walkers, n_heavy = W * heavy_parts, n_derive = W * 2 * NPOPS * derive_parts;
     int b = blockIdx.x;
-    if (derive_first) {          // [heavy][all derivation workgroups][pad] [hot]
-        if (b >= front_blocks) { step_hot<NFP, NPOPS>(pk, st, sd, b - front_blocks, tiles_per_block, n_groups, smem); return; }
-        if (b >= W * heavy_parts) {
-            b -= W * heavy_parts;
-            if (b >= W * 2 * NPOPS * derive_parts) return;       // padding to a multiple of 8
-            const int part = b % derive_parts; b /= derive_parts;
-            const int pop = b % NPOPS; b /= NPOPS;
-            step_derive(pk, sd, pr, b >> 1, b & 1, pop, part, derive_parts);
-            return;
-        }
-    }
+    // role of this workgroup: 0 hot, 1 heavy, 2 derivation (index b within the role), 3 none (padding)
+    int role;
     if (b < front_blocks) {
-        if (b < W * heavy_parts) {
-            const int w = b / heavy_parts, part = b - w * heavy_parts;
-            double lp_new;
-            const int sel = step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0;
-            const size_t rows = (size_t)W * NPOPS, cs = (size_t)(sd.set * 2 + sel);
-            heavy_stars<NFP, NPOPS>(pk, st, sd.cand_hdr + cs * rows, sd.cand_iso + cs * rows * sd.iso_stride, sd.iso_stride,
-                                    sd.mass_cap, sd.cand_par + cs * W * B9_NPARAM, w, part, heavy_parts,
-                                    sd.partial + (size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) +
-                                        (size_t)n_groups * 4 + part,
-                                    nullptr, smem);
-            return;
+        if (b < n_heavy) role = 1;
+        else {
+            b -= n_heavy;
+            if (derive_first) role = b < n_derive ? 2 : 3;
+            else if (b < W) { role = 2; b *= 2 * NPOPS * derive_parts; }       // the writer of walker b: (cand 0, pop 0, part 0)
+            else role = 3;
         }
-        b -= W * heavy_parts;
-        if (b < W) step_derive(pk, sd, pr, b, 0, 0, 0, derive_parts);      // the writer of walker b (also derives its share)
-        return;                                                             // else: padding to a multiple of 8
+    } else {
+        b -= front_blocks;
+        if (b < hot_blocks) role = 0;
+        else {                                                                  // trailing derivation workgroups (derive_first == 0)
+            b -= hot_blocks;
+            const bool writer = (b % (2 * NPOPS * derive_parts)) == 0;          // those already ran in front
+            role = (b < n_derive && !writer && sd.derive_next) ? 2 : 3;
+        }
     }
-    b -= front_blocks;
-    if (b < hot_blocks) { step_hot<NFP, NPOPS>(pk, st, sd, b, tiles_per_block, n_groups, smem); return; }
-    b -= hot_blocks;
-    const int part = b % derive_parts; b /= derive_parts;
-    const int pop = b % NPOPS; b /= NPOPS;
-    const int cand = b & 1, w = b >> 1;
-    if (w >= W || (cand == 0 && pop == 0 && part == 0)) return;            // the writers already ran in front
-    if (!sd.derive_next) return;
-    step_derive(pk, sd, pr, w, cand, pop, part, derive_parts);
+    if (role == 0) { step_hot<NFP, NPOPS>(pk, st, sd, b, tiles_per_block, n_groups, smem); return; }
+    if (role == 1) {
+        const int w = b / heavy_parts, part = b - w * heavy_parts;
+        double lp_new;
+        const int sel = step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0;
+        const size_t rows = (size_t)W * NPOPS, cs = (size_t)(sd.set * 2 + sel);
+        heavy_stars<NFP, NPOPS>(pk, st, sd.cand_hdr + cs * rows, sd.cand_iso + cs * rows * sd.iso_stride, sd.iso_stride,
+                                sd.mass_cap, sd.cand_par + cs * W * B9_NPARAM, w, part, heavy_parts,
+                                sd.partial + (size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) +
+                                    (size_t)n_groups * 4 + part,
+                                nullptr, smem);
+        return;
+    }
+    if (role == 2) {       // b = ((w * 2 + cand) * NPOPS + pop) * derive_parts + part
+        const int part = b % derive_parts; b /= derive_parts;
+        const int pop = b % NPOPS; b /= NPOPS;
+        step_derive(pk, sd, pr, b >> 1, b & 1, pop, part, derive_parts);
+    }
 }
 
 // the block's last decision: one workgroup per walker, writer role only
