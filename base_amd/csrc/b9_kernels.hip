@@ -1614,6 +1614,19 @@ __device__ __forceinline__ double log_prior_mass_dev(double lmn, double m)
 // which lanes visit the nodes -- the CPU oracle, which walks them sequentially, picks the same node.
 // Nodes the pruning drops (> 40 e-folds below the maximum) draw no number: they could only win with
 // probability e^-40.
+#ifdef B9_MARG_STATS      // diagnostic build only: where the marginalised kernel's iterations go
+__device__ unsigned long long g_marg_stats[8];
+#define MSTAT(k, v) do { if (lane == 0) atomicAdd(&g_marg_stats[k], (unsigned long long)(v)); } while (0)
+extern "C" int b9_debug_marg_stats(unsigned long long *out, int clear)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_marg_stats), sizeof(unsigned long long) * 8);
+    if (clear) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_marg_stats), z, sizeof z); }
+    return rc;
+}
+#else
+#define MSTAT(k, v) do {} while (0)
+#endif
+
 struct MargSample {
     double *mass, *ratio, *member;   // [rows][n_stars]
     int *pop;                        // [rows][n_stars] or null
@@ -1635,7 +1648,7 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                                                     const double *__restrict__ iso_data, long long iso_stride,
                                                     int mass_cap, const double *__restrict__ params,
                                                     double *__restrict__ vals, double *__restrict__ perstar,
-                                                    int K, int Q, MargSample ms)
+                                                    int K, int Q, MargSample ms, int chunk_cap)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.y;
@@ -1662,6 +1675,49 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
         iso[kp].mass = dst; iso[kp].mags = dst + mass_cap;
     }
     __syncthreads();
+    // Chunk-level pruning table, per 64-node chunk c of the primary-mass loop and per filter f (three planes):
+    //   faint[c][f]  = the FAINTEST magnitude among the chunk's EEP rows.  Every node of the chunk interpolates
+    //                  between those rows and a companion only adds flux, so no system of the chunk is fainter:
+    //                  where even that is brighter than observed, every node pays the excess (chunk form of (A)).
+    //   brt[c][f]    = the brightest a system of the chunk can be: brightest row of the chunk (primary) plus the
+    //                  brightest row at or below the chunk (a companion is less massive than its primary, so its
+    //                  two bracketing rows lie at or below the chunk's last row).  Where even that is fainter
+    //                  than observed, every node and every mass ratio pays the deficit.
+    //   (third plane: the chunk's own brightest row, an intermediate of the prefix minimum.)
+    double *const chunk_tab = smem + (size_t)NPOPS * mass_cap * (NFP + 1);
+    const size_t plane = (size_t)NPOPS * chunk_cap * NFP;
+    if (chunk_cap > 0) {
+#pragma unroll
+        for (int kp = 0; kp < NPOPS; ++kp) {
+            const int n = iso[kp].n, n_chunks = ((n - 1) * K + 63) >> 6;
+            for (int idx = tid; idx < n_chunks * NFP; idx += 256) {
+                const int c = idx / NFP, f = idx - c * NFP;
+                const int r0 = (64 * c) / K;
+                int r1 = (64 * c + 63) / K + 1;
+                r1 = r1 > n - 1 ? n - 1 : r1;
+                double mx = iso[kp].mags[(size_t)r0 * NFP + f], mn = mx;
+                for (int r = r0 + 1; r <= r1; ++r) { const double v = iso[kp].mags[(size_t)r * NFP + f]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+                chunk_tab[((size_t)kp * chunk_cap + c) * NFP + f] = mx;
+                chunk_tab[2 * plane + ((size_t)kp * chunk_cap + c) * NFP + f] = mn;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < NPOPS; ++kp) {
+            const int n = iso[kp].n, n_chunks = ((n - 1) * K + 63) >> 6;
+            for (int idx = tid; idx < n_chunks * NFP; idx += 256) {
+                const int c = idx / NFP, f = idx - c * NFP;
+                const double own = chunk_tab[2 * plane + ((size_t)kp * chunk_cap + c) * NFP + f];
+                double pre = own;                              // brightest row at or below the chunk
+                for (int cc = 0; cc < c; ++cc) { const double v = chunk_tab[2 * plane + ((size_t)kp * chunk_cap + cc) * NFP + f]; pre = v < pre ? v : pre; }
+                // -2.5 log10(10^(-0.4 own) + 10^(-0.4 pre)), pre <= own:  pre - 2.5 log10(1 + 10^(-0.4 (own - pre)));
+                // lowered by 1e-9 mag so that rounding can only make the bound weaker, never wrong
+                chunk_tab[plane + ((size_t)kp * chunk_cap + c) * NFP + f] =
+                    (pre - (2.5 / LN10) * log1p(exp((-0.4 * LN10) * (own - pre)))) - 1e-9;
+            }
+        }
+        __syncthreads();
+    }
     if (slot >= st.n_pad) return;
     const int orig = st.perm[slot];
     if (orig < 0) { if (lane == 0) vals[(size_t)w * st.n_pad + slot] = 0.0; return; }
@@ -1758,12 +1814,66 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
             for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(dmax, o, 64); dmax = t > dmax ? t : dmax; }
             const double mlow = is.mass[0] > 0.1 ? is.mass[0] : 0.1;
             const double bmax = (dmax > 0.0) ? log_prior_mass_dev(pk.log_mass_norm, mlow) + log(dmax / K / Q) : NEG_INF;
-            for (int p0 = 0; p0 < n_nodes; p0 += 64) {
+            // Pre-pass over the chunk table with the lanes laid out as (chunk, filter): 64 / NFP chunks are bounded
+            // per pass (one table word and one multiply-add per lane, a log2(NFP)-step shuffle sum), against
+            // the SEED of the running maximum -- a looser cut than the loop's own test below uses, so the
+            // survivors are a superset of the chunks that test keeps and the result is unchanged.  Their
+            // indices, in ascending order, go to this wave's list in LDS.
+            int n_list = -1;                                   // -1: no list, visit every chunk
+            int *const my_list = reinterpret_cast<int *>(chunk_tab + 3 * plane + (size_t)4 * 2 * NFP) + (size_t)wave * chunk_cap;
+            if (chunk_cap > 0) {
+                double *const pre = chunk_tab + 3 * plane + (size_t)wave * 2 * NFP;
+                if (lane == 0) {
+#pragma unroll
+                    for (int f = 0; f < NFP; ++f) { pre[f] = shift[f] - obs[f]; pre[NFP + f] = wgt[f]; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int f = lane & (NFP - 1), cg = lane / NFP, n_chunks = (n_nodes + 63) >> 6;
+                const double off = pre[f], wg = pre[NFP + f];
+                const double cut0 = 2.0 * ((bmax - seed) + B9_MARG_CUT);          // +inf without a seed: nothing is dropped here
+                n_list = 0;
+                for (int c0 = 0; c0 < n_chunks; c0 += 64 / NFP) {
+                    const int c = c0 + cg;
+                    const bool in = c < n_chunks;
+                    const double *cm = chunk_tab + ((size_t)kp * chunk_cap + (in ? c : 0)) * NFP;
+                    const double too_bright = cm[f] + off, too_faint = cm[plane + f] + off;
+                    const double dd = too_bright < 0.0 ? too_bright : (too_faint > 0.0 ? too_faint : 0.0);
+                    double term = (wg * dd) * dd;
+#pragma unroll
+                    for (int o = NFP / 2; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
+                    const bool keep = in && f == 0 && !(term > cut0);
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) my_list[n_list + __popcll(m & ((1ull << lane) - 1ull))] = c;
+                    n_list += __popcll(m);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            const int n_visit = n_list >= 0 ? n_list : (n_nodes + 63) >> 6;
+            for (int iv = 0; iv < n_visit; ++iv) {
+                const int p0 = (n_list >= 0 ? my_list[iv] : iv) << 6;
                 const int pnode = p0 + lane;
                 // wave-wide running maximum (conservative for every lane)
                 double wmx = acc.mx > seed ? acc.mx : seed;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(wmx, o, 64); wmx = t > wmx ? t : wmx; }
+                MSTAT(0, 1);
+                if (chunk_cap > 0) {       // the whole chunk at once (wave-uniform: every lane reads the same LDS words)
+                    const double *cm = chunk_tab + ((size_t)kp * chunk_cap + (p0 >> 6)) * NFP;
+                    double cb = 0.0;
+#pragma unroll
+                    for (int f = 0; f < NFP; ++f) {
+                        const double off = shift[f] - obs[f];
+                        const double too_bright = cm[f] + off, too_faint = cm[plane + f] + off;
+                        const double dd = too_bright < 0.0 ? too_bright : (too_faint > 0.0 ? too_faint : 0.0);
+                        cb = fma(wgt[f] * dd, dd, cb);
+                    }
+                    if (cb > 2.0 * ((bmax - wmx) + B9_MARG_CUT)) continue;
+                }
+                MSTAT(1, 1);
                 bool live = pnode < n_nodes;
                 int e = 0, s = 0;
                 double a = 0.0, d = 1.0;
@@ -1787,6 +1897,7 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                 const double cut_ub = 2.0 * ((bmax - wmx) + B9_MARG_CUT);
                 live = live && !(chi_lb > cut_ub);                           // chi0 >= chi_lb
                 if (__ballot(live) == 0ull) continue;
+                MSTAT(2, 1);
                 const double base = live ? log_prior_mass_dev(pk.log_mass_norm, m1) + log(dM / Q) : NEG_INF;
                 if (live && isfinite(chi0)) {
                     lse_add(acc, base - 0.5 * chi0);
@@ -1795,6 +1906,7 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                 const double cut = 2.0 * ((base - wmx) + B9_MARG_CUT);       // chi^2 beyond this is negligible
                 bool want = live && !(chi_lb > cut);
                 if (__ballot(want) == 0ull) continue;                        // (A) for the whole wave
+                MSTAT(3, 1); MSTAT(6, __popcll(__ballot(want)));
                 for (int j = 1; j < Q; ++j) {
                     const double m2 = ((double)j / (double)Q) * m1;
                     const bool dark2 = m2 < is.mass[0];
@@ -1803,9 +1915,11 @@ __global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, cons
                     const double *s0 = is.mags + (size_t)lo2 * NFP;
                     double chi2 = want ? 0.0 : __builtin_inf();
                     bool done = false;
+                    MSTAT(4, 1);
 #pragma unroll
                     for (int f = 0; f < NFP; ++f) {
                         if (!done) {
+                            MSTAT(5, 1);
                             const double p2 = dark2 ? B9_MAG_NOFLUX : lerp(s0[f], s0[NFP + f], t2);
                             const double pc = p1[f] - (2.5 / LN10) * log1pexp((-0.4 * LN10) * (p2 - p1[f]));
                             const double dd = (pc + shift[f]) - obs[f];
@@ -1961,7 +2075,11 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
                                      long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
                                      double *vals, double *perstar, int K, int Q, const B9MargSample *smp, hipStream_t stream)
 {
-    const size_t lds = sizeof(double) * (size_t)NPOPS * mass_cap * (NFP + 1);
+    size_t lds = sizeof(double) * (size_t)NPOPS * mass_cap * (NFP + 1);
+    int chunk_cap = ((mass_cap - 1) * K + 63) / 64 + 1;                     // chunk-bound table, when LDS has room for it
+    // three planes + per wave: 2 NFP doubles of the star's offsets/weights and a list of surviving chunks
+    const size_t with_table = lds + sizeof(double) * ((size_t)NPOPS * chunk_cap * NFP * 3 + 4 * 2 * NFP) + sizeof(int) * 4 * ((size_t)chunk_cap + 1);
+    if (with_table <= 160 * 1024 && !getenv("B9_NO_CHUNK_BOUNDS")) lds = with_table; else chunk_cap = 0;
     auto kern = k_star_marg<NFP, NPOPS, SAMPLE>;
     MargSample ms{};
     if (SAMPLE) { ms.mass = smp->mass; ms.ratio = smp->ratio; ms.member = smp->member; ms.pop = smp->pop; ms.k0 = smp->k0; ms.k1 = smp->k1; ms.row0 = smp->row0; }
@@ -1971,7 +2089,7 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((st.n_pad + 3) / 4, n_walkers), dim3(256), lds, stream, pk, st, hdr, iso_data, iso_stride,
-                       mass_cap, d_params, vals, perstar, K, Q, ms);
+                       mass_cap, d_params, vals, perstar, K, Q, ms, chunk_cap);
     return hipGetLastError();
 }
 
