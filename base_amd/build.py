@@ -42,7 +42,7 @@ def _run(cmd: List[str]) -> None:
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in ("b9_kernels.hip", "b9_capi.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("b9_device.h", "b9_launch.h")] + \
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(ROOT, "include", "base9_hip.h")]
     if not force and _newer(HIP_LIB, deps):
         return HIP_LIB

@@ -1,0 +1,353 @@
+// b9_mcmc_step.hip.h -- k_mcmc_step: the fused one-launch sampler step (decision + stars + speculative candidates).
+// Part of the single translation unit b9_kernels.hip (included there, in this order); gfx950 only.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// k_mcmc_step: the fused sampler step (see StepDev in b9_device.h).  ONE launch per MCMC step.
+//
+// Roles by workgroup id:  [heavy-star workgroups][candidate-derivation workgroups][pad to 8][hot].
+// Every role starts with step_decide(): the accept/reject decision of the PREVIOUS step, taken
+// redundantly by every workgroup of a walker from the same fixed-order sum (identical bits).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ const double *step_state_in(const StepDev &sd, int w)
+{
+    return sd.state + ((size_t)(sd.set ^ 1) * sd.n_walkers + w) * B9_STATE_STRIDE;
+}
+
+// Decision of step t-1 for walker w.  Every WAVE takes it on its own -- lane l adds the partials
+// l, l + 64, ... in order, then the shuffle tree -- so there is no LDS traffic and no barrier, all
+// waves of all workgroups obtain the same bits, and a wave may use the shortcut below whatever its
+// neighbours do.  lp_new = log-posterior of the state after that step (not set on the shortcut).
+// SHORTCUT: the caller only needs the 0/1 outcome -- if the walker's writer workgroup (which leads
+// the grid) has already published it for this step, take it from there and skip the sum.  Waves
+// that start before the writer is done compute it themselves: same bits either way, nobody waits.
+#ifndef B9_SHORTCUT
+#define B9_SHORTCUT true
+#endif
+template <bool SHORTCUT>
+__device__ __forceinline__ bool step_decide(const StepDev &sd, int w, double &lp_new)
+{
+    const int lane = threadIdx.x & 63;
+    const double *in = step_state_in(sd, w);
+    const double lp_cur = in[B9_ST_LP];
+    if (!sd.has_prev) { lp_new = lp_cur; return false; }
+    if (SHORTCUT) {
+        const unsigned long long f = __hip_atomic_load(sd.decided + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((f >> 1) == sd.step) { lp_new = 0.0; return (f & 1ull) != 0; }      // wave-uniform: one word per walker
+    }
+    const double *part = sd.partial + (size_t)w * sd.partial_stride + (size_t)(sd.set ^ 1) * (sd.partial_stride / 2);
+    double acc = 0.0;
+    for (int j = lane; j < sd.n_partial; j += 64) acc += part[j];
+    const double lpr = in[B9_ST_LPRIOR], lu = in[B9_ST_LOGU];
+    STAMP(9);
+    const double t = __shfl(wave_sum(acc), 0, 64);
+    STAMP(10);
+    STAMP(11);
+    const double lp_prop = (lpr != NEG_INF) ? lpr + t : NEG_INF;       // prior + sum, as k_finalize forms it
+    const bool ok = isfinite(lp_prop) && (lu < lp_prop - lp_cur);
+    lp_new = ok ? lp_prop : lp_cur;
+    return ok;
+}
+
+// Asynchronous global -> LDS staging of one wave's 64 stars of a tile: observed magnitudes, weights, c0
+// = 2 NFP + 1 arrays of 64 doubles.  Lanes 0..31 each move 16 bytes per array (global_load_lds_dwordx4:
+// the hardware places lane l's data at dst + 16 l, so the 512 bytes land in star order); no VGPR holds
+// the data and nothing waits here -- hot_star waits (vmcnt) when it needs them, a few thousand cycles later.
+template <int NFP>
+__device__ __forceinline__ void stage_tile(const DevStars &st, int slot0 /* first slot of this wave's 64 */, double *dst)
+{
+    const int lane = threadIdx.x & 63;
+    typedef const __attribute__((address_space(1))) void *gptr;
+    typedef __attribute__((address_space(3))) void *lptr;
+    if (lane < 32) {
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            __builtin_amdgcn_global_load_lds((gptr)(st.obs + (size_t)f * st.n_pad + slot0 + 2 * lane), (lptr)(dst + f * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(st.w + (size_t)f * st.n_pad + slot0 + 2 * lane), (lptr)(dst + (NFP + f) * 64), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((gptr)(st.c0 + slot0 + 2 * lane), (lptr)(dst + 2 * NFP * 64), 16, 0, 0);
+    }
+}
+
+// Measured on the bench shape: 20.4 us/step with the stage vs 19.6 without (the other waves of the SIMD already
+// hide that round trip; the stage adds 17 DMA instructions and two waits per tile).  Kept as a tested
+// compile-time option (-DB9_USE_LDS_STAGE), off.
+#ifdef B9_USE_LDS_STAGE
+#define B9_LDS_STAGE(NFP) ((NFP) <= 8)        // 16 padded filters would need 68 KB per workgroup: not worth the occupancy
+#else
+#define B9_LDS_STAGE(NFP) false
+#endif
+
+// Hot role: k_star_like's body for one walker, with the mass columns and headers of BOTH candidates
+// requested before the decision is known (same round trip as the partial sums the decision needs).
+template <int NFP, int NPOPS>
+__device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, const StepDev &sd, int L,
+                                         int tiles_per_block, int n_groups, double *smem)
+{
+    const int tid = threadIdx.x, W = sd.n_walkers, mass_cap = sd.mass_cap;
+    const int xcd = L & 7, s = L >> 3;
+    const int w = s % W;
+    const int group = (s / W) * 8 + xcd;                 // tile group = tiles_per_block consecutive tiles
+    if (group >= n_groups) return;
+    // A workgroup's tiles are STRIDED over the slot order (group, group + n_groups, ...): binaries lead that
+    // order, so consecutive tiles would give some workgroups only expensive (binary) tiles and others only
+    // cheap ones; strided, every workgroup gets its share of both and they finish together.
+    // (Only when the launch is a single occupancy round; with several rounds the slots never idle and
+    //  contiguous tiles are faster -- measured 84 vs 94 us at 64 walkers.)
+    const bool strided = tiles_per_block < 0;
+    if (strided) tiles_per_block = -tiles_per_block;
+    const int tile0 = strided ? group : group * tiles_per_block, tile_step = strided ? n_groups : 1;
+    STAMP(0);
+    int i = tile0 * 256 + tid;
+    int il = i < st.n_pad ? i : st.n_pad - 1;
+    double m1 = st.mass1[il], q = st.q[il], ea = st.ea[il];
+    // this wave's LDS stage for the tile's observations (behind the mass columns)
+    double *const stage_w = smem + (size_t)(2 * NPOPS) * mass_cap + 8 + (size_t)(tid >> 6) * ((2 * NFP + 1) * 64);
+    if (B9_LDS_STAGE(NFP) && tile0 * 256 < st.n_pad) stage_tile<NFP>(st, tile0 * 256 + (tid & ~63), stage_w);
+    const size_t rows = (size_t)W * NPOPS;
+    const size_t cb0 = (size_t)(sd.set * 2) * rows + (size_t)w * NPOPS;      // candidate 0; candidate 1 is `rows` further
+    double *const lds_mass = smem;
+    // The 2 * NPOPS mass columns are contiguous in LDS, so flat element f of the copy lands at lds2[f].
+    // The first FR * 256 elements travel through registers: their loads are issued HERE, before the
+    // decision's partial sums are requested, and written to LDS after it -- one memory round trip
+    // for everything instead of two.
+    constexpr int FR = 4;
+    const int half = mass_cap / 2, total2 = 2 * NPOPS * half;
+    double2 *const lds2 = reinterpret_cast<double2 *>(lds_mass);
+    auto src2 = [&](int f) -> const double2 * {
+        const int c = f / half, j = f - c * half;
+        return reinterpret_cast<const double2 *>(sd.cand_iso + (cb0 + (size_t)(c / NPOPS) * rows + (c % NPOPS)) * sd.iso_stride) + j;
+    };
+    double2 fr[FR];
+#pragma unroll
+    for (int k = 0; k < FR; ++k) {
+        const int f = tid + k * 256;
+        fr[k] = f < total2 ? *src2(f) : double2{0.0, 0.0};
+    }
+    IsoHdr h[2][NPOPS];
+    double pmod[2], pav[2], plam[2];
+#pragma unroll
+    for (int cand = 0; cand < 2; ++cand) {
+#pragma unroll
+        for (int kp = 0; kp < NPOPS; ++kp) h[cand][kp] = sd.cand_hdr[cb0 + (size_t)cand * rows + kp];
+        const double *par = sd.cand_par + ((size_t)(sd.set * 2 + cand) * W + w) * B9_NPARAM;
+        pmod[cand] = par[B9_P_MOD]; pav[cand] = par[B9_P_ABS]; plam[cand] = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+    }
+    double lp_new;
+    STAMP(1);
+    const int sel = step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0;
+    STAMP(2);
+#pragma unroll
+    for (int k = 0; k < FR; ++k) {
+        const int f = tid + k * 256;
+        if (f < total2) lds2[f] = fr[k];
+    }
+    for (int f = tid + FR * 256; f < total2; f += 256) lds2[f] = *src2(f);     // very long isochrones only
+    __syncthreads();                                     // the LDS mass columns
+    STAMP(3);
+    IsoView<NFP> iso[NPOPS];
+    bool valid = true;
+    double tip_min = __builtin_inf();
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        const IsoHdr hh = sel ? h[1][kp] : h[0][kp];
+        valid = valid && hh.valid;
+        iso[kp].n = hh.n; iso[kp].tip = hh.agb_tip;
+        iso[kp].i_feh = hh.i_feh; iso[kp].i_y = hh.i_y; iso[kp].t_feh = hh.t_feh; iso[kp].t_y = hh.t_y;
+        iso[kp].mass = lds_mass + (size_t)(sel * NPOPS + kp) * mass_cap;
+        iso[kp].mags = sd.cand_iso + (cb0 + (size_t)sel * rows + kp) * sd.iso_stride + mass_cap;
+        tip_min = hh.agb_tip < tip_min ? hh.agb_tip : tip_min;
+    }
+    const double mod = sel ? pmod[1] : pmod[0], av = sel ? pav[1] : pav[0], lam = sel ? plam[1] : plam[0];
+    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+
+    MixAcc acc;
+    acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;         // = 1.0
+    for (int t = 0; t < tiles_per_block; ++t) {
+        if ((tile0 + t * tile_step) * 256 >= st.n_pad) break;
+#ifndef B9_NO_TILE_PREFETCH
+        // the NEXT tile's star scalars are requested before this tile's arithmetic: one memory round
+        // trip less on every tile after the first, for 6 VGPRs
+        const int i_n = (tile0 + (t + 1) * tile_step) * 256 + tid;
+        const int il_n = i_n < st.n_pad ? i_n : st.n_pad - 1;
+        const double m1_n = st.mass1[il_n], q_n = st.q[il_n], ea_n = st.ea[il_n];
+#else
+        if (t > 0) {
+            i = (tile0 + t * tile_step) * 256 + tid;
+            il = i < st.n_pad ? i : st.n_pad - 1;
+            m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
+        }
+#endif
+        if (valid && i < st.n_pad && !(m1 > tip_min)) {   // empty slots hold m1 = +inf
+            const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, il,
+                                                  B9_LDS_STAGE(NFP) ? stage_w + (tid & 63) : nullptr, log_lam, log_1ml);
+            mix_add(acc, ea, l);
+        }
+#ifndef B9_NO_TILE_PREFETCH
+        i = i_n; il = il_n; m1 = m1_n; q = q_n; ea = ea_n;
+#endif
+        if (B9_LDS_STAGE(NFP) && t + 1 < tiles_per_block && (tile0 + (t + 1) * tile_step) * 256 < st.n_pad) {
+            // the next tile's observations: every lane of this wave has consumed the current ones (their
+            // ds_reads have returned -- the chi^2 used them), so the stage can be overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage_tile<NFP>(st, (tile0 + (t + 1) * tile_step) * 256 + (tid & ~63), stage_w);
+        }
+    }
+    STAMP(7);
+    const double tot = mix_wave_total(acc);
+    if ((tid & 63) == 0)
+        sd.partial[(size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) + group * 4 + (tid >> 6)] = valid ? tot : 0.0;
+    STAMP(8);
+}
+
+// Candidate-derivation role (and, for candidate 0 / population 0 / part 0 of each walker, the
+// WRITER of the new state and of the chain record).
+__device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd, const DevPriors &pr,
+                                            int w, int cand, int pop, int part, int parts)
+{
+    const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers, n_pops = sd.n_pops;
+    __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_prop[B9_NPARAM];
+    const AxisRegs axr = preload_axis(pk);                 // first round trip, needs no parameter
+    // everything the role reads before the isochrone tables is requested now, in one round trip
+    const double *in = step_state_in(sd, w);
+    const double cur_v = tid < B9_NPARAM ? in[B9_ST_CUR + tid] : 0.0;
+    const double prev_prop_v = tid < B9_NPARAM ? in[B9_ST_PROP + tid] : 0.0;
+    const size_t rows = (size_t)W * n_pops;
+    const double pc0 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 0) * W + w) * B9_NPARAM + tid] : 0.0;
+    const double pc1 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 1) * W + w) * B9_NPARAM + tid] : 0.0;
+    bool v0 = true, v1 = true;
+    for (int k = 0; k < n_pops; ++k) {
+        v0 = v0 && sd.cand_hdr[(size_t)(sd.set * 2 + 0) * rows + (size_t)w * n_pops + k].valid;
+        v1 = v1 && sd.cand_hdr[(size_t)(sd.set * 2 + 1) * rows + (size_t)w * n_pops + k].valid;
+    }
+    double crow[11];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) crow[j] = (tid < d && j < d) ? sd.chol[tid * d + j] : 0.0;
+    const int fidx = tid < d ? sd.free_idx[tid] : 0;
+    {   // wave 3: the normals of step t+1 (Philox + Box-Muller), independent of every decision
+        const int j = tid - 192, n_pairs = (d + 1) >> 1;
+        if (j >= 0 && j < n_pairs) {
+            unsigned r[4];
+            const unsigned long long sn = sd.step + 1;
+            philox4x32((unsigned)sn, (unsigned)(sn >> 32), (unsigned)sd.walker_ids[w], (unsigned)j, sd.k0, sd.k1, r);
+            const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+            const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+            s_z[2 * j] = rad * cos(ang);
+            s_z[2 * j + 1] = rad * sin(ang);
+        }
+    }
+    double lp_new;
+    const bool ok = step_decide<false>(sd, w, lp_new);
+    if (tid < B9_NPARAM) {
+        s_cur[tid] = ok ? prev_prop_v : cur_v;             // state after step t-1
+        s_prop[tid] = ok ? pc1 : pc0;                      // the proposal THIS launch's star workgroups evaluate
+    }
+    const bool writer = (cand == 0 && pop == 0 && part == 0);
+    if (writer && tid == 0 && sd.has_prev)                 // publish the outcome for workgroups that start later
+        __hip_atomic_store(sd.decided + w, (sd.step << 1) | (ok ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (writer) {
+        double *out = sd.state + ((size_t)sd.set * W + w) * B9_STATE_STRIDE;
+        if (tid < B9_NPARAM) { out[B9_ST_CUR + tid] = s_cur[tid]; out[B9_ST_PROP + tid] = s_prop[tid]; }
+        if (tid == 0) {
+            out[B9_ST_LP] = lp_new;
+            const bool pv = ok ? v1 : v0;
+            out[B9_ST_LPRIOR] = pv ? log_prior_cluster(pr, s_prop, n_pops) : NEG_INF;
+            out[B9_ST_SEL] = ok ? 1.0 : 0.0;
+            {   // log u of the accept test of the proposal evaluated by THIS launch (draw index n_pairs of its step)
+                unsigned r[4];
+                philox4x32((unsigned)sd.step, (unsigned)(sd.step >> 32), (unsigned)sd.walker_ids[w], (unsigned)((d + 1) >> 1), sd.k0, sd.k1, r);
+                out[B9_ST_LOGU] = log(u01(r[0], r[1]));
+            }
+            if (sd.has_prev) {
+                if (ok) atomicAdd(sd.n_acc, 1ull);
+                if (sd.lps) sd.lps[(size_t)sd.row * W + w] = lp_new;
+            }
+        }
+        if (sd.has_prev && sd.samples && tid < d) sd.samples[((size_t)sd.row * W + w) * d + tid] = s_cur[fidx];
+    }
+    if (!sd.derive_next) return;
+    // candidate `cand` of step t+1:  base = state (step t rejected) or step t's proposal (accepted);
+    // row[free[i]] += sum_j chol[i][j] z_j  (j ascending, plain multiply-add -- as the host twin does)
+    if (tid < B9_NPARAM) s_par[tid] = cand ? s_prop[tid] : s_cur[tid];
+    double delta = 0.0;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) if (j < d) delta = delta + crow[j] * s_z[j];
+    __syncthreads();
+    if (tid < d) s_par[fidx] += delta;
+    __syncthreads();
+    const size_t cset = (size_t)((sd.set ^ 1) * 2 + cand);
+    if (pop == 0 && part == 0 && tid < B9_NPARAM) sd.cand_par[(cset * W + w) * B9_NPARAM + tid] = s_par[tid];
+    derive_iso_block(pk, s_par, pop, w * n_pops + pop, sd.cand_hdr + cset * rows, sd.cand_iso + cset * rows * sd.iso_stride,
+                     sd.iso_stride, sd.mass_cap, part, parts, axr);
+}
+
+// Grid: [heavy-star workgroups][one WRITER per walker][pad to 8][hot workgroups][derivation workgroups].
+// The writers lead so that the new state and the published decision exist early; the other
+// derivation workgroups trail the grid -- nobody in this launch waits for their output, so they
+// fill the slots the last hot workgroups leave free.  (B9_DERIVE_FIRST=1 puts them in front.)
+template <int NFP, int NPOPS>
+__global__ __launch_bounds__(256, (NPOPS == 2 && B9_K1_MIN_WAVES > B9_K1_MIN_WAVES_2POP) ? B9_K1_MIN_WAVES_2POP : B9_K1_MIN_WAVES)
+void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_per_block, int n_groups,
+                 int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int W = sd.n_walkers, n_heavy = W * heavy_parts, n_derive = W * 2 * NPOPS * derive_parts;
+    int b = blockIdx.x;
+    // role of this workgroup: 0 hot, 1 heavy, 2 derivation (index b within the role), 3 none (padding)
+    int role;
+    if (b < front_blocks) {
+        if (b < n_heavy) role = 1;
+        else {
+            b -= n_heavy;
+            if (derive_first) role = b < n_derive ? 2 : 3;
+            else if (b < W) { role = 2; b *= 2 * NPOPS * derive_parts; }       // the writer of walker b: (cand 0, pop 0, part 0)
+            else role = 3;
+        }
+    } else {
+        b -= front_blocks;
+        if (b < hot_blocks) role = 0;
+        else {                                                                  // trailing derivation workgroups (derive_first == 0)
+            b -= hot_blocks;
+            const bool writer = (b % (2 * NPOPS * derive_parts)) == 0;          // those already ran in front
+            role = (b < n_derive && !writer && sd.derive_next) ? 2 : 3;
+        }
+    }
+    if (role == 0) { step_hot<NFP, NPOPS>(pk, st, sd, b, tiles_per_block, n_groups, smem); return; }
+    if (role == 1) {
+        const int w = b / heavy_parts, part = b - w * heavy_parts;
+        double lp_new;
+        const int sel = step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0;
+        const size_t rows = (size_t)W * NPOPS, cs = (size_t)(sd.set * 2 + sel);
+        heavy_stars<NFP, NPOPS>(pk, st, sd.cand_hdr + cs * rows, sd.cand_iso + cs * rows * sd.iso_stride, sd.iso_stride,
+                                sd.mass_cap, sd.cand_par + cs * W * B9_NPARAM, w, part, heavy_parts,
+                                sd.partial + (size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) +
+                                    (size_t)n_groups * 4 + part,
+                                nullptr, smem);
+        return;
+    }
+    if (role == 2) {       // b = ((w * 2 + cand) * NPOPS + pop) * derive_parts + part
+        const int part = b % derive_parts; b /= derive_parts;
+        const int pop = b % NPOPS; b /= NPOPS;
+        step_derive(pk, sd, pr, b >> 1, b & 1, pop, part, derive_parts);
+    }
+}
+
+// the block's last decision: one workgroup per walker, writer role only
+__global__ __launch_bounds__(256) void k_mcmc_finish(DevPack pk, StepDev sd, DevPriors pr)
+{
+    step_derive(pk, sd, pr, blockIdx.x, 0, 0, 0, 1);
+}
+
+#ifdef B9_STAMPS
+extern "C" int b9_debug_read_stamps(unsigned long long *out, int n_waves)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * B9_NSTAMP * n_waves);
+}
+extern "C" int b9_debug_clear_stamps(void)
+{
+    static unsigned long long zeros[8192 * B9_NSTAMP];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof zeros);
+}
+#endif
+

@@ -1,0 +1,480 @@
+// b9_star_like.hip.h -- k_star_like: the given-mass star kernel -- hot (one lane per star) and heavy (WD branch) roles.
+// Part of the single translation unit b9_kernels.hip (included there, in this order); gfx950 only.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// k_star_like  (given-mass mode): the hot kernel.  One lane per star, MS/RGB branch only --
+// stars heavier than the walker's AGB tip (WD / NS-BH branch; two contiguous ranges because
+// stars are sorted by mass) are left to k_finalize so that pow/log10 and the WD tables do not
+// cost this kernel registers.
+//
+// Workgroup -> (star tile, walker) map is XCD-aware: workgroups are dealt round-robin over the 8
+// XCDs, so linear id L runs on XCD L % 8.  All walkers of one star tile are given ids with the
+// same L % 8 and consecutive L / 8: the tile's star data is fetched from HBM once into that
+// XCD's L2 and re-read from L2 by the other walkers.  (Placement affects speed only.)
+// ------------------------------------------------------------------------------------------
+#ifndef B9_K1_MIN_WAVES
+#define B9_K1_MIN_WAVES 3
+#endif
+#ifndef B9_K1_MIN_WAVES_2POP
+#define B9_K1_MIN_WAVES_2POP 2      // two populations: the loop-carried state pushes the body past 168 VGPRs
+#endif
+
+// Bracket of mass m in an LDS-resident mass column: the largest i in [0, n-2] with mass[i] <= m
+// (what the oracle's binary search returns -- the bracket is unique for a sorted column, so any
+// correct search yields the same i and hence bit-identical weights).  8-ary: every step issues 7
+// independent ds_reads and narrows the range eightfold, so a 400-point column takes 3 dependent
+// LDS round trips instead of the 9 of a binary search (measured: the binary search was 19 % of the
+// kernel's VALU instructions but 3.3 of its 20.5 us).
+__device__ __forceinline__ void find_bracket(const double *mass, int n, double m, int &lo_out, double &t_out)
+{
+    int lo = 0, len = n - 1;                 // the answer lies in [lo, lo + len)
+    while (len >= 8) {                       // 7 probes at lo + j*step, all inside the range (7*step < len)
+        const int step = len >> 3;
+        const double *p = mass + lo;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) c += (p[j * step] <= m) ? 1 : 0;
+        lo += c * step;
+        len = (c == 7) ? len - 7 * step : step;
+    }
+    {                                        // fewer than 8 candidates left: probe them all at once
+        const double *p = mass + lo;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) c += (j < len && p[j] <= m) ? 1 : 0;     // reads stay inside the column: lo + 7 <= n + 6 < capacity
+        lo += c;
+    }
+    const double a = mass[lo], d = mass[lo + 1] - a;
+#ifdef B9_EXACT_DIV
+    t_out = (d > 0.0) ? (m - a) / d : 0.0;
+#else
+    // (m - a) / d by a v_rcp_f64 seed, two Newton steps and a residual correction: within 1 ulp of
+    // the IEEE quotient (the weight is then off by <= 1e-16 relative -- seven orders inside the
+    // stated tolerance) at a third of the instructions and latency of the exact division sequence
+    const double num = m - a;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double tq = num * r;
+    tq = fma(fma(-d, tq, num), r, tq);
+    t_out = (d > 0.0) ? tq : 0.0;
+#endif
+    lo_out = lo;
+}
+
+#ifndef B9_EARLY_OBS
+#define B9_LATE_OBS 1        // measured: 20.3 us vs 22.3 us (early) on the 50k x 8 x 8 bench shape
+#endif
+#ifdef B9_LATE_OBS
+#define B9_OBS_ARGS const DevStars &st, int il, const double *stage
+#else
+#define B9_OBS_ARGS double c0, const double (&obs)[NFP], const double (&wgt)[NFP]
+#endif
+// -DB9_QUAD_PASS: filters in passes of four (rows + observations of a pass requested together).
+// Measured equal to the all-at-once form (20.7 vs 20.6 us) and only 5 VGPRs leaner -- the pressure
+// comes from the unrolled exp/log temporaries, not the row arrays -- so it is off by default.
+template <int NFP, int NPOPS>
+__device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP> (&iso)[NPOPS],
+                                           double mod, double av, double m1, double q,
+                                           B9_OBS_ARGS, double log_lam, double log_1ml)
+{
+#ifdef B9_ABL_NOBIN
+    const bool binary = false;
+#else
+    const bool binary = q > 0.0;
+#endif
+    const double m2 = q * m1;
+    double ll[2] = {0.0, 0.0};
+    // The population loop is deliberately NOT unrolled: unrolled, the compiler overlaps the two
+    // populations' row loads and transcendental temporaries and spills (324 B of scratch per lane,
+    // 5x slower per star-eval); rolled, the body keeps the single-population register footprint.
+    // The isochrone view is picked with wave-uniform selects.
+#pragma unroll 1
+    for (int k = 0; k < NPOPS; ++k) {
+        const double *is_mass = (NPOPS == 2 && k) ? iso[NPOPS - 1].mass : iso[0].mass;
+        const double *is_mags = (NPOPS == 2 && k) ? iso[NPOPS - 1].mags : iso[0].mags;
+        const int is_n = (NPOPS == 2 && k) ? iso[NPOPS - 1].n : iso[0].n;
+        int lo1, lo2 = 0;
+        double t1, t2 = 0.0;
+        const bool dark1 = !(m1 > 0.0) || m1 < is_mass[0];
+        const bool dark2 = !(m2 > 0.0) || m2 < is_mass[0];
+#ifdef B9_ABL_NOSEARCH
+        lo1 = (int)(m1 * 100.0) % (is_n - 1); t1 = m1 - (int)m1; lo2 = lo1 / 2; t2 = t1;
+#else
+        find_bracket(is_mass, is_n, m1, lo1, t1);
+        if (binary) find_bracket(is_mass, is_n, m2, lo2, t2);
+#endif
+        STAMP(4);
+        // two consecutive rows = 2*NFP contiguous doubles
+        const double2 *r1 = reinterpret_cast<const double2 *>(is_mags + (size_t)lo1 * NFP);
+        const double2 *r2 = reinterpret_cast<const double2 *>(is_mags + (size_t)lo2 * NFP);
+        double chi2 = 0.0;
+#if defined(B9_QUAD_PASS) && defined(B9_LATE_OBS)
+        // Passes of four filters.  Each pass requests its slice of the primary rows, of the secondary
+        // rows and of the observed magnitudes / weights TOGETHER (one round trip per pass, the same
+        // two round trips as the all-at-once form at 8 filters), so only a quarter of the row and
+        // observation registers are live at a time.
+#pragma unroll 1
+        for (int h = 0; h < NFP / 4; ++h) {
+            double2 a1[4], a2[4];
+            a1[0] = r1[2 * h]; a1[1] = r1[2 * h + 1]; a1[2] = r1[NFP / 2 + 2 * h]; a1[3] = r1[NFP / 2 + 2 * h + 1];
+            if (binary) { a2[0] = r2[2 * h]; a2[1] = r2[2 * h + 1]; a2[2] = r2[NFP / 2 + 2 * h]; a2[3] = r2[NFP / 2 + 2 * h + 1]; }
+            double o[4], wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = st.obs[(size_t)(4 * h + j) * st.n_pad + il];
+                wv[j] = st.w[(size_t)(4 * h + j) * st.n_pad + il];
+            }
+            double p[4];
+            p[0] = dark1 ? B9_MAG_NOFLUX : lerp(a1[0].x, a1[2].x, t1);
+            p[1] = dark1 ? B9_MAG_NOFLUX : lerp(a1[0].y, a1[2].y, t1);
+            p[2] = dark1 ? B9_MAG_NOFLUX : lerp(a1[1].x, a1[3].x, t1);
+            p[3] = dark1 ? B9_MAG_NOFLUX : lerp(a1[1].y, a1[3].y, t1);
+            if (binary) {
+                double s[4];
+                s[0] = dark2 ? B9_MAG_NOFLUX : lerp(a2[0].x, a2[2].x, t2);
+                s[1] = dark2 ? B9_MAG_NOFLUX : lerp(a2[0].y, a2[2].y, t2);
+                s[2] = dark2 ? B9_MAG_NOFLUX : lerp(a2[1].x, a2[3].x, t2);
+                s[3] = dark2 ? B9_MAG_NOFLUX : lerp(a2[1].y, a2[3].y, t2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s[j] - p[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = (p[j] + (mod + pk.abs_m1[4 * h + j] * av)) - o[j];
+                chi2 = fma(wv[j] * d, d, chi2);
+            }
+        }
+        const double c0 = st.c0[il];
+        STAMP(6);
+#else
+        double2 a1[NFP], a2[NFP];
+#pragma unroll
+        for (int j = 0; j < NFP; ++j) a1[j] = r1[j];
+        if (binary) {
+#pragma unroll
+            for (int j = 0; j < NFP; ++j) a2[j] = r2[j];
+        }
+        double p[NFP];
+#pragma unroll
+        for (int j = 0; j < NFP / 2; ++j) {
+            p[2 * j] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].x, a1[NFP / 2 + j].x, t1);
+            p[2 * j + 1] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].y, a1[NFP / 2 + j].y, t1);
+        }
+        STAMP(5);
+        if (binary) {
+#ifdef B9_COMBINE_UNROLL
+#pragma unroll B9_COMBINE_UNROLL
+#else
+#pragma unroll
+#endif
+            for (int j = 0; j < NFP / 2; ++j) {
+                const double s0 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].x, a2[NFP / 2 + j].x, t2);
+                const double s1 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].y, a2[NFP / 2 + j].y, t2);
+                p[2 * j] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s0 - p[2 * j]));
+                p[2 * j + 1] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s1 - p[2 * j + 1]));
+            }
+        }
+        STAMP(6);
+#ifdef B9_LATE_OBS
+        // observed magnitudes and weights are requested only now: they cost 32 VGPRs while live,
+        // and keeping them out of the search / row / combine phases buys a wave per SIMD
+        __builtin_amdgcn_sched_barrier(0);
+        double obs[NFP], wgt[NFP];
+        double c0;
+        if (stage) {
+            // the fused step stages this wave's observed magnitudes, weights and c0 in LDS with asynchronous
+            // global->LDS loads issued at the START of the tile (stage_tile): by now they have landed, so
+            // this phase costs LDS reads instead of a memory round trip
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int f = 0; f < NFP; ++f) { obs[f] = stage[f * 64]; wgt[f] = stage[(NFP + f) * 64]; }
+            c0 = stage[2 * NFP * 64];
+        } else {
+#pragma unroll
+            for (int f = 0; f < NFP; ++f) {
+                obs[f] = st.obs[(size_t)f * st.n_pad + il];
+                wgt[f] = st.w[(size_t)f * st.n_pad + il];
+            }
+            c0 = st.c0[il];
+        }
+#endif
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            const double d = (p[f] + (mod + pk.abs_m1[f] * av)) - obs[f];
+            chi2 = fma(wgt[f] * d, d, chi2);
+        }
+#endif
+        const double llk = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
+        if (k == 0) ll[0] = llk; else ll[1] = llk;
+    }
+    double l = ll[0];
+    if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[1]);
+    return l;       // log p_i L_i ; the field-star mixture is applied by the caller in product form
+}
+
+// Field-star mixture in PRODUCT form.  sum_i log(A_i + e^{l_i}) = log prod_i (A_i + e^{l_i}),
+// A_i = (1 - p_i) fsLike (a per-star constant staged at load): each star costs one exp and one
+// multiply; the running product is kept as (mantissa in [0.5,1), binary exponent) so it can neither
+// overflow nor underflow, and ONE log per wave turns it back into a sum.  Stars with A_i = 0
+// (certain members) or l_i > 600 (e^{l} would overflow; A_i is then negligible) contribute l_i
+// additively instead.
+struct MixAcc {
+    double mant;    // product of factors, renormalised
+    int expo;       // its binary exponent
+    double add;     // additive part
+};
+
+__device__ __forceinline__ void mix_add(MixAcc &a, double ea, double l)
+{
+#ifdef B9_ABL_NOMIX
+    const bool additive = true;
+#else
+    const bool additive = (ea == 0.0) || (l > 600.0);
+#endif
+    const double u = additive ? 1.0 : ea + exp_fast(l);
+    a.add += additive ? l : 0.0;
+    const double m = a.mant * u;
+    a.expo += __builtin_amdgcn_frexp_exp(m);
+    a.mant = __builtin_amdgcn_frexp_mant(m);
+}
+
+// per-star value for the diagnostic per-star output (library log: u may be < 1)
+__device__ __forceinline__ double mix_value(double ea, double l)
+{
+    return ((ea == 0.0) || (l > 600.0)) ? l : log(ea + exp_fast(l));
+}
+
+// wave-wide combine; result valid in lane 0:  log(prod) + sum(add)
+__device__ __forceinline__ double mix_wave_total(MixAcc a)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double m2 = __shfl_down(a.mant, o, 64);
+        const int e2 = __shfl_down(a.expo, o, 64);
+        const double d2 = __shfl_down(a.add, o, 64);
+        const double m = a.mant * m2;                      // both in [0.5, 1): product in [0.25, 1)
+        a.expo += e2 + __builtin_amdgcn_frexp_exp(m);
+        a.mant = __builtin_amdgcn_frexp_mant(m);
+        a.add += d2;
+    }
+    // mant in [0.5, 1): log(mant) = log_ge1(2 mant) - ln 2 (the lean log instead of the library one)
+    return (log_ge1(a.mant + a.mant) + (double)(a.expo - 1) * 0.693147180559945309417) + a.add;
+}
+
+// The stars the hot path skips -- primary heavier than the walker's AGB tip (SURVEY 8a row a7:
+// IFMR -> WD cooling -> WD atmosphere, or NS/BH) -- are evaluated by extra workgroups of the SAME
+// launch, through the general per-star code.  Because stars are also indexed by descending mass
+// (heavy_mass / heavy_slot), that set is a prefix whose length each heavy workgroup finds with a
+// 256-ary search (two rounds for 50k stars).  The WD axes are staged in LDS.  `parts` workgroups
+// share a walker's heavy stars; each writes one partial.
+template <int NFP, int NPOPS>
+__device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *__restrict__ hdr,
+                                         const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
+                                         const double *__restrict__ params, int w, int part, int parts,
+                                         double *__restrict__ out_partial, double *__restrict__ perstar, double *smem)
+{
+    const int tid = threadIdx.x;
+    int *s_cnt = reinterpret_cast<int *>(smem);         // 4 ints
+    double *s_red = smem + 2;                            // 4 doubles
+    double *s_axes = smem + 8;
+    const double *par = params + (size_t)w * B9_NPARAM;
+    IsoView<NFP> iso[NPOPS];
+    double tip_min;
+    const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
+    if (!valid) { if (tid == 0) *out_partial = 0.0; return; }
+    int lo = 0, hi = st.n;                               // count = first k with heavy_mass[k] <= tip_min
+    while (lo < hi) {
+        const int span = hi - lo, step = (span + 255) / 256;
+        const int p = lo + tid * step;
+        const bool above = (p < hi) && (st.heavy_mass[p] > tip_min);
+        const int c = block_count(above, s_cnt);
+        if (c == 0) { hi = lo; }
+        else { const int nlo = lo + (c - 1) * step + 1, nhi = lo + c * step; lo = nlo; hi = nhi < hi ? nhi : hi; }
+    }
+    const int count = lo;
+    double acc = 0.0;
+    if (count > 0) {
+        WdAxes ax[NPOPS];
+        const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1;
+        double *d = s_axes;
+        const double *src[6] = {pk.log_age, pk.wc_log_age, pk.wc_mass, pk.wc_carb, pk.at_log_teff, pk.at_logg};
+        const int len[6] = {na, pk.n_wc_age, pk.n_wc_mass, pk.n_wc_carb, pk.n_at_teff, pk.n_at_logg};
+        const double *dst[6];
+        for (int a = 0; a < 6; ++a) {
+            dst[a] = d;
+            for (int j = tid; j < len[a]; j += 256) d[j] = src[a][j];
+            d += len[a];
+        }
+        for (int kp = 0; kp < NPOPS; ++kp)               // each population brackets (FeH, Y) on its own
+            for (int c = 0; c < 4; ++c) {
+                const int df = c >> 1, dy = c & 1;
+                const double *tips = pk.tips + (size_t)((iso[kp].i_feh + df) * pk.n_y + (iso[kp].i_y + (dy < ny ? dy : 0))) * na;
+                for (int j = tid; j < na; j += 256) d[j] = tips[j];
+                ax[kp].tips[c] = d;
+                d += na;
+            }
+        __syncthreads();
+        for (int kp = 0; kp < NPOPS; ++kp) {
+            ax[kp].log_age = dst[0]; ax[kp].wc_log_age = dst[1]; ax[kp].wc_mass = dst[2]; ax[kp].wc_carb = dst[3];
+            ax[kp].at_log_teff = dst[4]; ax[kp].at_logg = dst[5];
+        }
+        const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+        const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+        for (int j = part * 256 + tid; j < count; j += parts * 256) {
+            const int i = st.heavy_slot[j];
+            const double v = star_value<NFP, NPOPS>(pk, ax, iso, par, st, i, log_lam, log_1ml);
+            if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
+            acc += v;
+        }
+    }
+    const double sum = wave_sum(acc);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) *out_partial = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+template <int NFP, int NPOPS, int WB>
+__global__ __launch_bounds__(256, (NPOPS == 2 && B9_K1_MIN_WAVES > B9_K1_MIN_WAVES_2POP) ? B9_K1_MIN_WAVES_2POP : B9_K1_MIN_WAVES) void k_star_like(DevPack pk, DevStars st,
+                                                    const IsoHdr *__restrict__ hdr,
+                                                    const double *__restrict__ iso_data,
+                                                    long long iso_stride, int mass_cap,
+                                                    const double *__restrict__ params, int n_walkers,
+                                                    double *__restrict__ partial, long long partial_stride, int n_groups,
+                                                    double *__restrict__ perstar, int tiles_per_block,
+                                                    int hot_blocks, int heavy_parts)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // Heavy-star workgroups come FIRST in the grid (hot_blocks = their padded count): they have the
+    // longest dependent chain, so they must start at once and run beside the hot workgroups.
+    if ((int)blockIdx.x < hot_blocks) {        // hot_blocks doubles as "first hot workgroup id"
+        const int hb = blockIdx.x;
+        if (hb >= n_walkers * heavy_parts) return;            // padding to a multiple of 8
+        const int w = hb / heavy_parts, part = hb - w * heavy_parts;
+#ifndef B9_ABL_NO_HEAVY
+        heavy_stars<NFP, NPOPS>(pk, st, hdr, iso_data, iso_stride, mass_cap, params, w, part, heavy_parts,
+                                partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part, perstar, smem);
+#else
+        if (threadIdx.x == 0) partial[(size_t)w * partial_stride + (size_t)n_groups * 4 + part] = 0.0;   // ablation build
+#endif
+        return;
+    }
+    // LDS: the mass column of each (walker, population) isochrone this workgroup evaluates -- the binary search runs in LDS (dependent ds_reads
+    // instead of dependent L2 round trips); the magnitude rows a star needs are then read from L2
+    // (coalesced: stars are sorted by mass, so neighbouring lanes hit the same or adjacent rows).
+    // A lane keeps its star in registers and evaluates it for WB walkers in turn, so the star data
+    // crosses the L2 -> CU fabric once per WB walkers.
+    const int tid = threadIdx.x;
+    STAMP(0);
+    const int n_wsets = (n_walkers + WB - 1) / WB;
+    const int L = blockIdx.x - hot_blocks, xcd = L & 7, s = L >> 3;      // hot_blocks is a multiple of 8
+    const int wset = s % n_wsets, w0 = wset * WB;
+    const int group = (s / n_wsets) * 8 + xcd;          // tile group = tiles_per_block consecutive tiles
+    if (group >= n_groups) return;
+    const int nwb = (n_walkers - w0) < WB ? (n_walkers - w0) : WB;   // walkers in this set
+    const int tile0 = group * tiles_per_block;
+
+    // ---- first round trip: everything that depends only on the kernel arguments ------------
+    int i = tile0 * 256 + tid;
+    int il = i < st.n_pad ? i : st.n_pad - 1;               // stay inside the padded arrays
+    double m1, q, ea;
+#ifndef B9_LATE_OBS
+    double obs[NFP], wgt[NFP], c0;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) {
+        obs[f] = st.obs[(size_t)f * st.n_pad + il];
+        wgt[f] = st.w[(size_t)f * st.n_pad + il];
+    }
+    c0 = st.c0[il];
+#endif
+    m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
+    // the mass columns: the source address needs no header field, and copying the full capacity
+    // instead of hdr.n entries costs nothing (the tail is never searched)
+    double *const lds_mass = smem;
+    for (int c = 0; c < nwb * NPOPS; ++c) {
+        const double2 *sm = reinterpret_cast<const double2 *>(iso_data + (size_t)(w0 * NPOPS + c) * iso_stride);
+        double2 *dm = reinterpret_cast<double2 *>(lds_mass + (size_t)c * mass_cap);
+        for (int j = tid; j < mass_cap / 2; j += 256) dm[j] = sm[j];
+    }
+    // headers and the few parameters the star loop needs (scalar loads, same round trip)
+    IsoView<NFP> iso[WB][NPOPS];
+    bool valid[WB];
+    double tip_min[WB], mod[WB], av[WB], log_lam[WB], log_1ml[WB];
+#pragma unroll
+    for (int b = 0; b < WB; ++b) {
+        const int w = (b < nwb) ? w0 + b : w0;
+        const double *par = params + (size_t)w * B9_NPARAM;
+        bool ok = b < nwb;
+        double tmin = __builtin_inf();
+#pragma unroll
+        for (int kp = 0; kp < NPOPS; ++kp) {
+            const IsoHdr h = hdr[w * NPOPS + kp];
+            ok = ok && h.valid;
+            iso[b][kp].n = h.n; iso[b][kp].tip = h.agb_tip;
+            iso[b][kp].i_feh = h.i_feh; iso[b][kp].i_y = h.i_y; iso[b][kp].t_feh = h.t_feh; iso[b][kp].t_y = h.t_y;
+            iso[b][kp].mass = lds_mass + (size_t)(b * NPOPS + kp) * mass_cap;
+            iso[b][kp].mags = iso_data + (size_t)(w * NPOPS + kp) * iso_stride + mass_cap;
+            tmin = h.agb_tip < tmin ? h.agb_tip : tmin;
+        }
+        valid[b] = ok; tip_min[b] = tmin;
+        mod[b] = par[B9_P_MOD]; av[b] = par[B9_P_ABS];
+        const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+        log_lam[b] = NPOPS == 2 ? log(lam) : 0.0;
+        log_1ml[b] = NPOPS == 2 ? log1p(-lam) : 0.0;
+    }
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+
+    MixAcc acc[WB];
+#pragma unroll
+    for (int b = 0; b < WB; ++b) { acc[b].mant = 0.5; acc[b].expo = 1; acc[b].add = 0.0; }   // = 1.0
+    for (int t = 0; t < tiles_per_block; ++t) {
+        if ((tile0 + t) * 256 >= st.n_pad) break;
+        if (t > 0) {
+            i = (tile0 + t) * 256 + tid;
+            il = i < st.n_pad ? i : st.n_pad - 1;
+#ifndef B9_LATE_OBS
+#pragma unroll
+            for (int f = 0; f < NFP; ++f) {
+                obs[f] = st.obs[(size_t)f * st.n_pad + il];
+                wgt[f] = st.w[(size_t)f * st.n_pad + il];
+            }
+            c0 = st.c0[il];
+#endif
+            m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
+        }
+        STAMP(3);
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+            if (b >= nwb) continue;
+            const int w = w0 + b;
+            if (!valid[b]) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
+                if (perstar && i < st.n_pad && st.perm[i] >= 0) perstar[(size_t)w * st.n + st.perm[i]] = NEG_INF;
+                continue;
+            }
+            if (i < st.n_pad && !(m1 > tip_min[b])) {     // empty slots hold m1 = +inf
+#ifdef B9_LATE_OBS
+                const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, st, il, nullptr, log_lam[b], log_1ml[b]);
+#else
+                const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, c0, obs, wgt, log_lam[b], log_1ml[b]);
+#endif
+                mix_add(acc[b], ea, l);
+                if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = mix_value(ea, l);
+            }
+        }
+    }
+    STAMP(7);
+    // wave combine (one log per wave and walker); every wave stores its own partial -- no
+    // end-of-kernel barrier, so a cheap (single-star) wave never waits for an expensive one
+#pragma unroll
+    for (int b = 0; b < WB; ++b) {
+        const double tot = mix_wave_total(acc[b]);
+        if ((tid & 63) == 0 && b < nwb)
+            partial[(size_t)(w0 + b) * partial_stride + group * 4 + (tid >> 6)] = valid[b] ? tot : 0.0;
+    }
+    STAMP(8);
+}
+
