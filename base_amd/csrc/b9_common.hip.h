@@ -98,7 +98,11 @@ __device__ __forceinline__ double exp_fast(double x)
 }
 
 // log(1 + exp(x)), any x (x = -inf gives 0)
+#ifdef B9_ABL_CHEAP_L1PE      // ablation build only: what the flux combine's exp + log cost (results are wrong)
+__device__ __forceinline__ double log1pexp(double x) { return fma(x, 0.01, 0.3); }
+#else
 __device__ __forceinline__ double log1pexp(double x) { return log_ge1(1.0 + exp_fast(x)); }
+#endif
 
 __device__ __forceinline__ double logaddexp(double a, double b)
 {
