@@ -39,9 +39,11 @@ MCMC_BLOCK = 100       # steps between adaptation points (= between all-gathers)
 TIMING_EVERY = 25       # HIP-event bracket on every 25th launch of the dominant kernel in the timed region (a bracket costs ~5 us of stream time)
 
 
-def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0):
+def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0, eng=None):
     """Time the CPU oracle on a bounded sample of the same workload (rank 0 only): all host cores
-    (OpenMP over stars, as the reference's thread pool [RECALL]) and one thread."""
+    (OpenMP over stars, as the reference's thread pool [RECALL]) and one thread.  With `eng`, the same
+    leg also reports BASELINE.json's second figure, |delta logPost| of the HIP path against that CPU
+    path, over 128 random in-grid parameter rows on the full 50k-star cluster."""
     import oracle
     from base_amd import abi, synth
     try:
@@ -72,7 +74,19 @@ def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0):
     v_all, reps, dt = timed(cores, budget_s / 2)
     v_one, reps1, dt1 = timed(1, budget_s / 2)
     best, best_cores = (v_all, cores) if v_all >= v_one else (v_one, 1)      # the CPU's best effort is the baseline
-    return {"value": best, "unit": "star-likelihood evals/s", "cores": best_cores, "kind": "port",
+    delta = None
+    if eng is not None:
+        import numpy as np
+        orc.lib.b9o_set_threads(cores)
+        rows = synth.walker_params(truth, 128, seed=4242, scale=1.0)      # a wide ball around the truth, all inside the grid
+        want = orc.logpost(rows)
+        got = np.concatenate([eng.logpost(rows[k:k + 32]) for k in range(0, 128, 32)])
+        fin = np.isfinite(want)
+        rel = np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))
+        delta = {"n_rows": 128, "n_finite": int(fin.sum()), "same_support": bool(np.array_equal(np.isfinite(got), fin)),
+                 "max_abs": float(np.max(np.abs(got[fin] - want[fin]))), "max_rel": float(rel.max()), "median_rel": float(np.median(rel)),
+                 "tolerance_rel": 1e-9, "against": "this repo's CPU oracle on all host cores (BASE-9 parity unpinned)"}
+    return {"delta_logpost": delta, "value": best, "unit": "star-likelihood evals/s", "cores": best_cores, "kind": "port",
             "value_all_cores": v_all, "host_cores": cores, "value_1thread": v_one,
             "sample": f"{reps} x logpost of {WALKERS_PER_GPU} walkers x {N_STARS} stars x {N_FILT} filters on {cores} "
                       f"OpenMP thread(s) ({dt:.1f} s) and {reps1} x on 1 thread ({dt1:.1f} s); oracle/b9_oracle.c "
@@ -208,7 +222,7 @@ def main():
             "parity": "vs this repo's CPU oracle (BASE-9 parity unpinned: reference source not mounted)",
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pack_d, cl, truth)
+            out["cpu_baseline"] = cpu_baseline(pack_d, cl, truth, eng=eng)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1:
             out["marginalised_mode"] = marginalised_leg(pack, stars, priors, truth, local_rank)
