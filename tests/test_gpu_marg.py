@@ -45,3 +45,23 @@ def test_marginalised_mcmc_block_runs():
     s.initialise(eng.logpost)
     s.run(60)
     assert np.all(np.isfinite(s.all_logpost)) and s.accepted > 0
+
+
+@pytest.mark.parametrize("n_pops", [1, 2])
+def test_marginalised_device_block_matches_host_twin(n_pops):
+    """The two-launch sampler step (what marginalised mode runs) against the host twin driving the same
+    marginalised log-posterior: same chain."""
+    from base_amd import engine, mcmc
+    pack_d, cl, pack, stars, priors, _ = build_problem("dsed", 5, n_stars=120, wd_frac=0.05, n_y=3 if n_pops == 2 else 1,
+                                                       n_pops=n_pops, n_feh=3, n_age=5, n_eep=40, seed=6)
+    eng = engine.Engine(pack, stars, priors, abi.make_options(abi.MODE_MARGINALISED, n_pops, 2, 3))
+    free = np.array([abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS] + ([abi.P_Y, abi.P_Y2, abi.P_LAMBDA] if n_pops == 2 else []))
+    chol = np.diag([5e-4, 3e-3, 1e-3, 1e-3] + ([4e-4, 4e-4, 3e-3] if n_pops == 2 else []))
+    start = synth.walker_params(cl["truth"], 5, seed=2, scale=0.1, n_pops=n_pops)
+    lp0 = eng.logpost(start)
+    host = mcmc.HostBlockRunner(eng.logpost).run(start, lp0, np.arange(5), free, chol, 21, 500, 15)
+    dev = mcmc.DeviceBlockRunner(eng).run(start, lp0, np.arange(5), free, chol, 21, 500, 15)
+    assert dev[4] == host[4] and 0 < dev[4] < 75
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
+    np.testing.assert_allclose(dev[1], oracle.Oracle(pack, stars, priors, abi.make_options(abi.MODE_MARGINALISED, n_pops, 2, 3)).logpost(dev[0]), rtol=1e-9)
