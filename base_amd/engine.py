@@ -145,6 +145,9 @@ class Engine:
     def bytes_per_star_eval(self) -> int:
         return int(self.lib.b9_bytes_per_star_eval(self._ctx))
 
+    def device_id(self) -> int:
+        return int(self.lib.b9_device_id(self._ctx))
+
     def max_eep(self) -> int:
         return int(self.lib.b9_max_eep(self._ctx))
 

@@ -180,3 +180,39 @@ def test_parameters_exactly_on_grid_nodes_and_edges(name, n_filt, n_y, n_pops):
     got = eng2.logpost(p[None, :], perstar=True)
     want = oracle.Oracle(pack, st2, priors, options).logpost(p[None, :], perstar=True)
     assert _err(got[1], want[1]) <= 1e-9 and _err(got[0], want[0]) <= 1e-9
+
+
+_DEVICE_PTR_SCRIPT = r"""
+import sys
+sys.path.insert(0, "tests")
+import numpy as np, torch
+torch.cuda.init()                      # torch's HIP runtime first: the process must hold ONE copy of libamdhip64
+from base_amd import abi, engine, synth
+from conftest import build_problem
+pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=500, wd_frac=0.05)
+eng = engine.Engine(pack, stars, priors, options)
+params = synth.walker_params(cl["truth"], 6, seed=3)
+params[5, abi.P_FEH] = pack_d["feh"][-1] + 1.0                       # one walker outside the grid
+want_lp, want_ps = eng.logpost(params, perstar=True)
+dev = torch.device("cuda", eng.device_id())
+stream = torch.cuda.Stream(device=dev)
+with torch.cuda.stream(stream):
+    d_par = torch.from_numpy(params).to(dev)
+    d_lp = torch.full((6,), 123.0, dtype=torch.float64, device=dev)
+    d_ps = torch.zeros((6, 500), dtype=torch.float64, device=dev)
+    eng.logpost_device(d_par.data_ptr(), 6, d_lp.data_ptr(), d_ps.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+assert np.array_equal(d_lp.cpu().numpy(), want_lp) and np.array_equal(d_ps.cpu().numpy(), want_ps)
+assert np.isneginf(want_lp[5]) and np.isfinite(want_lp[:5]).all()
+print("device-pointer path ok")
+"""
+
+
+def test_logpost_device_with_caller_buffers_and_stream():
+    """b9_logpost_device: parameters and outputs stay in HBM (caller's torch tensors) and the launches go on the
+    caller's stream -- the zero-copy form a multi-GPU driver hands straight to RCCL.  Runs in a child process
+    because torch must initialise its own HIP runtime before libbase9hip.so is loaded (as bench.py does)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DEVICE_PTR_SCRIPT], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "device-pointer path ok" in r.stdout, r.stdout + r.stderr
