@@ -58,6 +58,8 @@ struct b9_ctx {
     double *d_params = nullptr, *d_logpost = nullptr, *d_perstar = nullptr;
     size_t perstar_cap = 0;
     void *d_mcmc = nullptr;          // device state of b9_mcmc_run_block
+    double *h_lp = nullptr, *h_lp_dev = nullptr;   // b9_logpost: 8 log-posteriors in mapped pinned host memory (host / device view)
+    bool no_kernarg_rows = false;    // B9_NO_KERNARG_ROWS=1: always upload the rows with a copy
     void *h_stage = nullptr;         // its pinned host mirror (fused sampler step: one upload, one download per block)
     size_t mcmc_cap = 0, stage_cap = 0;
 
@@ -352,6 +354,7 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
     if (const char *s = getenv("B9_WALKERS_PER_LANE")) ctx->walkers_per_lane = atoi(s) >= 2 ? 2 : 1;
     if (const char *s = getenv("B9_DERIVE_PARTS")) ctx->derive_parts = atoi(s);
+    if (const char *s = getenv("B9_NO_KERNARG_ROWS")) ctx->no_kernarg_rows = atoi(s) != 0;
     if (const char *s = getenv("B9_DERIVE_ORDER")) ctx->derive_order = atoi(s);
     if (const char *s = getenv("B9_TWO_LAUNCH_STEPS")) ctx->two_launch_steps = atoi(s) != 0;
     *out = ctx;
@@ -368,6 +371,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
     void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_mcmc};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_lp) (void)hipHostFree(ctx->h_lp);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -554,7 +558,7 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
 // One log-posterior evaluation of rows that are already in buffer set 0's parameter rows (or in
 // d_params when that is a caller's device pointer): derive -> stars -> finalize.
 static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, double *d_logpost,
-                          double *d_perstar, hipStream_t stream)
+                          double *d_perstar, hipStream_t stream, const double *host_rows = nullptr)
 {
     const int n_pops = ctx->opt.n_pops;
     const Plan plan = make_plan(ctx, n_walkers, n_pops);
@@ -564,8 +568,12 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
     bf.params = d_params;
     const McmcDev off{};
     const B9Prev none{nullptr, 0, 0, nullptr, nullptr};
-    HIPCHK(ctx, b9k_derive_iso(ctx->pk, bf.params, n_walkers, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap,
-                               off, ctx->pr, none, stream));
+    if (host_rows)      // <= 8 rows travel in the kernel arguments: no upload
+        HIPCHK(ctx, b9k_derive_iso_rows(ctx->pk, host_rows, bf.params, n_walkers, n_pops, bf.hdr, bf.iso, ctx->iso_stride,
+                                        ctx->mass_cap, stream));
+    else
+        HIPCHK(ctx, b9k_derive_iso(ctx->pk, bf.params, n_walkers, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap,
+                                   off, ctx->pr, none, stream));
     rc = launch_stars(ctx, bf, n_walkers, d_perstar, plan, stream);
     if (rc) return rc;
     HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, partial_count(ctx, plan), ctx->st.n_pad, n_pops, bf.params, ctx->pr,
@@ -819,14 +827,28 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     (void)plan;
     rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)ctx->st.n_pad * n_walkers, out_perstar != nullptr);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
-    rc = b9_logpost_device(ctx, ctx->d_params, n_walkers, ctx->d_logpost, out_perstar ? ctx->d_perstar : nullptr, ctx->stream);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(out_logpost, ctx->d_logpost, sizeof(double) * n_walkers, hipMemcpyDeviceToHost, ctx->stream));
+    // The per-step call of a host-driven sampler (the reference's logPostStep) is latency: for up
+    // to 8 rows the parameters ride in the first launch's kernel arguments and the log-posteriors are written by
+    // k_finalize straight into pinned host memory mapped into the device -- no copy command in the stream at all.
+    if (!ctx->h_lp) {
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lp, sizeof(double) * 8, hipHostMallocMapped));
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_lp_dev, ctx->h_lp, 0));
+    }
+    const bool small = n_walkers <= 8 && !ctx->no_kernarg_rows;
+    if (small) {
+        rc = launch_logpost(ctx, ctx->d_params, n_walkers, ctx->h_lp_dev, out_perstar ? ctx->d_perstar : nullptr, ctx->stream, params);
+        if (rc) return rc;
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
+        rc = b9_logpost_device(ctx, ctx->d_params, n_walkers, ctx->d_logpost, out_perstar ? ctx->d_perstar : nullptr, ctx->stream);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(out_logpost, ctx->d_logpost, sizeof(double) * n_walkers, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (out_perstar)
         HIPCHK(ctx, hipMemcpyAsync(out_perstar, ctx->d_perstar, sizeof(double) * (size_t)n_walkers * ctx->st.n,
                                    hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (small) std::memcpy(out_logpost, ctx->h_lp, sizeof(double) * n_walkers);
     return B9_OK;
 }
 

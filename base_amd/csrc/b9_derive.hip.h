@@ -238,3 +238,24 @@ __global__ __launch_bounds__(256) void k_derive_iso(DevPack pk, double *__restri
     derive_iso_block(pk, par, pop, wp, hdr, iso_data, iso_stride, mass_cap, blockIdx.y, gridDim.y, axr);
 }
 
+
+// k_derive_iso_rows: the same derivation for up to 8 parameter rows that travel IN THE KERNEL ARGUMENTS
+// (a host-driven b9_logpost call then needs no upload of its own: one launch carries the data).  The
+// workgroup (pop 0, part 0) of every walker also stores the row in `params` for the launches that follow.
+struct HostRows { double v[8][B9_NPARAM]; };
+
+__global__ __launch_bounds__(256) void k_derive_iso_rows(DevPack pk, HostRows rows, double *__restrict__ params, int n_pops,
+                                                          IsoHdr *__restrict__ hdr, double *__restrict__ iso_data,
+                                                          long long iso_stride, int mass_cap)
+{
+    const int wp = blockIdx.x, w = wp / n_pops, pop = wp % n_pops, tid = threadIdx.x;
+    __shared__ double s_row[B9_NPARAM];
+    const AxisRegs axr = preload_axis(pk);
+    if (tid < B9_NPARAM) {
+        const double v = rows.v[w][tid];
+        s_row[tid] = v;
+        if (blockIdx.y == 0 && pop == 0) params[(size_t)w * B9_NPARAM + tid] = v;
+    }
+    __syncthreads();
+    derive_iso_block(pk, s_row, pop, wp, hdr, iso_data, iso_stride, mass_cap, blockIdx.y, gridDim.y, axr);
+}

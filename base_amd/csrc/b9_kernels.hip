@@ -39,6 +39,7 @@
 #include "b9_device.h"
 #include "b9_launch.h"
 #include <algorithm>
+#include <cstring>
 #include "../../include/base9_hip.h"
 
 #include "b9_common.hip.h"
@@ -83,6 +84,18 @@ hipError_t b9k_derive_iso(const DevPack &pk, double *d_params, int n_walkers, in
     hipLaunchKernelGGL(k_derive_iso, dim3(n_walkers * n_pops, gy), dim3(256), 0, stream,
                        pk, d_params, n_pops, hdr, iso_data, iso_stride, mass_cap, mc, pr,
                        prev.partial, prev.n_partial, prev.partial_stride, prev.hdr, prev.params);
+    return hipGetLastError();
+}
+
+hipError_t b9k_derive_iso_rows(const DevPack &pk, const double *host_rows, double *d_params, int n_walkers, int n_pops,
+                               IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap, hipStream_t stream)
+{
+    if (n_walkers < 1 || n_walkers > 8) return hipErrorInvalidValue;
+    HostRows rows{};
+    std::memcpy(rows.v, host_rows, sizeof(double) * B9_NPARAM * n_walkers);
+    const int gy = (mass_cap * (pk.nfp + 1) + 255) / 256;
+    hipLaunchKernelGGL(k_derive_iso_rows, dim3(n_walkers * n_pops, gy), dim3(256), 0, stream,
+                       pk, rows, d_params, n_pops, hdr, iso_data, iso_stride, mass_cap);
     return hipGetLastError();
 }
 

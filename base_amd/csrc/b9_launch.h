@@ -15,6 +15,10 @@ hipError_t b9k_derive_iso(const DevPack &pk, double *d_params, int n_walkers, in
                           IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap,
                           const McmcDev &mc, const DevPriors &pr, const B9Prev &prev, hipStream_t stream);
 
+// up to 8 HOST rows carried in the kernel arguments (no upload); also stored to d_params for the later launches
+hipError_t b9k_derive_iso_rows(const DevPack &pk, const double *host_rows, double *d_params, int n_walkers, int n_pops,
+                               IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap, hipStream_t stream);
+
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
                          const double *d_params, int n_walkers, int n_pops, int wb,
