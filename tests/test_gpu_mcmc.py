@@ -108,3 +108,19 @@ def test_fused_step_many_walkers_and_two_populations_several_rounds(monkeypatch)
     assert dev[4] == host[4] and dev[4] > 0
     np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
+
+
+def test_device_chain_is_bit_reproducible():
+    """No atomics on the data path, fixed summation orders, counter-based RNG: the same block run twice is the
+    same bits (also when several occupancy rounds let late workgroups take the published decision)."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=20000, wd_frac=0.03, small=False, seed=9)
+    eng = engine.Engine(pack, stars, priors, options)
+    free, chol = np.array(mcmc.DEFAULT_FREE), np.diag([5e-5, 3e-4, 1e-4, 1e-4])
+    start = synth.walker_params(cl["truth"], 16, seed=5, scale=0.05)
+    lp0 = eng.logpost(start)
+    a = eng.mcmc_run_block(start, lp0, np.arange(16), free, chol, 3, 0, 300)
+    b = eng.mcmc_run_block(start, lp0, np.arange(16), free, chol, 3, 0, 300)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert 0 < a[4] < 300 * 16
