@@ -79,8 +79,11 @@ __device__ __forceinline__ double gumbel(unsigned k0, unsigned k1, unsigned long
     return -log(-log(u01(r[0], r[1])));
 }
 
+#ifndef B9_MARG_MIN_WAVES
+#define B9_MARG_MIN_WAVES 3      // measured on 50k x 8 x 8, 6384 nodes: 2 waves/SIMD (209 VGPRs) 3.24e7 star-evals/s, 3 waves (168, the WD branch spills) 3.87e7, 4 waves 2.50e7
+#endif
 template <int NFP, int NPOPS, bool SAMPLE>
-__global__ __launch_bounds__(256) void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
+__global__ __launch_bounds__(256, B9_MARG_MIN_WAVES) void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                                                     const double *__restrict__ iso_data, long long iso_stride,
                                                     int mass_cap, const double *__restrict__ params,
                                                     double *__restrict__ vals, double *__restrict__ perstar,
