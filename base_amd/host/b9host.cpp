@@ -561,7 +561,7 @@ McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double
                 for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) m2[i * d + j] += dl[i] * (x[j] - mean[j]);
             }
             const double rate = (double)blk.n_accept / ((double)n * W);
-            scale *= step_scale_factor(rate);
+            scale = std::min(std::max(scale * step_scale_factor(rate), 1e-8), 1e8);     // stays finite whatever the acceptance does
             if (n_mom > 20.0 * d) {
                 std::vector<double> cov((size_t)d * d);
                 for (int i = 0; i < d * d; ++i) cov[i] = m2[i] / (n_mom - 1.0) * (2.38 * 2.38 / d);

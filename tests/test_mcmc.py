@@ -95,3 +95,17 @@ def test_two_ranks_match_one_rank(tmp_path):
         np.testing.assert_array_equal(r["chol"], one.chol)
         np.testing.assert_array_equal(r["all_params"], one.all_params)
         np.testing.assert_array_equal(r["all_logpost"], one.all_logpost)
+
+
+def test_step_scale_stays_finite_when_every_step_moves():
+    """A flat (or improper) posterior accepts everything: the global step scale must saturate, not overflow."""
+    class AlwaysMoves:
+        def run(self, params, logpost, ids, free, chol, seed, step0, n):
+            W, d = params.shape[0], len(free)
+            samples = params[None, :, free] + np.random.default_rng(step0).normal(size=(n, W, d)) * 1e-4
+            return params, logpost, samples, np.zeros((n, W)), n * W
+    start = np.tile(np.arange(abi.B9_NPARAM, dtype=float), (4, 1))
+    s = mcmc.WalkerSampler(start, AlwaysMoves(), block=20)
+    s.initialise(lambda p: np.zeros(len(p)))
+    s.run(20 * 1500)
+    assert s.scale == mcmc.SCALE_MAX and np.all(np.isfinite(s.chol))
