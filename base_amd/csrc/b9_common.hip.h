@@ -165,7 +165,7 @@ __device__ inline double log_prior_cluster(const DevPriors &pr, const double *__
             lp -= 0.5 * d * d / pr.var[k];
         }
     }
-    return lp;
+    return isfinite(lp) ? lp : NEG_INF;      // a NaN parameter is outside the support, as the oracle treats it
 }
 
 // block-wide sum of one int per thread (all threads get the result); blockDim.x = 256

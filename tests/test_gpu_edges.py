@@ -216,3 +216,22 @@ def test_logpost_device_with_caller_buffers_and_stream():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _DEVICE_PTR_SCRIPT], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "device-pointer path ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n_pops,mode", [(1, abi.MODE_GIVEN_MASS), (2, abi.MODE_GIVEN_MASS), (1, abi.MODE_MARGINALISED)])
+def test_non_finite_parameters_are_outside_the_support(n_pops, mode):
+    """NaN / +-inf / +-1e300 in any parameter: no hang, and the same verdict as the oracle (finite or -inf, never NaN)."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, _ = build_problem("dsed", 5, n_stars=300, wd_frac=0.1, n_y=3 if n_pops == 2 else 1, n_pops=n_pops, seed=4)
+    opt = abi.make_options(mode=mode, n_pops=n_pops, marg_iso_increm=2, marg_n_q=2)
+    eng, orc = engine.Engine(pack, stars, priors, opt), oracle.Oracle(pack, stars, priors, opt)
+    rows = []
+    for k in range(abi.B9_NPARAM):
+        for bad in (np.nan, np.inf, -np.inf, 1e300, -1e300):
+            r = cl["truth"].copy(); r[k] = bad; rows.append(r)
+    rows = np.array(rows)
+    got = np.concatenate([eng.logpost(rows[i:i + 20]) for i in range(0, len(rows), 20)])
+    want = orc.logpost(rows)
+    assert not np.isnan(got).any() and not np.isnan(want).any()
+    assert np.array_equal(np.isfinite(got), np.isfinite(want)) and np.isfinite(want).sum() >= 20
+    assert _err(got, want) <= 1e-9
