@@ -182,7 +182,9 @@ int build_stars(b9_ctx *ctx)
         double g = 0.0;
         for (int f = 0; f < nf; ++f) {
             double sig = h.sigma[(size_t)s * nf + f];
-            obs[(size_t)f * n_pad + i] = h.obs[(size_t)s * nf + f];
+            // an unused filter (sigma <= 0) carries weight 0; its observation is stored as 0 so that whatever the
+            // file holds there (99.999, NaN, ...) cannot turn 0 * d * d into NaN
+            obs[(size_t)f * n_pad + i] = sig > 0.0 ? h.obs[(size_t)s * nf + f] : 0.0;
             if (sig > 0.0) {
                 double var = sig * sig;
                 w[(size_t)f * n_pad + i] = 1.0 / var;
@@ -475,6 +477,14 @@ int b9_load_stars(b9_ctx *ctx, const b9_stars *s)
         if (!(s->filter_prior_max[f] > s->filter_prior_min[f])) return fail(ctx, B9_ERR_INVALID, "filter_prior_max must exceed filter_prior_min");
     for (size_t i = 0; i < n; ++i)
         if (!(s->clust_prior[i] > 0.0 && s->clust_prior[i] <= 1.0)) return fail(ctx, B9_ERR_INVALID, "clust_prior must be in (0, 1]");
+    // a filter in use (sigma > 0) needs a finite observation and a sigma whose 1/sigma^2 is finite; NaN sigmas
+    // are input errors, not "unused" (the .phot convention for unused is a negative sigma)
+    for (size_t i = 0; i < n * nf; ++i) {
+        const double sg = s->sigma[i];
+        if (std::isnan(sg)) return fail(ctx, B9_ERR_INVALID, "sigma is NaN (use a negative sigma for an unused filter)");
+        if (sg > 0.0 && (!(sg >= 1e-150) || std::isinf(sg) || !std::isfinite(s->obs[i])))
+            return fail(ctx, B9_ERR_INVALID, "a filter in use needs a finite observation and 1e-150 <= sigma < inf");
+    }
     h.n = (int)n; h.nf = (int)nf;
     h.obs.assign(s->obs, s->obs + n * nf);
     h.sigma.assign(s->sigma, s->sigma + n * nf);

@@ -235,3 +235,22 @@ def test_non_finite_parameters_are_outside_the_support(n_pops, mode):
     assert not np.isnan(got).any() and not np.isnan(want).any()
     assert np.array_equal(np.isfinite(got), np.isfinite(want)) and np.isfinite(want).sum() >= 20
     assert _err(got, want) <= 1e-9
+
+
+def test_load_stars_rejects_non_finite_photometry():
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 4, n_stars=20)
+    for mutate, text in ((lambda o, s: o.__setitem__(5, np.nan), "finite observation"), (lambda o, s: o.__setitem__(6, np.inf), "finite observation"),
+                         (lambda o, s: s.__setitem__(7, np.nan), "sigma is NaN"), (lambda o, s: s.__setitem__(8, 1e-300), "1e-150"),
+                         (lambda o, s: s.__setitem__(9, np.inf), "sigma < inf")):
+        c2 = dict(cl); o, s = np.array(cl["obs"], copy=True), np.array(cl["sigma"], copy=True)
+        mutate(o, s); c2["obs"], c2["sigma"] = o, s
+        with pytest.raises(RuntimeError) as e:
+            engine.Engine(pack, abi.make_stars(c2), priors, options)
+        assert text in str(e.value)
+    c2 = dict(cl); o, s = np.array(cl["obs"], copy=True), np.array(cl["sigma"], copy=True)
+    o[3] = np.nan; s[3] = -1.0                                              # an UNUSED filter may hold anything
+    c2["obs"], c2["sigma"] = o, s
+    st2 = abi.make_stars(c2)
+    got = engine.Engine(pack, st2, priors, options).logpost(cl["truth"][None, :])
+    assert np.isfinite(got[0]) and _err(got, oracle.Oracle(pack, st2, priors, options).logpost(cl["truth"][None, :])) <= 1e-9
