@@ -124,3 +124,21 @@ def test_device_chain_is_bit_reproducible():
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert 0 < a[4] < 300 * 16
+
+
+@pytest.mark.parametrize("n_stars", [1, 2, 63, 64, 65, 255, 256, 257, 511, 513])
+def test_fused_step_at_chunk_and_tile_boundaries(n_stars):
+    """Clusters of exactly / just under / just over one 64-star chunk and one 256-star tile (binaries and singles
+    are chunked separately, so these sizes exercise half-empty waves and all-empty tiles)."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("dsed", 5, n_stars=n_stars, wd_frac=0.1 if n_stars > 10 else 0.0, small=False, seed=n_stars)
+    eng = engine.Engine(pack, stars, priors, options)
+    free, chol = np.array(mcmc.DEFAULT_FREE), np.diag([3e-3, 2e-2, 8e-3, 6e-3])
+    start = synth.walker_params(cl["truth"], 3, seed=8, scale=0.1)
+    lp0 = eng.logpost(start)
+    np.testing.assert_allclose(lp0, oracle.Oracle(pack, stars, priors, options).logpost(start), rtol=1e-9)
+    host = mcmc.HostBlockRunner(eng.logpost).run(start, lp0, np.arange(3), free, chol, 5, 0, 12)
+    dev = mcmc.DeviceBlockRunner(eng).run(start, lp0, np.arange(3), free, chol, 5, 0, 12)
+    assert dev[4] == host[4]
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
