@@ -228,3 +228,45 @@ def test_samplemass_cli_matches_oracle(hostlib, tmp_path):
     assert safe.mean() > 0.98
     assert np.max(np.abs(ms[:, 0::2][safe] - om[safe])) < 2e-6 and np.max(np.abs(ms[:, 1::2][safe] - oq[safe])) < 1e-4
     assert np.max(np.abs(mb - omem)) < 1e-4
+
+
+def test_corrupted_input_files_are_rejected_or_read_never_crash(hostlib, tmp_path):
+    """Random damage to the photometry file and to every model file (truncation, cut lines, junk tokens and
+    lines, blanked lines, shuffled tokens): the readers either accept what is still a well-formed file or
+    return an error with a message."""
+    import random, shutil
+    pack_d = synth.make_pack("dsed", 4, n_feh=3, n_age=4, n_eep=30)
+    truth = synth.default_params(pack_d)
+    cl = synth.make_cluster(pack_d, 40, seed=3, truth=truth, wd_frac=0.1)
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    phot = synth.write_phot(cl, pack_d["filters"], str(tmp_path / "c.phot"))
+    filters = ",".join(pack_d["filters"]).encode()
+    files = [os.path.join(dp, f) for dp, _, fs in os.walk(root) for f in fs]
+    rng = random.Random(7)
+
+    def corrupt(path, out):
+        lines = open(path).read().split("\n")
+        k, i = rng.randrange(6), rng.randrange(len(lines))
+        if k == 0: lines = lines[:i]
+        elif k == 1: lines[i] = lines[i][: len(lines[i]) // 2]
+        elif k == 2: lines[i] = lines[i].replace(" ", " x ", 1)
+        elif k == 3: lines.insert(i, "nan inf -1e999 &&&")
+        elif k == 4: lines[i] = ""
+        else: lines[i] = " ".join(reversed(lines[i].split()))
+        open(out, "w").write("\n".join(lines))
+
+    rejected = 0
+    for _ in range(80):
+        out = str(tmp_path / "f.phot"); corrupt(phot, out)
+        h, view, buf = C.c_void_p(), abi.b9_stars(), C.create_string_buffer(4096)
+        rc = hostlib.b9h_read_phot(out.encode(), -1e300, 1e300, 0, C.byref(h), C.byref(view), buf, 4096)
+        if rc == 0: hostlib.b9h_free_phot(h)
+        else: rejected += 1; assert hostlib.b9h_last_error()
+        src = rng.choice(files)
+        r2 = str(tmp_path / "m2"); shutil.rmtree(r2, ignore_errors=True); shutil.copytree(root, r2)
+        corrupt(src, os.path.join(r2, os.path.relpath(src, root)))
+        h, pv = C.c_void_p(), abi.b9_pack()
+        rc = hostlib.b9h_load_pack(r2.encode(), b"dsed", b"montgomery", filters, C.byref(h), C.byref(pv))
+        if rc == 0: hostlib.b9h_free_pack(h)
+        else: rejected += 1; assert hostlib.b9h_last_error()
+    assert rejected > 40
