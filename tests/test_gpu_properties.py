@@ -67,3 +67,67 @@ def test_device_block_matches_host_twin_from_random_states(seed, step0, n_steps,
     assert dev[4] == host[4]
     np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
+
+
+def _ragged_pack(rng, n_filt, with_wd):
+    """A small random model pack with RAGGED isochrones: every (FeH, Y, age) isochrone has its own first EEP and
+    length, so corner EEP ranges intersect partially, barely (2 points) or not at all."""
+    base = synth.make_pack("girardi", n_filt, n_feh=2, n_age=2, n_eep=8)          # for the WD tables and coefficients
+    n_feh, n_y, n_age = int(rng.integers(2, 4)), int(rng.integers(1, 3)), int(rng.integers(2, 4))
+    feh = np.sort(rng.uniform(-2, 0.5, n_feh)) + np.arange(n_feh) * 0.05
+    y = np.sort(rng.uniform(0.23, 0.33, n_y)) + np.arange(n_y) * 0.01
+    log_age = np.sort(rng.uniform(8.0, 10.0, n_age)) + np.arange(n_age) * 0.05
+    first, cnt, off, mass, mags = [], [], [], [], []
+    for _ in range(n_feh * n_y * n_age):
+        f0, n = int(rng.integers(0, 4)), int(rng.integers(2, 14))
+        m = np.cumsum(rng.uniform(0.0, 0.4, n)) + rng.uniform(0.1, 0.3)           # non-descending, sometimes flat
+        first.append(f0); cnt.append(n); off.append(len(mass))
+        mass.extend(m)
+        mags.extend((12.0 - 6.0 * np.log10(m)[:, None] + rng.normal(0, 0.3, (n, n_filt)) + np.arange(n_filt) * 0.2).ravel())
+    d = dict(base)
+    d.update(feh=feh, y=y, log_age=log_age, iso_first_eep=np.array(first), iso_n_eep=np.array(cnt), iso_offset=np.array(off),
+             mass=np.array(mass), mags=np.array(mags), n_filt=n_filt)
+    if not with_wd:
+        for k in ("wc_carb", "wc_mass", "wc_log_age", "wc_log_teff", "wc_log_radius", "at_logg", "at_log_teff", "at_mags"):
+            d[k] = np.zeros(0)
+        d["n_at_type"] = 0
+    return d
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 10**6), n_filt=st.sampled_from([1, 3, 5, 8]), with_wd=st.booleans(), two_pops=st.booleans(),
+       marg=st.booleans())
+def test_ragged_random_packs_match_oracle(seed, n_filt, with_wd, two_pops, marg):
+    from base_amd import engine
+    rng = np.random.default_rng(seed)
+    pack_d = _ragged_pack(rng, n_filt, with_wd)
+    n_pops = 2 if (two_pops and len(pack_d["y"]) > 1) else 1
+    n = 150
+    sig = rng.uniform(0.02, 0.2, (n, n_filt)); sig[rng.random((n, n_filt)) < 0.15] = -1.0
+    cl = dict(n_filt=n_filt, obs=rng.uniform(8, 16, (n, n_filt)).ravel(), sigma=sig.ravel(), mass1=rng.uniform(0.05, 5.0, n),
+              mass_ratio=np.where(rng.random(n) < 0.4, rng.uniform(0, 1, n), 0.0), clust_prior=rng.uniform(0.05, 1.0, n),
+              stage=np.where(rng.random(n) < 0.1, abi.STAGE_WD, abi.STAGE_MSRG).astype(np.int32), wd_type=(rng.random(n) < 0.3).astype(np.int32),
+              filter_prior_min=np.full(n_filt, 7.0), filter_prior_max=np.full(n_filt, 17.0))
+    pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
+    priors = abi.make_priors(log_age_min=-1e9, log_age_max=1e9)
+    opt = abi.make_options(mode=abi.MODE_MARGINALISED if marg else abi.MODE_GIVEN_MASS, n_pops=n_pops, marg_iso_increm=2, marg_n_q=3)
+    rows = []
+    for _ in range(6):
+        r = np.zeros(abi.B9_NPARAM)
+        r[abi.P_LOGAGE] = rng.uniform(pack_d["log_age"][0] - 0.05, pack_d["log_age"][-1] + 0.05)
+        r[abi.P_FEH] = rng.uniform(pack_d["feh"][0] - 0.05, pack_d["feh"][-1] + 0.05)
+        r[abi.P_Y], r[abi.P_Y2] = rng.uniform(pack_d["y"][0], pack_d["y"][-1], 2)
+        r[abi.P_MOD], r[abi.P_ABS], r[abi.P_CARBONICITY] = rng.uniform(-1, 1), rng.uniform(0, 0.5), rng.uniform(0, 1)
+        r[abi.P_IFMR_INTERCEPT], r[abi.P_IFMR_SLOPE], r[abi.P_LAMBDA] = 0.77, 0.08, rng.uniform(0.05, 0.95)
+        rows.append(r)
+    rows = np.array(rows)
+    got, got_ps = engine.Engine(pack, stars, priors, opt).logpost(rows, perstar=True)
+    want, want_ps = oracle.Oracle(pack, stars, priors, opt).logpost(rows, perstar=True)
+    fin = np.isfinite(want_ps)
+    assert np.array_equal(np.isfinite(got_ps), fin) and not np.isnan(got_ps).any()
+    if fin.any():
+        assert np.max(np.abs(got_ps[fin] - want_ps[fin]) / np.maximum(1.0, np.abs(want_ps[fin]))) <= 1e-9
+    f = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), f)
+    if f.any():
+        assert np.max(np.abs(got[f] - want[f]) / np.maximum(1.0, np.abs(want[f]))) <= 1e-9
