@@ -131,3 +131,37 @@ def test_ragged_random_packs_match_oracle(seed, n_filt, with_wd, two_pops, marg)
     assert np.array_equal(np.isfinite(got), f)
     if f.any():
         assert np.max(np.abs(got[f] - want[f]) / np.maximum(1.0, np.abs(want[f]))) <= 1e-9
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 10**6), n_filt=st.sampled_from([3, 8]), two_pops=st.booleans(), scale=st.floats(0.3, 30.0))
+def test_sampler_on_ragged_packs_matches_host_twin(seed, n_filt, two_pops, scale):
+    """Large steps on a ragged grid: proposals keep falling where the corner isochrones share fewer than two EEPs
+    or outside the grid altogether -- invalid candidates must be rejected exactly as the host twin rejects them."""
+    from base_amd import engine
+    rng = np.random.default_rng(seed)
+    pack_d = _ragged_pack(rng, n_filt, True)
+    n_pops = 2 if (two_pops and len(pack_d["y"]) > 1) else 1
+    n = 200
+    cl = dict(n_filt=n_filt, obs=rng.uniform(8, 16, (n, n_filt)).ravel(), sigma=rng.uniform(0.05, 0.3, (n, n_filt)).ravel(),
+              mass1=rng.uniform(0.05, 5.0, n), mass_ratio=np.where(rng.random(n) < 0.4, rng.uniform(0, 1, n), 0.0),
+              clust_prior=rng.uniform(0.05, 1.0, n), stage=np.where(rng.random(n) < 0.1, abi.STAGE_WD, abi.STAGE_MSRG).astype(np.int32),
+              wd_type=(rng.random(n) < 0.3).astype(np.int32), filter_prior_min=np.full(n_filt, 7.0), filter_prior_max=np.full(n_filt, 17.0))
+    eng = engine.Engine(abi.make_pack(pack_d), abi.make_stars(cl), abi.make_priors(log_age_min=-1e9, log_age_max=1e9), abi.make_options(n_pops=n_pops))
+    W = 5
+    start = np.zeros((W, abi.B9_NPARAM))
+    start[:, abi.P_LOGAGE] = rng.uniform(pack_d["log_age"][0], pack_d["log_age"][-1], W)
+    start[:, abi.P_FEH] = rng.uniform(pack_d["feh"][0], pack_d["feh"][-1], W)
+    start[:, abi.P_Y] = rng.uniform(pack_d["y"][0], pack_d["y"][-1], W); start[:, abi.P_Y2] = rng.uniform(pack_d["y"][0], pack_d["y"][-1], W)
+    start[:, abi.P_MOD], start[:, abi.P_ABS], start[:, abi.P_LAMBDA] = 0.2, 0.1, 0.5
+    start[:, abi.P_IFMR_INTERCEPT], start[:, abi.P_IFMR_SLOPE] = 0.77, 0.08
+    free = np.array([abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS] + ([abi.P_Y, abi.P_Y2, abi.P_LAMBDA] if n_pops == 2 else []))
+    chol = np.diag([0.05, 0.1, 0.02, 0.02] + ([0.01, 0.01, 0.05] if n_pops == 2 else [])) * scale
+    lp0 = eng.logpost(start)
+    host = mcmc.HostBlockRunner(eng.logpost).run(start, lp0, np.arange(W), free, chol, seed, 7, 14)
+    dev = mcmc.DeviceBlockRunner(eng).run(start, lp0, np.arange(W), free, chol, seed, 7, 14)
+    assert dev[4] == host[4]
+    np.testing.assert_array_equal(np.isfinite(dev[3]), np.isfinite(host[3]))
+    fin = np.isfinite(host[3])
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[3][fin], host[3][fin], rtol=1e-10)
