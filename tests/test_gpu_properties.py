@@ -131,6 +131,13 @@ def test_ragged_random_packs_match_oracle(seed, n_filt, with_wd, two_pops, marg)
     assert np.array_equal(np.isfinite(got), f)
     if f.any():
         assert np.max(np.abs(got[f] - want[f]) / np.maximum(1.0, np.abs(want[f]))) <= 1e-9
+    if marg:       # the sampleMass draws on the same ragged grid
+        gm, gq, gmem, gpop = engine.Engine(pack, stars, priors, opt).sample_mass(rows[:3], seed=seed, row0=3)
+        om, oq, omem, opop, margin = oracle.Oracle(pack, stars, priors, opt).sample_mass(rows[:3], seed=seed, row0=3)
+        safe = margin > 1e-6
+        assert np.array_equal(gq[safe], oq[safe]) and np.array_equal(gpop[safe], opop[safe])
+        np.testing.assert_allclose(gm[safe], om[safe], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(gmem, omem, rtol=1e-8, atol=1e-300)
 
 
 @settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
