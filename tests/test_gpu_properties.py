@@ -172,3 +172,29 @@ def test_sampler_on_ragged_packs_matches_host_twin(seed, n_filt, two_pops, scale
     fin = np.isfinite(host[3])
     np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(dev[3][fin], host[3][fin], rtol=1e-10)
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 10**6), n_filt=st.sampled_from([1, 4, 8, 12]))
+def test_derived_isochrone_is_bit_exact_on_ragged_packs(seed, n_filt):
+    """b9_derive_isochrone (what makeCMD prints and every step uses) against the oracle, bit for bit, where the corner
+    isochrones' EEP ranges overlap fully, partly, by two points, or not at all."""
+    from base_amd import engine
+    rng = np.random.default_rng(seed)
+    pack_d = _ragged_pack(rng, n_filt, False)
+    pack = abi.make_pack(pack_d)
+    cl = dict(n_filt=n_filt, obs=np.full(n_filt, 10.0), sigma=np.full(n_filt, 0.1), mass1=np.array([1.0]), mass_ratio=np.array([0.0]),
+              clust_prior=np.array([0.9]), filter_prior_min=np.full(n_filt, 7.0), filter_prior_max=np.full(n_filt, 17.0))
+    eng = engine.Engine(pack, abi.make_stars(cl), abi.make_priors(), abi.make_options())
+    lib = oracle.load()
+    for _ in range(8):
+        r = np.zeros(abi.B9_NPARAM)
+        r[abi.P_LOGAGE] = rng.uniform(pack_d["log_age"][0] - 0.02, pack_d["log_age"][-1] + 0.02)
+        r[abi.P_FEH] = rng.uniform(pack_d["feh"][0] - 0.02, pack_d["feh"][-1] + 0.02)
+        r[abi.P_Y] = rng.uniform(pack_d["y"][0], pack_d["y"][-1]); r[abi.P_Y2] = rng.uniform(pack_d["y"][0], pack_d["y"][-1])
+        for pop in (0, 1):
+            g = eng.derive_isochrone(r, pop=pop, cap=64)
+            w = oracle.derive_isochrone(lib, pack, r, pop=pop, cap=64)
+            assert g[0] == w[0] and g[3] == w[3]
+            np.testing.assert_array_equal(g[1], w[1])
+            np.testing.assert_array_equal(g[2], w[2])
