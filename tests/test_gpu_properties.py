@@ -198,3 +198,32 @@ def test_derived_isochrone_is_bit_exact_on_ragged_packs(seed, n_filt):
             assert g[0] == w[0] and g[3] == w[3]
             np.testing.assert_array_equal(g[1], w[1])
             np.testing.assert_array_equal(g[2], w[2])
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 10**6), log_sig=st.floats(-6.0, 3.0), log_field=st.floats(-300.0, 2.0), marg=st.booleans())
+def test_extreme_likelihood_scales(seed, log_sig, log_field, marg):
+    """sigmas from 1e-6 to 1e3 mag (chi^2 up to ~1e14: exp underflow, the additive branch of the product-form
+    mixture when e^l would overflow) and field-star densities down to 1e-300: same values as the oracle."""
+    pack_d, cl0, _, _ = _setup(("parsec", 8, 1, 1, abi.MODE_GIVEN_MASS))
+    from base_amd import engine
+    rng = np.random.default_rng(seed)
+    cl = dict(cl0)
+    n = len(cl0["mass1"])
+    cl["sigma"] = (10.0 ** log_sig * rng.uniform(0.5, 2.0, (n, 8))).ravel()
+    width = 10.0 ** (-log_field / 8.0)                                    # box volume = width^8 -> field-star density 10^log_field
+    cl["filter_prior_min"], cl["filter_prior_max"] = np.full(8, 10.0), np.full(8, 10.0 + width)
+    pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
+    priors = synth.default_priors(pack_d, cl0["truth"])
+    opt = abi.make_options(mode=abi.MODE_MARGINALISED if marg else abi.MODE_GIVEN_MASS, marg_iso_increm=2, marg_n_q=2)
+    rows = synth.walker_params(cl0["truth"], 3, seed=seed % 97, scale=0.5)
+    got, got_ps = engine.Engine(pack, stars, priors, opt).logpost(rows, perstar=True)
+    want, want_ps = oracle.Oracle(pack, stars, priors, opt).logpost(rows, perstar=True)
+    assert not np.isnan(got_ps).any()
+    fin = np.isfinite(want_ps)
+    assert np.array_equal(np.isfinite(got_ps), fin)
+    assert np.max(np.abs(got_ps[fin] - want_ps[fin]) / np.maximum(1.0, np.abs(want_ps[fin]))) <= 1e-9
+    f = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), f)
+    if f.any():
+        assert np.max(np.abs(got[f] - want[f]) / np.maximum(1.0, np.abs(want[f]))) <= 1e-9
