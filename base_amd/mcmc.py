@@ -23,6 +23,8 @@ latency-bound, and amortised over `block` steps.
 """
 from __future__ import annotations
 
+import concurrent.futures
+
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -191,19 +193,13 @@ class WalkerSampler:
         self.all_logpost, self.all_params = rows[:, 0].copy(), rows[:, 1:].copy()
 
     def run_block(self, n_steps: Optional[int] = None):
+        """One block, unpipelined: execute, start the block's gather, consume the previous block's."""
         n = self.block if n_steps is None else n_steps
         self.params, self.logpost, samples, lps, n_acc = self.runner.run(
             self.params, self.logpost, self.ids, self.free, self.scale * self.chol, self.seed, self.step, n)
         self.step += n
         self.accepted += n_acc
-        # one row per local walker: [lp, full position, #moves, n, sum x, sum x x^T] over the block,
-        # x measured from the common origin x0 (the ensemble's starting mean) so that the pooled
-        # second moments do not cancel catastrophically
-        x = samples - self.x0                                     # [n, per, d]
-        moved = (np.abs(np.diff(samples, axis=0)).sum(axis=2) > 0).sum(axis=0)
-        row = np.concatenate([self.logpost[:, None], self.params, moved[:, None].astype(np.float64),
-                              np.full((self.per, 1), float(n)), x.sum(axis=0),
-                              self._second_moments(x)], axis=1)
+        row = self._make_row(samples, self.params, self.logpost, n)
         # THE collective of the block is started now and consumed after the NEXT block has run, so its
         # latency hides behind that block's GPU work: the proposal of block b+1 is adapted from the rows
         # of blocks <= b-1.  The lag is the same for every rank count (also for one rank), so chains
@@ -212,6 +208,15 @@ class WalkerSampler:
         if previous is not None:
             self._consume(*previous)
         return samples, lps
+
+    def _make_row(self, samples: np.ndarray, params_end: np.ndarray, logpost_end: np.ndarray, n: int) -> np.ndarray:
+        """One row per local walker: [lp, full position, #moves, n, sum x, sum x x^T] over the block, x measured
+        from the common origin x0 (the ensemble's starting mean) so that the pooled second moments do not
+        cancel catastrophically."""
+        x = samples - self.x0                                     # [n, per, d]
+        moved = (np.abs(np.diff(samples, axis=0)).sum(axis=2) > 0).sum(axis=0)
+        return np.concatenate([logpost_end[:, None], params_end, moved[:, None].astype(np.float64),
+                               np.full((self.per, 1), float(n)), x.sum(axis=0), self._second_moments(x)], axis=1)
 
     @staticmethod
     def _second_moments(x: np.ndarray) -> np.ndarray:
@@ -267,14 +272,30 @@ class WalkerSampler:
                 self.chol = new                                      # `scale` keeps multiplying it
 
     def run(self, n_steps: int, record: Optional[List] = None) -> None:
-        done = 0
-        while done < n_steps:
-            n = min(self.block, n_steps - done)
-            samples, lps = self.run_block(n)
-            if record is not None:
-                record.append((samples, lps))
-            done += n
+        """n_steps in blocks, PIPELINED: while block b executes (the runner's C call releases the GIL; a worker
+        thread makes it), this thread turns block b-1's samples into rows, exchanges them (the all-gather then
+        runs beside block b's kernels) and adapts the proposal.  Data dependencies are those of run_block --
+        the proposal of block b+1 is adapted from the rows of blocks <= b-1 -- so the chains are the same bits."""
         self.flush()
+        done, finished = 0, None            # finished: (samples, params_end, logpost_end, n) of the block that ran last
+        with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+            while done < n_steps:
+                n = min(self.block, n_steps - done)
+                fut = pool.submit(self.runner.run, self.params, self.logpost, self.ids, self.free,
+                                  self.scale * self.chol, self.seed, self.step, n)
+                if finished is not None:                             # overlapped with the block now running
+                    s_prev, p_prev, l_prev, n_prev = finished
+                    self._consume(self._start_gather(self._make_row(s_prev, p_prev, l_prev, n_prev)), n_prev)
+                self.params, self.logpost, samples, lps, n_acc = fut.result()
+                self.step += n
+                self.accepted += n_acc
+                if record is not None:
+                    record.append((samples, lps))
+                finished = (samples, self.params, self.logpost, n)
+                done += n
+        if finished is not None:
+            s_prev, p_prev, l_prev, n_prev = finished
+            self._consume(self._start_gather(self._make_row(s_prev, p_prev, l_prev, n_prev)), n_prev)
 
 
 # ------------------------------------------------------------------------------------------

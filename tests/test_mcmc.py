@@ -109,3 +109,29 @@ def test_step_scale_stays_finite_when_every_step_moves():
     s.initialise(lambda p: np.zeros(len(p)))
     s.run(20 * 1500)
     assert s.scale == mcmc.SCALE_MAX and np.all(np.isfinite(s.chol))
+
+
+def test_pipelined_run_equals_block_by_block():
+    """WalkerSampler.run overlaps a block's host work with the next block's execution; the data dependencies are
+    those of the unpipelined run_block loop, so states, proposal factor and scale are the same bits."""
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 4, n_stars=60, seed=2)
+    orc = oracle.Oracle(pack, stars, priors, options)
+    start = synth.walker_params(cl["truth"], 4, seed=3, scale=0.1)
+    out = []
+    for pipelined in (True, False):
+        s = mcmc.WalkerSampler(start, mcmc.HostBlockRunner(orc.logpost), block=15, seed=11)
+        s.initialise(orc.logpost)
+        rec = []
+        if pipelined:
+            s.run(100, rec)          # 6 blocks of 15 + one of 10
+            s.run(20, rec)
+        else:
+            for n in (15,) * 6 + (10,):
+                rec.append(s.run_block(n))
+            s.flush()
+            for n in (15, 5):
+                rec.append(s.run_block(n))
+            s.flush()
+        out.append((s.params.copy(), s.logpost.copy(), s.chol.copy(), s.scale, s.accepted, np.concatenate([r[0] for r in rec])))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
