@@ -17,6 +17,7 @@ B9_NPARAM = 12
 PARAM_NAMES = ["logAge", "Y", "FeH", "modulus", "absorption", "carbonicity",
                "IFMRconst", "IFMRlin", "IFMRquad", "Y2", "lambda", "reserved"]
 
+BLOCK_CONTINUE, BLOCK_ASYNC = 1, 2
 STAGE_MSRG, STAGE_WD, STAGE_NSBH, STAGE_BD, STAGE_DNE = 1, 3, 4, 5, 9
 IFMR_WEIDEMANN, IFMR_WILLIAMS, IFMR_SALARIS_LIN, IFMR_SALARIS_PW, IFMR_LINEAR, IFMR_QUADRATIC = range(6)
 MODE_GIVEN_MASS, MODE_MARGINALISED = 0, 1
@@ -70,7 +71,7 @@ class b9_mcmc_block(C.Structure):
     _fields_ = [("n_walkers", C.c_int32), ("n_free", C.c_int32),
                 ("free_idx", _ip), ("chol", _dp), ("walker_ids", _ip),
                 ("seed", C.c_uint64), ("step0", C.c_int64),
-                ("n_steps", C.c_int32), ("reserved", C.c_int32),
+                ("n_steps", C.c_int32), ("flags", C.c_int32),
                 ("params", _dp), ("logpost", _dp), ("samples", _dp), ("lps", _dp),
                 ("n_accept", C.c_int64)]
 
@@ -163,7 +164,7 @@ HIP_LIB_PATH = os.path.join(REPO_ROOT, "base_amd", "csrc", "libbase9hip.so")
 ABI_SYMBOLS = [
     "b9_abi_version", "b9_ctx_create", "b9_ctx_destroy", "b9_last_error",
     "b9_load_pack", "b9_load_stars", "b9_set_priors", "b9_set_options",
-    "b9_logpost", "b9_logpost_device", "b9_mcmc_run_block", "b9_sample_mass", "b9_derive_isochrone",
+    "b9_logpost", "b9_logpost_device", "b9_mcmc_run_block", "b9_mcmc_wait", "b9_sample_mass", "b9_derive_isochrone",
     "b9_max_eep", "b9_device_id", "b9_bytes_per_star_eval",
     "b9_enable_timing", "b9_kernel_time_ms", "b9_calibrate_timing",
 ]
@@ -191,6 +192,7 @@ def load_hip_library(path: Optional[str] = None) -> C.CDLL:
     lib.b9_logpost.argtypes = [vp, _dp, C.c_int32, _dp, _dp]
     lib.b9_logpost_device.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
     lib.b9_mcmc_run_block.argtypes = [vp, C.POINTER(b9_mcmc_block)]
+    lib.b9_mcmc_wait.argtypes = [vp, C.POINTER(b9_mcmc_block)]
     lib.b9_sample_mass.argtypes = [vp, _dp, C.c_int32, C.c_uint64, C.c_int64, _dp, _dp, _dp, _ip]
     lib.b9_derive_isochrone.argtypes = [vp, _dp, C.c_int32, C.c_int32, _dp, _dp, _ip, _ip, _dp]
     lib.b9_max_eep.argtypes = [vp]

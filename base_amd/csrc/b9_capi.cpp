@@ -57,11 +57,20 @@ struct b9_ctx {
     size_t partial_cap = 0;
     double *d_params = nullptr, *d_logpost = nullptr, *d_perstar = nullptr;
     size_t perstar_cap = 0;
-    void *d_mcmc = nullptr;          // device state of b9_mcmc_run_block
+    void *d_mcmc = nullptr;          // device state of b9_mcmc_run_block (two-launch step)
+    struct McmcSlot {                // fused step: one enqueued block (device block, pinned mirror, completion event)
+        void *d = nullptr, *h = nullptr;
+        size_t cap = 0, hcap = 0;
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+        const void *owner = nullptr; // the b9_mcmc_block it was enqueued for
+        int W = 0, final_parity = 0;
+        size_t o_nacc = 0, o_st0 = 0, o_st1 = 0, o_samp = 0, o_lps = 0, n_samp = 0, n_lps = 0;
+    } slot[2];
+    int next_slot = 0, last_slot = -1;
     double *h_lp = nullptr, *h_lp_dev = nullptr;   // b9_logpost: 8 log-posteriors in mapped pinned host memory (host / device view)
     bool no_kernarg_rows = false;    // B9_NO_KERNARG_ROWS=1: always upload the rows with a copy
-    void *h_stage = nullptr;         // its pinned host mirror (fused sampler step: one upload, one download per block)
-    size_t mcmc_cap = 0, stage_cap = 0;
+    size_t mcmc_cap = 0;
 
     // launch plan
     int tiles_per_block = 0;   // 0 = auto
@@ -348,7 +357,16 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return B9_ERR_NO_DEVICE; }
     b9_ctx *ctx = new b9_ctx();
     ctx->device = device_id;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    // The context's stream has the LOWEST priority: a sampler block is a long train of short kernels, and a
+    // collective a multi-GPU driver issues on its own stream (RCCL all-gather of the previous block's rows) must
+    // get in at the next kernel boundary instead of waiting behind the whole train (measured with a 1-rank RCCL
+    // group: the gather took 1.4 ms = the rest of the block; B9_STREAM_PRIORITY=default restores the default).
+    int least = 0, greatest = 0;
+    const char *prio = getenv("B9_STREAM_PRIORITY");
+    const bool low = !(prio && std::string(prio) == "default") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+    const hipError_t se = low ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, least)
+                              : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
         delete ctx; g_create_error = "hipStreamCreate failed"; return B9_ERR_HIP;
     }
     for (int k = 0; k < 12; ++k) { ctx->pr.mean[k] = 0.0; ctx->pr.var[k] = 0.0; }
@@ -372,7 +390,11 @@ void b9_ctx_destroy(b9_ctx *ctx)
     free_all(ctx->star_allocs);
     void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_mcmc};
     for (void *p : bufs) if (p) (void)hipFree(p);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    for (auto &sl : ctx->slot) {
+        if (sl.d) (void)hipFree(sl.d);
+        if (sl.h) (void)hipHostFree(sl.h);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     if (ctx->h_lp) (void)hipHostFree(ctx->h_lp);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
@@ -637,12 +659,38 @@ static int timing_end(b9_ctx *ctx, hipStream_t stream, long slot)
  *   K(t) = k_mcmc_step: decision of step t-1, star likelihood of step t's proposal, and -- on a few
  *          extra workgroups -- both candidate isochrone sets of step t+1
  *   F    = k_mcmc_finish: decision of step S-1. */
+// Collect an enqueued block: wait for its download, unpack the pinned mirror into the caller's arrays.
+static int collect_block(b9_ctx *ctx, b9_ctx::McmcSlot &sl, b9_mcmc_block *blk)
+{
+    HIPCHK(ctx, hipEventSynchronize(sl.done));
+    sl.in_flight = false;
+    const double *stage = static_cast<const double *>(sl.h);
+    const double *fin = stage + (sl.final_parity ? sl.o_st1 : sl.o_st0);
+    for (int w = 0; w < sl.W; ++w) {
+        std::memcpy(blk->params + (size_t)w * B9_NPARAM, fin + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, sizeof(double) * B9_NPARAM);
+        blk->logpost[w] = fin[(size_t)w * B9_STATE_STRIDE + B9_ST_LP];
+    }
+    if (sl.n_samp && blk->samples) std::memcpy(blk->samples, stage + sl.o_samp, sl.n_samp * 8);
+    if (sl.n_lps && blk->lps) std::memcpy(blk->lps, stage + sl.o_lps, sl.n_lps * 8);
+    unsigned long long n_acc;
+    std::memcpy(&n_acc, stage + sl.o_nacc, 8);
+    blk->n_accept = (int64_t)n_acc;
+    return B9_OK;
+}
+
 static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
 {
     const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps, n_pops = ctx->opt.n_pops;
+    const bool cont = (blk->flags & B9_BLOCK_CONTINUE) != 0, async = (blk->flags & B9_BLOCK_ASYNC) != 0;
     const StepPlan sp = make_step_plan(ctx, W, n_pops);
     const Plan &plan = sp.plan;
     const int derive_parts = sp.derive_parts;
+    // two slots (device block + pinned mirror + event) alternate, so that a block can be enqueued while its
+    // predecessor is still running or waiting to be collected
+    b9_ctx::McmcSlot &sl = ctx->slot[ctx->next_slot];
+    if (sl.in_flight) return fail(ctx, B9_ERR_STATE, "two blocks are already outstanding: collect one with b9_mcmc_wait first");
+    if (cont && (ctx->last_slot < 0 || ctx->slot[ctx->last_slot].W != W))
+        return fail(ctx, B9_ERR_STATE, "B9_BLOCK_CONTINUE needs a previous block of this context with the same n_walkers");
     const size_t n_state = (size_t)W * B9_STATE_STRIDE, n_cur = (size_t)W * B9_NPARAM,
                  n_samp = blk->samples ? (size_t)S * W * d : 0, n_lps = blk->lps ? (size_t)S * W : 0;
     // One device allocation, laid out so that the block needs ONE upload and ONE download (each small
@@ -655,19 +703,21 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
                  o_int = o_dec + W, o_nacc = o_int + n_int, o_st0 = o_nacc + 1, o_st1 = o_st0 + n_state,
                  o_samp = o_st1 + n_state, o_lps = o_samp + n_samp, n_total = o_lps + n_lps;
     const size_t up_words = o_st1, down_words = n_total - o_nacc;
-    if (n_total * 8 > ctx->mcmc_cap) {
-        if (ctx->d_mcmc) (void)hipFree(ctx->d_mcmc);
-        ctx->d_mcmc = nullptr; ctx->mcmc_cap = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_mcmc, n_total * 8));
-        ctx->mcmc_cap = n_total * 8;
+    if (n_total * 8 > sl.cap) {
+        // (a CONTINUE block reads the OTHER slot's final state, never this slot's old contents)
+        if (sl.d) (void)hipFree(sl.d);
+        sl.d = nullptr; sl.cap = 0;
+        HIPCHK(ctx, hipMalloc(&sl.d, n_total * 8));
+        sl.cap = n_total * 8;
     }
-    if (n_total * 8 > ctx->stage_cap) {
-        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-        ctx->h_stage = nullptr; ctx->stage_cap = 0;
-        HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, n_total * 8, hipHostMallocDefault));    // pinned staging mirror
-        ctx->stage_cap = n_total * 8;
+    if (n_total * 8 > sl.hcap) {
+        if (sl.h) (void)hipHostFree(sl.h);
+        sl.h = nullptr; sl.hcap = 0;
+        HIPCHK(ctx, hipHostMalloc(&sl.h, n_total * 8, hipHostMallocDefault));    // pinned staging mirror
+        sl.hcap = n_total * 8;
     }
-    double *const dev = static_cast<double *>(ctx->d_mcmc), *const stage = static_cast<double *>(ctx->h_stage);
+    if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    double *const dev = static_cast<double *>(sl.d), *const stage = static_cast<double *>(sl.h);
     double *d_state = dev + o_st0;                   // [2][W][stride]; the block's first launch has parity 1 and reads parity 0
     double *d_cur0 = dev + o_cur0, *d_lp0 = dev + o_lp0, *d_chol = dev + o_chol;
     unsigned long long *d_decided = reinterpret_cast<unsigned long long *>(dev + o_dec);
@@ -676,22 +726,31 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     double *d_samples = n_samp ? dev + o_samp : nullptr, *d_lps = n_lps ? dev + o_lps : nullptr;
     hipStream_t s = ctx->stream;
     {
-        std::memcpy(stage + o_cur0, blk->params, n_cur * 8);
-        std::memcpy(stage + o_lp0, blk->logpost, (size_t)W * 8);
+        std::memset(stage + o_cur0, 0, (n_cur + W) * 8);
+        if (!cont) {
+            std::memcpy(stage + o_cur0, blk->params, n_cur * 8);
+            std::memcpy(stage + o_lp0, blk->logpost, (size_t)W * 8);
+        }
         std::memcpy(stage + o_chol, blk->chol, (size_t)d * d * 8);
         std::memset(stage + o_dec, 0xFF, (size_t)W * 8);                 // no step published yet
         int *hi = reinterpret_cast<int *>(stage + o_int);
         std::memcpy(hi, blk->free_idx, d * sizeof(int));
         std::memcpy(hi + d, blk->walker_ids, W * sizeof(int));
         std::memset(stage + o_nacc, 0, 8);
-        double *st1 = stage + o_st0;                                      // starting state -> parity 0, which K(0) (parity 1) reads
-        std::memset(st1, 0, n_state * 8);
-        for (int w = 0; w < W; ++w) {
-            std::memcpy(st1 + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, blk->params + (size_t)w * B9_NPARAM, sizeof(double) * B9_NPARAM);
-            st1[(size_t)w * B9_STATE_STRIDE + B9_ST_LP] = blk->logpost[w];
-            st1[(size_t)w * B9_STATE_STRIDE + B9_ST_LPRIOR] = -INFINITY;
-        }
+        double *st0 = stage + o_st0;                                      // starting state -> parity 0, which K(0) (parity 1) reads
+        std::memset(st0, 0, n_state * 8);
+        if (!cont)
+            for (int w = 0; w < W; ++w) {
+                std::memcpy(st0 + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, blk->params + (size_t)w * B9_NPARAM, sizeof(double) * B9_NPARAM);
+                st0[(size_t)w * B9_STATE_STRIDE + B9_ST_LP] = blk->logpost[w];
+                st0[(size_t)w * B9_STATE_STRIDE + B9_ST_LPRIOR] = -INFINITY;
+            }
         HIPCHK(ctx, hipMemcpyAsync(dev, stage, up_words * 8, hipMemcpyHostToDevice, s));
+        if (cont) {      // the previous block's final state, device to device (stream-ordered behind its last launch)
+            const b9_ctx::McmcSlot &pv = ctx->slot[ctx->last_slot];
+            const double *prev_final = static_cast<const double *>(pv.d) + (pv.final_parity ? pv.o_st1 : pv.o_st0);
+            HIPCHK(ctx, b9k_mcmc_continue(prev_final, d_cur0, d_lp0, d_state, W, s));
+        }
     }
     StepDev sd{};
     sd.d = d; sd.n_walkers = W; sd.n_pops = n_pops;
@@ -726,18 +785,13 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     sd.step = (unsigned long long)(blk->step0 + S);
     HIPCHK(ctx, b9k_mcmc_finish(ctx->pk, sd, ctx->pr, s));
     HIPCHK(ctx, hipMemcpyAsync(stage + o_nacc, dev + o_nacc, down_words * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    const double *fin = stage + (((S + 1) & 1) ? o_st1 : o_st0);
-    for (int w = 0; w < W; ++w) {
-        std::memcpy(blk->params + (size_t)w * B9_NPARAM, fin + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, sizeof(double) * B9_NPARAM);
-        blk->logpost[w] = fin[(size_t)w * B9_STATE_STRIDE + B9_ST_LP];
-    }
-    if (n_samp) std::memcpy(blk->samples, stage + o_samp, n_samp * 8);
-    if (n_lps) std::memcpy(blk->lps, stage + o_lps, n_lps * 8);
-    unsigned long long n_acc;
-    std::memcpy(&n_acc, stage + o_nacc, 8);
-    blk->n_accept = (int64_t)n_acc;
-    return B9_OK;
+    HIPCHK(ctx, hipEventRecord(sl.done, s));
+    sl.W = W; sl.final_parity = (S + 1) & 1;
+    sl.o_nacc = o_nacc; sl.o_st0 = o_st0; sl.o_st1 = o_st1; sl.o_samp = o_samp; sl.o_lps = o_lps; sl.n_samp = n_samp; sl.n_lps = n_lps;
+    sl.in_flight = true; sl.owner = blk;
+    ctx->last_slot = ctx->next_slot;
+    ctx->next_slot ^= 1;
+    return async ? B9_OK : collect_block(ctx, sl, blk);
 }
 
 /* Device-resident Metropolis block (the caller of the hot path).  Given-mass mode
@@ -762,6 +816,7 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     rc = ensure_capacity(ctx, W, n_pops, (size_t)ctx->st.n_pad * W, false);
     if (rc) return rc;
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) return run_block_fused(ctx, blk);
+    if (blk->flags) return fail(ctx, B9_ERR_INVALID, "B9_BLOCK_CONTINUE / B9_BLOCK_ASYNC need the fused step (given-mass mode)");
     // marginalised mode (and B9_TWO_LAUNCH_STEPS=1): two launches per step
     // one device allocation for the block's state
     const size_t n_cur = (size_t)W * B9_NPARAM, n_samp = blk->samples ? (size_t)S * W * d : 0,
@@ -826,6 +881,22 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     HIPCHK(ctx, hipStreamSynchronize(s));
     blk->n_accept = (int64_t)n_acc;
     return B9_OK;
+}
+
+int b9_mcmc_wait(b9_ctx *ctx, b9_mcmc_block *blk)
+{
+    if (!ctx || !blk || !blk->params || !blk->logpost) return B9_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // blocks are collected in the order they were enqueued: the older outstanding one is in next_slot when both
+    // are in flight, else in the other slot
+    for (int k = 0; k < 2; ++k) {
+        b9_ctx::McmcSlot &sl = ctx->slot[(ctx->next_slot + k) & 1];
+        if (sl.in_flight) {
+            if (sl.owner != blk) return fail(ctx, B9_ERR_STATE, "b9_mcmc_wait: blocks must be collected in the order they were enqueued");
+            return collect_block(ctx, sl, blk);
+        }
+    }
+    return fail(ctx, B9_ERR_STATE, "b9_mcmc_wait: no block is outstanding");
 }
 
 int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out_logpost, double *out_perstar)

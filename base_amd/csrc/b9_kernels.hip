@@ -245,6 +245,12 @@ hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &s
 #undef MS_ARGS
 }
 
+hipError_t b9k_mcmc_continue(const double *prev_final, double *cur0, double *lp0, double *state0, int n_walkers, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_mcmc_continue, dim3(n_walkers), dim3(64), 0, stream, prev_final, cur0, lp0, state0);
+    return hipGetLastError();
+}
+
 hipError_t b9k_mcmc_finish(const DevPack &pk, const StepDev &sd, const DevPriors &pr, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_mcmc_finish, dim3(sd.n_walkers), dim3(256), 0, stream, pk, sd, pr);

@@ -351,3 +351,15 @@ extern "C" int b9_debug_clear_stamps(void)
 }
 #endif
 
+
+// B9_BLOCK_CONTINUE: the next block's starting state is the previous block's final state, copied on the device
+// (state rows of the final parity -> this block's cur0 / lp0 for D0 and its parity-0 state rows for K(0)).
+__global__ void k_mcmc_continue(const double *__restrict__ prev_final, double *__restrict__ cur0, double *__restrict__ lp0,
+                                double *__restrict__ state0)
+{
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const double *src = prev_final + (size_t)w * B9_STATE_STRIDE;
+    double *dst = state0 + (size_t)w * B9_STATE_STRIDE;
+    if (tid < B9_NPARAM) { const double v = src[B9_ST_CUR + tid]; cur0[(size_t)w * B9_NPARAM + tid] = v; dst[B9_ST_CUR + tid] = v; }
+    if (tid == B9_NPARAM) { const double lp = src[B9_ST_LP]; lp0[w] = lp; dst[B9_ST_LP] = lp; dst[B9_ST_LPRIOR] = NEG_INF; }
+}

@@ -43,6 +43,7 @@ class Engine:
             self.load_stars(stars)
         if priors is not None:
             self.set_priors(priors)
+        self.options = abi.make_options()                # the context's defaults
         if options is not None:
             self.set_options(options)
 
@@ -76,6 +77,7 @@ class Engine:
 
     def set_options(self, options: abi.b9_options) -> None:
         self._check(self.lib.b9_set_options(self._ctx, C.byref(options)))
+        self.options = options
 
     # -- hot path -------------------------------------------------------------------------
     def logpost(self, params: np.ndarray, perstar: bool = False):
@@ -97,26 +99,40 @@ class Engine:
     def mcmc_run_block(self, params, logpost, walker_ids, free, chol, seed, step0, n_steps, record=True):
         """Device-resident Metropolis block (b9_mcmc_run_block).  Same contract as
         mcmc.HostBlockRunner.run: returns (params, logpost, samples, lps, n_accept)."""
+        return self.mcmc_collect(self.mcmc_submit(params, logpost, walker_ids, free, chol, seed, step0, n_steps, record,
+                                                  cont=False, asynchronous=False))
+
+    def mcmc_submit(self, params, logpost, walker_ids, free, chol, seed, step0, n_steps, record=True, cont=False,
+                    asynchronous=True):
+        """Enqueue a block (B9_BLOCK_ASYNC) -- with cont=True from the state the previous block left on the device
+        (B9_BLOCK_CONTINUE; params / logpost then only give the shapes).  Returns a handle for mcmc_collect; at
+        most two handles may be outstanding and they are collected in submission order."""
         params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, abi.B9_NPARAM).copy()
         W, d = params.shape[0], len(free)
         logpost = np.ascontiguousarray(logpost, dtype=np.float64).copy()
-        free_a = np.ascontiguousarray(free, dtype=np.int32)
-        ids = np.ascontiguousarray(walker_ids, dtype=np.int32)
-        chol_a = np.ascontiguousarray(chol, dtype=np.float64)
-        samples = np.empty((n_steps, W, d)) if record else None
-        lps = np.empty((n_steps, W)) if record else None
+        keep = dict(params=params, logpost=logpost, free=np.ascontiguousarray(free, dtype=np.int32),
+                    ids=np.ascontiguousarray(walker_ids, dtype=np.int32), chol=np.ascontiguousarray(chol, dtype=np.float64),
+                    samples=np.empty((n_steps, W, d)) if record else None, lps=np.empty((n_steps, W)) if record else None)
         blk = abi.b9_mcmc_block()
         blk.n_walkers, blk.n_free = W, d
-        blk.free_idx = free_a.ctypes.data_as(_ip)
-        blk.chol = chol_a.ctypes.data_as(_dp)
-        blk.walker_ids = ids.ctypes.data_as(_ip)
+        blk.free_idx = keep["free"].ctypes.data_as(_ip)
+        blk.chol = keep["chol"].ctypes.data_as(_dp)
+        blk.walker_ids = keep["ids"].ctypes.data_as(_ip)
         blk.seed, blk.step0, blk.n_steps = int(seed), int(step0), int(n_steps)
+        blk.flags = (abi.BLOCK_CONTINUE if cont else 0) | (abi.BLOCK_ASYNC if asynchronous else 0)
         blk.params = params.ctypes.data_as(_dp)
         blk.logpost = logpost.ctypes.data_as(_dp)
-        blk.samples = samples.ctypes.data_as(_dp) if record else None
-        blk.lps = lps.ctypes.data_as(_dp) if record else None
+        blk.samples = keep["samples"].ctypes.data_as(_dp) if record else None
+        blk.lps = keep["lps"].ctypes.data_as(_dp) if record else None
         self._check(self.lib.b9_mcmc_run_block(self._ctx, C.byref(blk)))
-        return params, logpost, samples, lps, int(blk.n_accept)
+        keep["blk"], keep["pending"] = blk, bool(asynchronous and n_steps > 0)
+        return keep
+
+    def mcmc_collect(self, h):
+        if h["pending"]:
+            self._check(self.lib.b9_mcmc_wait(self._ctx, C.byref(h["blk"])))
+            h["pending"] = False
+        return h["params"], h["logpost"], h["samples"], h["lps"], int(h["blk"].n_accept)
 
     def sample_mass(self, params: np.ndarray, seed: int = 1, row0: int = 0):
         """b9_sample_mass: per (row, star) one Gumbel-max draw of (primary mass, mass ratio, population) on the

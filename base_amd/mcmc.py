@@ -24,6 +24,7 @@ latency-bound, and amortised over `block` steps.
 from __future__ import annotations
 
 import concurrent.futures
+import os
 
 from typing import Callable, List, Optional, Sequence
 
@@ -129,6 +130,18 @@ class DeviceBlockRunner:
 
     def run(self, params, logpost, walker_ids, free, chol, seed, step0, n_steps):
         return self.engine.mcmc_run_block(params, logpost, walker_ids, free, chol, seed, step0, n_steps, self.record)
+
+    # Pipelining (given-mass mode): a block can be enqueued -- continuing from the device-resident state of the
+    # block before it -- while that block still runs, so the GPU's queue never drains between blocks.
+    def can_pipeline(self) -> bool:
+        return self.engine.options.mode == abi.MODE_GIVEN_MASS and not os.environ.get("B9_TWO_LAUNCH_STEPS") \
+            and not os.environ.get("B9_NO_BLOCK_PIPELINE")
+
+    def submit(self, params, logpost, walker_ids, free, chol, seed, step0, n_steps, cont):
+        return self.engine.mcmc_submit(params, logpost, walker_ids, free, chol, seed, step0, n_steps, self.record, cont=cont)
+
+    def collect(self, handle):
+        return self.engine.mcmc_collect(handle)
 
 
 FORGET = 0.9          # per-block forgetting factor of the pooled adaptation moments
@@ -277,6 +290,8 @@ class WalkerSampler:
         runs beside block b's kernels) and adapts the proposal.  Data dependencies are those of run_block --
         the proposal of block b+1 is adapted from the rows of blocks <= b-1 -- so the chains are the same bits."""
         self.flush()
+        if getattr(self.runner, "can_pipeline", lambda: False)() and n_steps > 0:
+            return self._run_device_pipeline(n_steps, record)
         done, finished = 0, None            # finished: (samples, params_end, logpost_end, n) of the block that ran last
         with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
             while done < n_steps:
@@ -296,6 +311,40 @@ class WalkerSampler:
         if finished is not None:
             s_prev, p_prev, l_prev, n_prev = finished
             self._consume(self._start_gather(self._make_row(s_prev, p_prev, l_prev, n_prev)), n_prev)
+
+
+    def _run_device_pipeline(self, n_steps: int, record: Optional[List]) -> None:
+        """Two blocks outstanding on the device: block b+1 is enqueued (continuing from block b's device-resident
+        state) as soon as block b-1 has been collected and its rows exchanged and consumed -- i.e. with exactly the
+        proposal the unpipelined loop would use -- while block b is still running."""
+        sizes, left = [], n_steps
+        while left > 0:
+            sizes.append(min(self.block, left)); left -= sizes[-1]
+        step = self.step
+        handles = []
+
+        def enqueue(b):
+            nonlocal step
+            handles.append(self.runner.submit(self.params, self.logpost, self.ids, self.free, self.scale * self.chol,
+                                              self.seed, step, sizes[b], cont=b > 0))
+            step += sizes[b]
+
+        def finish(b):           # collect block b, account for it, exchange its rows, adapt
+            self.params, self.logpost, samples, lps, n_acc = self.runner.collect(handles[b])
+            handles[b] = None
+            self.step += sizes[b]
+            self.accepted += n_acc
+            if record is not None:
+                record.append((samples, lps))
+            self._consume(self._start_gather(self._make_row(samples, self.params, self.logpost, sizes[b])), sizes[b])
+
+        enqueue(0)
+        for b in range(len(sizes)):
+            if b >= 1:
+                finish(b - 1)                                    # while block b runs
+            if b + 1 < len(sizes):
+                enqueue(b + 1)                                   # proposal adapted from blocks <= b-1, as unpipelined
+        finish(len(sizes) - 1)
 
 
 # ------------------------------------------------------------------------------------------

@@ -204,7 +204,7 @@ typedef struct b9_mcmc_block {
     const int32_t *walker_ids;   /* [n_walkers] global walker ids (random-number streams)     */
     uint64_t seed;
     int64_t step0;               /* global number of the block's first step                   */
-    int32_t n_steps, reserved;
+    int32_t n_steps, flags;      /* flags: B9_BLOCK_* (0 = start from params/logpost, synchronous)          */
     double *params;              /* [n_walkers*B9_NPARAM] in/out                              */
     double *logpost;             /* [n_walkers] in/out                                        */
     double *samples;             /* out, nullable                                             */
@@ -212,6 +212,19 @@ typedef struct b9_mcmc_block {
     int64_t n_accept;            /* out                                                       */
 } b9_mcmc_block;
 int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk);
+
+/*
+ * Pipelining blocks (given-mass mode).  B9_BLOCK_ASYNC: b9_mcmc_run_block returns as soon as the block is
+ * enqueued on the context's stream; b9_mcmc_wait(ctx, blk) -- same blk, whose host arrays must stay valid --
+ * blocks until it has run and fills params / logpost / samples / lps / n_accept.  B9_BLOCK_CONTINUE: the block
+ * starts from the state the PREVIOUS block of this context left on the device (its params / logpost inputs are
+ * ignored; n_walkers must match), so it can be enqueued before that block has finished.  At most two blocks
+ * may be outstanding; they are collected in the order they were enqueued.  A driver that adapts the proposal
+ * from block b-1 while block b runs keeps the GPU's queue non-empty: enqueue b+1 (CONTINUE | ASYNC), wait(b), ...
+ */
+#define B9_BLOCK_CONTINUE 1
+#define B9_BLOCK_ASYNC 2
+int b9_mcmc_wait(b9_ctx *ctx, b9_mcmc_block *blk);
 
 /*
  * Per-star mass posterior draws (the sampleMass counterpart; [RECALL] sampleMass

@@ -142,3 +142,64 @@ def test_fused_step_at_chunk_and_tile_boundaries(n_stars):
     assert dev[4] == host[4]
     np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
+
+
+def test_pipelined_blocks_continue_on_the_device():
+    """B9_BLOCK_CONTINUE | B9_BLOCK_ASYNC: blocks enqueued back to back from the device-resident state give the
+    chain of the synchronous block-by-block calls (and of one long block), whatever the block lengths."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=2000, wd_frac=0.03, small=False, seed=13)
+    eng = engine.Engine(pack, stars, priors, options)
+    free, chol = np.array(mcmc.DEFAULT_FREE), np.diag([3e-4, 2e-3, 8e-4, 6e-4])
+    start = synth.walker_params(cl["truth"], 6, seed=2, scale=0.1)
+    lp0 = eng.logpost(start)
+    sizes = [7, 1, 12, 2, 9]
+    # synchronous, block by block, host state handed over
+    p, lp, acc, samp = start, lp0, 0, []
+    s0 = 1000
+    for n in sizes:
+        p, lp, s, l, a = eng.mcmc_run_block(p, lp, np.arange(6), free, chol * (1 + 0.1 * len(samp)), 4, s0, n)
+        samp.append(s); acc += a; s0 += n
+    # pipelined: two outstanding, continuing on the device
+    hs, s0, got, acc2 = [], 1000, [], 0
+    for k, n in enumerate(sizes):
+        hs.append(eng.mcmc_submit(start, lp0, np.arange(6), free, chol * (1 + 0.1 * k), 4, s0, n, cont=k > 0))
+        s0 += n
+        if len(hs) == 2:
+            r = eng.mcmc_collect(hs.pop(0)); got.append(r[2]); acc2 += r[4]
+    while hs:
+        r = eng.mcmc_collect(hs.pop(0)); got.append(r[2]); acc2 += r[4]
+    assert acc2 == acc
+    for a, b in zip(samp, got):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(r[0], p)
+    np.testing.assert_array_equal(r[1], lp)
+    # misuse is reported, not UB
+    h1 = eng.mcmc_submit(start, lp0, np.arange(6), free, chol, 4, 0, 3)
+    h2 = eng.mcmc_submit(start, lp0, np.arange(6), free, chol, 4, 3, 3, cont=True)
+    with pytest.raises(RuntimeError):
+        eng.mcmc_submit(start, lp0, np.arange(6), free, chol, 4, 6, 3, cont=True)        # a third outstanding block
+    with pytest.raises(RuntimeError):
+        eng.mcmc_collect(h2)                                                              # out of order
+    eng.mcmc_collect(h1); eng.mcmc_collect(h2)
+    with pytest.raises(RuntimeError):
+        eng.mcmc_submit(start[:3], lp0[:3], np.arange(3), free, chol, 4, 0, 3, cont=True)  # other walker count
+
+
+def test_sampler_device_pipeline_equals_unpipelined(monkeypatch):
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("dsed", 8, n_stars=1500, small=False, seed=3)
+    eng = engine.Engine(pack, stars, priors, options)
+    start = synth.walker_params(cl["truth"], 8, seed=1, scale=0.05)
+    out = []
+    for pipe in (True, False):
+        if not pipe:
+            monkeypatch.setenv("B9_NO_BLOCK_PIPELINE", "1")
+        s = mcmc.WalkerSampler(start, mcmc.DeviceBlockRunner(eng), block=25, seed=5)
+        s.initialise(eng.logpost)
+        rec = []
+        s.run(260, rec)
+        s.run(40, rec)
+        out.append((s.params.copy(), s.logpost.copy(), s.chol.copy(), s.scale, s.accepted, s.step, np.concatenate([r[0] for r in rec])))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
