@@ -522,29 +522,56 @@ McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double
     std::vector<double> mean(d, 0.0), m2((size_t)d * d, 0.0);
     McmcResult res;
     const long total = cfg.burn_iter + cfg.run_iter;
-    std::vector<double> samples, lps, prev((size_t)W * d);
-    const auto t0 = std::chrono::steady_clock::now();
-    long done = 0;
-    while (done < total) {
+    // the blocks of the run (burn-in and main run never share a block)
+    struct Blk { long start; int n; bool burning; };
+    std::vector<Blk> blocks;
+    for (long done = 0; done < total;) {
         const bool burning = done < cfg.burn_iter;
-        const long left = (burning ? cfg.burn_iter : total) - done;
-        const int n = (int)std::min<long>(cfg.block, left);
-        samples.assign((size_t)n * W * d, 0.0); lps.assign((size_t)n * W, 0.0);
-        for (size_t k = 0; k < chol.size(); ++k) chol_scaled[k] = scale * chol[k];
-        for (int w = 0; w < W; ++w) for (int i = 0; i < d; ++i) prev[(size_t)w * d + i] = params[(size_t)w * B9_NPARAM + cfg.free_idx[i]];
-        b9_mcmc_block blk{};
-        blk.n_walkers = W; blk.n_free = d; blk.free_idx = cfg.free_idx.data(); blk.chol = chol_scaled.data();
-        blk.walker_ids = ids.data(); blk.seed = cfg.seed; blk.step0 = done; blk.n_steps = n;
-        blk.params = params.data(); blk.logpost = logpost.data(); blk.samples = samples.data(); blk.lps = lps.data();
-        if (b9_mcmc_run_block(ctx, &blk) != B9_OK) fail(b9_last_error(ctx));
+        const int n = (int)std::min<long>(cfg.block, (burning ? cfg.burn_iter : total) - done);
+        blocks.push_back({done, n, burning});
+        done += n;
+    }
+    // Blocks are pipelined on the device (B9_BLOCK_CONTINUE | B9_BLOCK_ASYNC): block b+1 is enqueued -- from the state
+    // block b will leave in HBM -- as soon as block b-1 has been collected, written out and used for the adaptation,
+    // so its proposal is adapted from blocks <= b-1 and the GPU's queue never drains.  The first block of the main
+    // run waits for the whole burn-in: the main run's proposal is frozen [RECALL].
+    struct Slot { std::vector<double> samples, lps, params, logpost, chol; b9_mcmc_block blk{}; };
+    Slot slot[2];
+    const auto t0 = std::chrono::steady_clock::now();
+
+    auto enqueue = [&](size_t b) {
+        Slot &s = slot[b & 1];
+        const Blk &k = blocks[b];
+        s.samples.assign((size_t)k.n * W * d, 0.0); s.lps.assign((size_t)k.n * W, 0.0);
+        s.params = params; s.logpost = logpost;                       // inputs only for the very first block
+        s.chol.resize(chol.size());
+        for (size_t i = 0; i < chol.size(); ++i) s.chol[i] = scale * chol[i];
+        s.blk = b9_mcmc_block{};
+        s.blk.n_walkers = W; s.blk.n_free = d; s.blk.free_idx = cfg.free_idx.data(); s.blk.chol = s.chol.data();
+        s.blk.walker_ids = ids.data(); s.blk.seed = cfg.seed; s.blk.step0 = k.start; s.blk.n_steps = k.n;
+        s.blk.flags = B9_BLOCK_ASYNC | (b > 0 ? B9_BLOCK_CONTINUE : 0);
+        s.blk.params = s.params.data(); s.blk.logpost = s.logpost.data(); s.blk.samples = s.samples.data(); s.blk.lps = s.lps.data();
+        if (b9_mcmc_run_block(ctx, &s.blk) != B9_OK) fail(b9_last_error(ctx));
+    };
+
+    auto finish = [&](size_t b) {
+        Slot &s = slot[b & 1];
+        const Blk &k = blocks[b];
+        if (b9_mcmc_wait(ctx, &s.blk) != B9_OK) fail(b9_last_error(ctx));
+        params = s.params; logpost = s.logpost;
+        const std::vector<double> &samples = s.samples, &lps = s.lps;
+        const int n = k.n;
+        const long done = k.start;
+        const bool burning = k.burning;
+        const b9_mcmc_block &blk = s.blk;
         res.accepted += blk.n_accept; res.steps += n;
         // output
         if (out)
-            for (int s = 0; s < n; ++s) {
-                if ((done + s) % cfg.thin) continue;
+            for (int st = 0; st < n; ++st) {
+                if ((done + st) % cfg.thin) continue;
                 for (int w = 0; w < W; ++w) {
-                    std::vector<double> v(samples.begin() + ((size_t)s * W + w) * d, samples.begin() + ((size_t)s * W + w + 1) * d);
-                    out->row(v, lps[(size_t)s * W + w], burning ? (done < cfg.burn_iter / 2 ? 1 : 2) : 3);
+                    std::vector<double> v(samples.begin() + ((size_t)st * W + w) * d, samples.begin() + ((size_t)st * W + w + 1) * d);
+                    out->row(v, lps[(size_t)st * W + w], burning ? (done < cfg.burn_iter / 2 ? 1 : 2) : 3);
                 }
             }
         // adaptation (burn-in only, as the reference freezes the proposal for the main run [RECALL])
@@ -553,8 +580,8 @@ McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double
             // part of a degeneracy ridge the chain has already left stop shaping the proposal
             n_mom *= kForget;
             for (double &v : m2) v *= kForget;
-            for (int s = 0; s < n; ++s) for (int w = 0; w < W; ++w) {
-                const double *x = &samples[((size_t)s * W + w) * d];
+            for (int st = 0; st < n; ++st) for (int w = 0; w < W; ++w) {
+                const double *x = &samples[((size_t)st * W + w) * d];
                 n_mom += 1.0;
                 std::vector<double> dl(d);
                 for (int i = 0; i < d; ++i) { dl[i] = x[i] - mean[i]; mean[i] += dl[i] / n_mom; }
@@ -590,8 +617,23 @@ McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double
                 }
             }
         }
-        done += n;
-        if (cfg.verbose) std::fprintf(stderr, "  step %ld/%ld  accept %.3f  scale %.3g  logPost[0] %.4f\n", done, total, (double)res.accepted / ((double)res.steps * W), scale, logpost[0]);
+        if (cfg.verbose) std::fprintf(stderr, "  step %ld/%ld  accept %.3f  scale %.3g  logPost[0] %.4f\n", done + n, total, (double)res.accepted / ((double)res.steps * W), scale, logpost[0]);
+    };
+
+    // e = next block to enqueue, f = next block to finish; at most two outstanding.  Block b may be enqueued once
+    // blocks <= b-2 are finished (its proposal is then adapted from them: one block of lag) -- or, when it opens the
+    // main run, once the whole burn-in is.
+    const size_t B = blocks.size();
+    size_t e = 0, f = 0;
+    auto may_enqueue = [&](size_t b) {
+        if (b == 0) return true;
+        const bool opens_main = !blocks[b].burning && blocks[b - 1].burning;
+        return opens_main ? f >= b : f + 1 >= b;
+    };
+    while (f < B) {
+        while (e < B && e - f < 2 && may_enqueue(e)) { enqueue(e); ++e; }
+        finish(f);
+        ++f;
     }
     res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     res.star_evals_per_s = (double)res.steps * W * n_stars / res.seconds;
