@@ -13,17 +13,18 @@ eng = engine.Engine(abi.make_pack(pack_d), abi.make_stars(cl), synth.default_pri
 start = synth.walker_params(truth, 8, seed=42, scale=0.05)
 runner = mcmc.DeviceBlockRunner(eng, record=True)
 t_c = [0.0]
-orig = runner.run
-def timed(*a, **k):
-    t0 = time.perf_counter(); r = orig(*a, **k); t_c[0] += time.perf_counter() - t0; return r
-runner.run = timed
+def wrap(f):
+    def timed(*a, **k):
+        t0 = time.perf_counter(); r = f(*a, **k); t_c[0] += time.perf_counter() - t0; return r
+    return timed
+runner.run, runner.submit, runner.collect = wrap(runner.run), wrap(runner.submit), wrap(runner.collect)   # C calls (enqueue + wait)
 s = mcmc.WalkerSampler(start, runner, block=block)
 s.initialise(eng.logpost)
 s.run(10 * block)
 t_c[0] = 0.0
 t0 = time.perf_counter(); s.run(blocks * block); tot = time.perf_counter() - t0
 n = blocks * block
-print(f"block {block}: total {tot/n*1e6:.2f} us/step; C call {t_c[0]/n*1e6:.2f} us/step; python around it {(tot-t_c[0])/blocks*1e6:.0f} us/block")
+print(f"block {block}: total {tot/n*1e6:.2f} us/step; inside the C calls (enqueue + wait) {t_c[0]/n*1e6:.2f} us/step; python around them {(tot-t_c[0])/blocks*1e6:.0f} us/block")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); s.run(10 * block); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
