@@ -84,6 +84,8 @@ struct b9_ctx {
     unsigned long long launch_no = 0;
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used = 0;
+    std::vector<int> ev_count;      // launches covered by each bracket
+    int timing_group = 8;            // fused step: a bracket spans this many consecutive launches (B9_TIMING_GROUP)
     double ms_accum = 0.0;
     int launches = 0;
 };
@@ -374,6 +376,7 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
     if (const char *s = getenv("B9_WALKERS_PER_LANE")) ctx->walkers_per_lane = atoi(s) >= 2 ? 2 : 1;
     if (const char *s = getenv("B9_DERIVE_PARTS")) ctx->derive_parts = atoi(s);
+    if (const char *s = getenv("B9_TIMING_GROUP")) ctx->timing_group = std::max(1, atoi(s));
     if (const char *s = getenv("B9_NO_KERNARG_ROWS")) ctx->no_kernarg_rows = atoi(s) != 0;
     if (const char *s = getenv("B9_DERIVE_ORDER")) ctx->derive_order = atoi(s);
     if (const char *s = getenv("B9_TWO_LAUNCH_STEPS")) ctx->two_launch_steps = atoi(s) != 0;
@@ -578,6 +581,8 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
             ctx->ev_start.push_back(a); ctx->ev_stop.push_back(b);
         }
         slot = ctx->ev_used++;
+        if (ctx->ev_count.size() < ctx->ev_used) ctx->ev_count.resize(ctx->ev_used, 1);
+        ctx->ev_count[slot] = 1;
         HIPCHK(ctx, hipEventRecord(ctx->ev_start[slot], stream));
     }
     HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
@@ -643,6 +648,8 @@ static int timing_begin(b9_ctx *ctx, hipStream_t stream, long *slot)
         ctx->ev_start.push_back(a); ctx->ev_stop.push_back(b);
     }
     *slot = (long)ctx->ev_used++;
+    if (ctx->ev_count.size() < ctx->ev_used) ctx->ev_count.resize(ctx->ev_used, 1);
+    ctx->ev_count[*slot] = 1;
     HIPCHK(ctx, hipEventRecord(ctx->ev_start[*slot], stream));
     return B9_OK;
 }
@@ -772,14 +779,26 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
                                    sd.cand_iso + c10 * rows * ctx->iso_stride, ctx->iso_stride, ctx->mass_cap,
                                    mc, ctx->pr, B9Prev{nullptr, 0, 0, nullptr, nullptr}, s));
     }
+    long t_slot = -1;
+    int t_covered = 0;
     for (int t = 0; t < S; ++t) {
         sd.set = (t + 1) & 1; sd.has_prev = t > 0; sd.derive_next = t + 1 < S; sd.row = t - 1;
         sd.step = (unsigned long long)(blk->step0 + t);
-        long slot;
-        int rc = timing_begin(ctx, s, &slot);
-        if (rc) return rc;
+        // Timing: every ctx->timing-th launch opens an event bracket that spans timing_group consecutive launches of
+        // this kernel (never past the block's last one), so the two event records cost 1/group of what a bracket
+        // around a single launch adds; the bracket's time / its launch count is the kernel's launch period.
+        if (t_slot < 0) {
+            int rc = timing_begin(ctx, s, &t_slot);
+            if (rc) return rc;
+            t_covered = 0;
+        } else if (ctx->timing > 0) ctx->launch_no++;
         HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, sp.strided ? -plan.tiles_per_block : plan.tiles_per_block, plan.n_groups, B9_HEAVY_PARTS, derive_parts, ctx->derive_order, s));
-        if ((rc = timing_end(ctx, s, slot))) return rc;
+        if (t_slot >= 0 && (++t_covered >= ctx->timing_group || t == S - 1)) {
+            ctx->ev_count[t_slot] = t_covered;
+            int rc = timing_end(ctx, s, t_slot);
+            if (rc) return rc;
+            t_slot = -1;
+        }
     }
     sd.set = (S + 1) & 1; sd.has_prev = 1; sd.derive_next = 0; sd.row = S - 1;
     sd.step = (unsigned long long)(blk->step0 + S);
@@ -1070,7 +1089,7 @@ int b9_kernel_time_ms(b9_ctx *ctx, int reset, double *total_ms, int32_t *n_launc
         float ms = 0.f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
         ctx->ms_accum += ms;
-        ctx->launches += 1;
+        ctx->launches += i < ctx->ev_count.size() ? ctx->ev_count[i] : 1;
     }
     ctx->ev_used = 0;
     *total_ms = ctx->ms_accum;

@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 N_STARS, N_FILT, WALKERS_PER_GPU = 50000, 8, 8
 MCMC_BLOCK = 100       # steps between adaptation points (= between all-gathers)
-TIMING_EVERY = 25       # HIP-event bracket on every 25th launch of the dominant kernel in the timed region (a bracket costs ~5 us of stream time)
+TIMING_EVERY = 25       # a HIP-event bracket opens at every 25th launch of the dominant kernel in the timed region and spans 8 launches
 
 
 def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0, eng=None):
@@ -215,7 +215,7 @@ def main():
                        "collective": "one all_gather of [logpost, position, moments] rows per 100-step block" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_mcmc_step", "launches_timed": k_n, "timed_every": TIMING_EVERY,
+                         "kernel": "k_mcmc_step", "launches_timed": k_n, "timed_every": TIMING_EVERY, "launches_per_bracket": 8,
                          "avg_launch_us": 1e6 * k_avg_s, "empty_kernel_bracket_us": 1e3 * bracket_ms,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_star_eval": bytes_eval},
             "accept_rate": (sampler.accepted - acc0) / float(WALKERS_PER_GPU * args.steps),

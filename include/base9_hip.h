@@ -264,8 +264,10 @@ int b9_device_id(const b9_ctx *ctx);
 int b9_bytes_per_star_eval(const b9_ctx *ctx);
 /* Elapsed ms of the dominant (star-likelihood) kernel over the TIMED launches since the last
  * call with reset != 0, measured with HIP events on the launch stream; *n_launches receives
- * their count.  b9_enable_timing(ctx, n): n = 0 off, n > 0 brackets every n-th launch
- * (n = 1: all of them; each bracket costs the host two hipEventRecord calls).              */
+ * their count.  b9_enable_timing(ctx, n): n = 0 off, n > 0 opens an event bracket at every n-th
+ * launch.  In the sampler's fused step a bracket spans 8 consecutive launches of the kernel (never
+ * past the block's end; B9_TIMING_GROUP), so that the two event records cost an eighth of what a
+ * bracket around a single launch adds (~2-3 us): total_ms / n_launches is the kernel's launch period. */
 int b9_enable_timing(b9_ctx *ctx, int on);
 int b9_kernel_time_ms(b9_ctx *ctx, int reset, double *total_ms, int32_t *n_launches);
 /* Mean elapsed ms of the same event bracket around an EMPTY kernel: what the bracket adds to a
