@@ -17,11 +17,12 @@ def test_oracle_and_host_parsers_under_asan_ubsan(tmp_path):
     cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "sanitize", "driver.cpp"),
            os.path.join(host, "b9host.cpp"), "-x", "c", os.path.join(ROOT, "oracle", "b9_oracle.c"), "-lm"]
-    # b9host.cpp references run_mcmc -> the C ABI; the driver never calls it, so stub the two symbols it needs
+    # b9host.cpp references run_mcmc -> the C ABI; the driver never calls it, so stub the symbols it needs
     stub = tmp_path / "stub.c"
     stub.write_text('#include "base9_hip.h"\n'
                     "int b9_logpost(b9_ctx *c, const double *p, int32_t n, double *o, double *s) { (void)c; (void)p; (void)n; (void)o; (void)s; return B9_ERR_NO_DEVICE; }\n"
                     "int b9_mcmc_run_block(b9_ctx *c, b9_mcmc_block *b) { (void)c; (void)b; return B9_ERR_NO_DEVICE; }\n"
+                    "int b9_mcmc_wait(b9_ctx *c, b9_mcmc_block *b) { (void)c; (void)b; return B9_ERR_NO_DEVICE; }\n"
                     'const char *b9_last_error(const b9_ctx *c) { (void)c; return "stub"; }\n')
     cmd += [str(stub), "-I", os.path.join(ROOT, "include")]
     r = subprocess.run(cmd, capture_output=True, text=True)
