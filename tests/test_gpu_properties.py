@@ -227,3 +227,34 @@ def test_extreme_likelihood_scales(seed, log_sig, log_field, marg):
     assert np.array_equal(np.isfinite(got), f)
     if f.any():
         assert np.max(np.abs(got[f] - want[f]) / np.maximum(1.0, np.abs(want[f]))) <= 1e-9
+
+
+@settings(max_examples=20, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(sizes=st.lists(st.integers(1, 9), min_size=1, max_size=7), record=st.lists(st.booleans(), min_size=7, max_size=7),
+       depth=st.integers(1, 2), seed=st.integers(0, 10**6), n_w=st.integers(1, 6))
+def test_block_pipeline_any_schedule(sizes, record, depth, seed, n_w):
+    """B9_BLOCK_CONTINUE | B9_BLOCK_ASYNC under random block lengths, record on/off and one or two outstanding blocks:
+    the chain of the synchronous block-by-block calls."""
+    pack_d, cl, eng, orc = _setup(("parsec", 8, 1, 1, abi.MODE_GIVEN_MASS))
+    free, chol = np.array(mcmc.DEFAULT_FREE), np.diag([3e-4, 2e-3, 8e-4, 6e-4])
+    start = synth.walker_params(cl["truth"], n_w, seed=seed % 100, scale=0.1)
+    lp0 = eng.logpost(start)
+    ids = np.arange(n_w)
+    p, lp, s0, want = start, lp0, 77, []
+    for k, n in enumerate(sizes):
+        p, lp, s, l, a = eng.mcmc_run_block(p, lp, ids, free, chol * (1 + 0.05 * k), seed, s0, n, record=record[k])
+        want.append((s, l, a)); s0 += n
+    hs, s0, got = [], 77, []
+    for k, n in enumerate(sizes):
+        hs.append(eng.mcmc_submit(start, lp0, ids, free, chol * (1 + 0.05 * k), seed, s0, n, record[k], cont=k > 0))
+        s0 += n
+        while len(hs) >= (2 if depth == 2 else 1):
+            r = eng.mcmc_collect(hs.pop(0)); got.append((r[2], r[3], r[4]))
+    while hs:
+        r = eng.mcmc_collect(hs.pop(0)); got.append((r[2], r[3], r[4]))
+    for (ws, wl, wa), (gs, gl, ga) in zip(want, got):
+        assert wa == ga
+        assert (ws is None) == (gs is None)
+        if ws is not None:
+            np.testing.assert_array_equal(ws, gs); np.testing.assert_array_equal(wl, gl)
+    np.testing.assert_array_equal(r[0], p); np.testing.assert_array_equal(r[1], lp)
