@@ -26,6 +26,7 @@ struct HostStars {
     int n = 0, nf = 0;
     std::vector<double> obs, sigma, mass1, q, prior, fmin, fmax;
     std::vector<int> stage, wd_type;
+    double min_mass1 = 0.0;
 };
 
 }  // namespace
@@ -73,6 +74,11 @@ struct b9_ctx {
     size_t mcmc_cap = 0;
 
     // launch plan
+    int n_cu = 256;            // compute units of the device (hipDeviceAttributeMultiprocessorCount)
+    int plan_debug_key = -1;
+    int step_blocks_per_cu = 0, step_occ_key = -1;   // k_mcmc_step workgroups per CU for (nfp, n_pops, mass_cap), and the key it was queried for
+    int heavy_parts = 4;       // workgroups per walker for the stars above the AGB tip (sized in check_ready)
+    int n_wd_stage = 0;        // stars the catalogue marks as white dwarfs
     int tiles_per_block = 0;   // 0 = auto
     int walkers_per_lane = 1;  // WB template parameter of k_star_like (1 or 2)
     int derive_parts = 0;      // fused sampler step: workgroups per candidate isochrone (0 = one value per thread)
@@ -206,7 +212,8 @@ int build_stars(b9_ctx *ctx)
         q[i] = h.q[s];
         const double pm = h.prior[s];
         c0m[i] = std::log(pm) + g;
-        c0[i] = std::log(pm) + (log_prior_mass(ctx->pk.log_mass_norm, h.mass1[s]) + g);
+        // (mass1 <= 0 is only accepted in the marginalised mode, which never reads c0)
+        c0[i] = h.mass1[s] > 0.0 ? std::log(pm) + (log_prior_mass(ctx->pk.log_mass_norm, h.mass1[s]) + g) : -INFINITY;
         la[i] = std::log1p(-pm) + log_fs;
         ea[i] = std::exp(la[i]);
         flags[i] = (h.wd_type[s] > 0 ? 1 : 0) | (h.stage[s] << 8);
@@ -221,8 +228,17 @@ int build_stars(b9_ctx *ctx)
     std::vector<double> heavy_mass(std::max(n, 1), 0.0);
     for (int k = 0; k < n; ++k) heavy_mass[k] = mass1[heavy_slot[k]];
 
+    // the heavy-order copy (DevStars::hv_*)
+    const int hv_pad = std::max(64, (n + 63) / 64 * 64);
+    std::vector<double> hv_obs((size_t)nfp * hv_pad, 0.0), hv_w((size_t)nfp * hv_pad, 0.0), hv_q(hv_pad, 0.0), hv_c0(hv_pad, 0.0), hv_la(hv_pad, -INFINITY);
+    std::vector<int> hv_flags(hv_pad, 0), hv_perm(hv_pad, -1);
+    for (int k = 0; k < n; ++k) {
+        const int i = heavy_slot[k];
+        for (int f = 0; f < nfp; ++f) { hv_obs[(size_t)f * hv_pad + k] = obs[(size_t)f * n_pad + i]; hv_w[(size_t)f * hv_pad + k] = w[(size_t)f * n_pad + i]; }
+        hv_q[k] = q[i]; hv_c0[k] = c0[i]; hv_la[k] = la[i]; hv_flags[k] = flags[i]; hv_perm[k] = permp[i];
+    }
     DevStars st{};
-    st.n = n; st.n_pad = n_pad;
+    st.n = n; st.n_pad = n_pad; st.hv_pad = hv_pad;
     int rc;
     if ((rc = upload(ctx, ctx->star_allocs, obs.data(), obs.size(), &st.obs))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, w.data(), w.size(), &st.w))) return rc;
@@ -236,14 +252,27 @@ int build_stars(b9_ctx *ctx)
     if ((rc = upload(ctx, ctx->star_allocs, permp.data(), permp.size(), &st.perm))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, heavy_mass.data(), heavy_mass.size(), &st.heavy_mass))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, heavy_slot.data(), heavy_slot.size(), &st.heavy_slot))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, hv_obs.data(), hv_obs.size(), &st.hv_obs))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, hv_w.data(), hv_w.size(), &st.hv_w))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, hv_q.data(), hv_q.size(), &st.hv_q))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, hv_c0.data(), hv_c0.size(), &st.hv_c0))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, hv_la.data(), hv_la.size(), &st.hv_la))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, hv_flags.data(), hv_flags.size(), &st.hv_flags))) return rc;
+    if ((rc = upload(ctx, ctx->star_allocs, hv_perm.data(), hv_perm.size(), &st.hv_perm))) return rc;
     ctx->st = st;
+    ctx->n_wd_stage = 0;
+    for (int i = 0; i < n; ++i) ctx->n_wd_stage += h.stage[i] == B9_STAGE_WD;
     ctx->stars_dirty = false;
     return B9_OK;
 }
 
 int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bool want_perstar)
 {
-    if (n_walkers > ctx->cap_walkers || n_pops > ctx->cap_pops || ctx->mass_cap != ((ctx->pk.max_eep + 1) & ~1)) {
+    // (the isochrone rows depend on BOTH the longest isochrone and the padded filter count of the loaded pack: a pack
+    //  reloaded with the same EEP count but more filters needs wider rows)
+    const int want_cap = (ctx->pk.max_eep + 1) & ~1;
+    if (n_walkers > ctx->cap_walkers || n_pops > ctx->cap_pops || ctx->mass_cap != want_cap ||
+        ctx->iso_stride != (long long)want_cap * (ctx->pk.nfp + 1)) {
         if (ctx->d_hdr) (void)hipFree(ctx->d_hdr);
         if (ctx->d_iso) (void)hipFree(ctx->d_iso);
         if (ctx->d_params) (void)hipFree(ctx->d_params);
@@ -278,7 +307,6 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
     return B9_OK;
 }
 
-#define B9_HEAVY_PARTS 4        // workgroups per walker for the stars above the AGB tip
 
 struct Plan { int tiles_per_block, n_groups; };
 
@@ -308,12 +336,20 @@ Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
 // parts give 21.8 us per step; 1 tile / 15 parts 26.0 us; 4 tiles 25.6 us).
 struct StepPlan { Plan plan; int derive_parts; bool strided; };
 
-StepPlan make_step_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
+StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
 {
     StepPlan sp;
+    const int key = (ctx->pk.nfp * 4 + n_pops) * 65536 + ctx->mass_cap;
+    if (ctx->step_occ_key != key) {
+        int per_cu = 0;
+        if (b9k_mcmc_step_occupancy(ctx->pk, n_pops, ctx->mass_cap, &per_cu) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (const char *s = getenv("B9_STEP_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(s));      // experiments only
+        ctx->step_blocks_per_cu = per_cu;
+        ctx->step_occ_key = key;
+    }
     const int n_tiles = ctx->st.n_pad / 256;
     const int full_parts = (ctx->mass_cap * (ctx->pk.nfp + 1) + 255) / 256;
-    const int slots = 256 * (n_pops == 2 ? 2 : 3);              // workgroups resident on 256 CUs (k_mcmc_step's launch bounds)
+    const int slots = ctx->n_cu * std::max(1, ctx->step_blocks_per_cu);   // workgroups resident at once (occupancy query of this instantiation)
     int tpb = ctx->tiles_per_block;
     if (tpb <= 0) {
         tpb = 1;
@@ -326,12 +362,18 @@ StepPlan make_step_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
     sp.plan.n_groups = (n_tiles + tpb - 1) / tpb;
     int parts = ctx->derive_parts;
     if (parts <= 0) {
-        const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_groups * n_walkers - (long long)n_walkers * B9_HEAVY_PARTS;
+        const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_groups * n_walkers - (long long)n_walkers * ctx->heavy_parts;
         parts = (int)std::max<long long>(2, room / ((long long)n_walkers * 2 * n_pops));
     }
     sp.derive_parts = std::max(1, std::min(parts, full_parts));
     // one round: a workgroup's tiles are strided over the slot order (binary and single-star tiles mixed)
     sp.strided = (long long)sp.plan.n_groups * n_walkers <= slots && !getenv("B9_CONTIGUOUS_TILES");
+    if (getenv("B9_PLAN_DEBUG") && ctx->plan_debug_key != key * 64 + n_walkers) {
+        ctx->plan_debug_key = key * 64 + n_walkers;
+        std::fprintf(stderr, "b9 step plan: %d CUs x %d workgroups = %d slots; %d walkers x %d tile groups (%d tiles each, %s) + %d heavy + %d derivation workgroups (%d parts)\n",
+                     ctx->n_cu, ctx->step_blocks_per_cu, slots, n_walkers, sp.plan.n_groups, tpb, sp.strided ? "strided" : "contiguous",
+                     n_walkers * ctx->heavy_parts, n_walkers * 2 * n_pops * sp.derive_parts, sp.derive_parts);
+    }
     return sp;
 }
 
@@ -359,6 +401,7 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return B9_ERR_NO_DEVICE; }
     b9_ctx *ctx = new b9_ctx();
     ctx->device = device_id;
+    if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ctx->n_cu < 1) ctx->n_cu = 256;
     // The context's stream has the LOWEST priority: a sampler block is a long train of short kernels, and a
     // collective a multi-GPU driver issues on its own stream (RCCL all-gather of the previous block's rows) must
     // get in at the next kernel boundary instead of waiting behind the whole train (measured with a 1-rank RCCL
@@ -510,10 +553,19 @@ int b9_load_stars(b9_ctx *ctx, const b9_stars *s)
         if (sg > 0.0 && (!(sg >= 1e-150) || std::isinf(sg) || !std::isfinite(s->obs[i])))
             return fail(ctx, B9_ERR_INVALID, "a filter in use needs a finite observation and 1e-150 <= sigma < inf");
     }
+    // masses: a NaN mass1 would break the ordering the slot sort relies on, and a non-positive one has no mass prior;
+    // the mass ratio is secondary / primary in [0, 1] (0 = single)
+    // (whether mass1 must also be positive depends on the mode -- the marginalised mode only uses it as a hint --
+    //  and is checked when the stars are staged: check_ready)
+    for (size_t i = 0; i < n; ++i) {
+        if (!std::isfinite(s->mass1[i])) return fail(ctx, B9_ERR_INVALID, "mass1 must be finite");
+        if (!(s->mass_ratio[i] >= 0.0 && s->mass_ratio[i] <= 1.0)) return fail(ctx, B9_ERR_INVALID, "mass_ratio must be in [0, 1]");
+    }
     h.n = (int)n; h.nf = (int)nf;
     h.obs.assign(s->obs, s->obs + n * nf);
     h.sigma.assign(s->sigma, s->sigma + n * nf);
     h.mass1.assign(s->mass1, s->mass1 + n);
+    h.min_mass1 = *std::min_element(h.mass1.begin(), h.mass1.end());
     h.q.assign(s->mass_ratio, s->mass_ratio + n);
     h.prior.assign(s->clust_prior, s->clust_prior + n);
     h.fmin.assign(s->filter_prior_min, s->filter_prior_min + nf);
@@ -555,7 +607,7 @@ static Bufs buffer_set(const b9_ctx *ctx, int set)
 // number of partial sums one walker gets from the star kernel under the current plan / mode
 static int partial_count(const b9_ctx *ctx, const Plan &plan)
 {
-    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.n_pad : plan.n_groups * 4 + B9_HEAVY_PARTS;
+    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.n_pad : plan.n_groups * 4 + ctx->heavy_parts;
 }
 
 // The star-likelihood launch (given-mass: hot + heavy workgroups; marginalised: one wave per star)
@@ -587,7 +639,7 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
     }
     HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
                               n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, ctx->st.n_pad, d_perstar,
-                              plan.tiles_per_block, plan.n_groups, B9_HEAVY_PARTS, stream));
+                              plan.tiles_per_block, plan.n_groups, ctx->heavy_parts, stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
     return B9_OK;
 }
@@ -623,6 +675,16 @@ static int check_ready(b9_ctx *ctx)
     if (!ctx->have_pack || !ctx->have_stars) return fail(ctx, B9_ERR_STATE, "load the pack and the stars first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
+    {   // Workgroups per walker for the stars above the AGB tip (WD branch / NS-BH).  Their number depends on the walker's
+        // age; the catalogue's WD-stage stars plus 2 % of the rest is the estimate.  A star takes 2 n_pops lanes
+        // (star_value_lanes) and the role is a latency chain, so there is one 256-lane workgroup per 256 lanes of them:
+        // a lane evaluates one descriptor, rarely two.
+        const int est = (ctx->n_wd_stage + ctx->hs.n / 50) * 2 * ctx->opt.n_pops;
+        ctx->heavy_parts = std::max(4, std::min(16, (est + 255) / 256));
+        if (const char *e = getenv("B9_HEAVY_PARTS")) ctx->heavy_parts = std::max(1, std::min(64, atoi(e)));
+    }
+    if (ctx->opt.mode == B9_MODE_GIVEN_MASS && ctx->hs.min_mass1 <= 0.0)
+        return fail(ctx, B9_ERR_INVALID, "given-mass mode needs mass1 > 0 for every star (the marginalised mode takes mass1 as a hint only)");
     return B9_OK;
 }
 
@@ -792,7 +854,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
             if (rc) return rc;
             t_covered = 0;
         } else if (ctx->timing > 0) ctx->launch_no++;
-        HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, sp.strided ? -plan.tiles_per_block : plan.tiles_per_block, plan.n_groups, B9_HEAVY_PARTS, derive_parts, ctx->derive_order, s));
+        HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, sp.strided ? -plan.tiles_per_block : plan.tiles_per_block, plan.n_groups, ctx->heavy_parts, derive_parts, ctx->derive_order, s));
         if (t_slot >= 0 && (++t_covered >= ctx->timing_group || t == S - 1)) {
             ctx->ev_count[t_slot] = t_covered;
             int rc = timing_end(ctx, s, t_slot);

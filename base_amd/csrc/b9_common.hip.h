@@ -31,6 +31,30 @@ __device__ unsigned long long g_stamps[8192 * B9_NSTAMP];
 #define STAMP(k) do {} while (0)
 #endif
 
+// -DB9_ASM_MARKERS (diagnostic): comments in the generated assembly that delimit a role's code (tools/role_isa.py)
+#ifdef B9_ASM_MARKERS
+#define B9_MARK(name) asm volatile("; b9-mark " name)
+#else
+#define B9_MARK(name) do {} while (0)
+#endif
+
+#ifdef B9_GANTT      // diagnostic build only: per-workgroup start / end times (s_memrealtime, 100 MHz) of 8 consecutive launches
+#define B9_GANTT_WG 4096
+__device__ unsigned long long g_gantt[8 * B9_GANTT_WG * 4];
+__device__ unsigned long long g_gantt_heavy[64 * 8];          // phase stamps of the heavy role (one slot per workgroup id < 64)
+extern "C" int b9_debug_read_gantt(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt), sizeof(unsigned long long) * 8 * B9_GANTT_WG * 4);
+}
+extern "C" int b9_debug_read_gantt_heavy(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_heavy), sizeof(unsigned long long) * 64 * 8);
+}
+#define HSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_heavy[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define HSTAMP(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ double lerp(double a, double b, double t) { return fma(t, b - a, a); }
 
 // largest i in [0, n-2] with ax[i] <= x (clamped); identical to the oracle's bracket()

@@ -46,6 +46,13 @@ struct DevStars {
     const int *perm;                 // [n_pad] original index of the star in slot i, -1 = empty
     const double *heavy_mass;        // [n] primary masses in descending order ...
     const int *heavy_slot;           // [n] ... and the slots that hold them
+    // A second copy of the per-star arrays IN THAT DESCENDING-MASS ORDER (stride hv_pad), read by the heavy-star role:
+    // star j of the list is element j of every array, so the role's first memory round trip fetches everything a star
+    // needs (through heavy_slot it took one trip for the slot and another for the data behind it).
+    int hv_pad;
+    const double *hv_obs, *hv_w;     // [nfp][hv_pad]
+    const double *hv_q, *hv_c0, *hv_la;   // [hv_pad]
+    const int *hv_flags, *hv_perm;   // [hv_pad]  (hv_perm: original index of the star)
 };
 
 // Header of one derived isochrone (one per walker x population).

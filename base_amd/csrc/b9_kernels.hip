@@ -208,13 +208,44 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 #undef SM_ARGS
 }
 
+// dynamic LDS of k_mcmc_step: the hot role's mass columns of both candidates (+ 8: find_bracket's masked over-read), or
+// the heavy role's axes, whichever is larger
+template <int NFP, int NPOPS>
+static size_t mcmc_step_lds(const DevPack &pk, int mass_cap)
+{
+    const size_t stage = B9_LDS_STAGE(NFP) ? (size_t)4 * (2 * NFP + 1) * 64 : 0;      // per-wave observation stage of the hot role
+    return sizeof(double) * std::max((size_t)2 * NPOPS * mass_cap + 8 + stage, heavy_lds_doubles(pk, NPOPS));
+}
+
+template <int NFP, int NPOPS>
+static hipError_t mcmc_step_occupancy(const DevPack &pk, int mass_cap, int *blocks_per_cu)
+{
+    const size_t lds = mcmc_step_lds<NFP, NPOPS>(pk, mass_cap);
+    auto kern = k_mcmc_step<NFP, NPOPS>;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(kern), 256, lds);
+}
+
+// Workgroups of the fused step that one CU holds at once for the loaded pack (registers, LDS, wave slots of THIS
+// instantiation): the launch plan sizes its single occupancy round from it instead of assuming a machine.
+hipError_t b9k_mcmc_step_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu)
+{
+#define OC2(NFP) mcmc_step_occupancy<NFP, 2>(pk, mass_cap, blocks_per_cu)
+#define OC1(NFP) mcmc_step_occupancy<NFP, 1>(pk, mass_cap, blocks_per_cu)
+    B9_SWITCH_NFP(OC2, OC1)
+#undef OC1
+#undef OC2
+}
+
 template <int NFP, int NPOPS>
 static hipError_t launch_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr,
                                    int tiles_per_block, int n_groups, int heavy_parts, int derive_parts, int derive_order, hipStream_t stream)
 {
-    // hot role: the mass columns of both candidates (+ 8: find_bracket's masked over-read)
-    const size_t stage = B9_LDS_STAGE(NFP) ? (size_t)4 * (2 * NFP + 1) * 64 : 0;      // per-wave observation stage of the hot role
-    const size_t lds = sizeof(double) * std::max((size_t)2 * NPOPS * sd.mass_cap + 8 + stage, heavy_lds_doubles(pk, NPOPS));
+    const size_t lds = mcmc_step_lds<NFP, NPOPS>(pk, sd.mass_cap);
     auto kern = k_mcmc_step<NFP, NPOPS>;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {

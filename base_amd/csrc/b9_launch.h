@@ -47,6 +47,8 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr,
                          int tiles_per_block, int n_groups, int heavy_parts, int derive_parts,
                          int derive_order /* >= 0: derivation workgroups lead the grid, < 0: they trail it */, hipStream_t stream);
+// resident workgroups per CU of k_mcmc_step's instantiation for this pack (occupancy query; no launch)
+hipError_t b9k_mcmc_step_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu);
 // B9_BLOCK_CONTINUE: previous block's final state rows -> this block's starting buffers
 hipError_t b9k_mcmc_continue(const double *prev_final, double *cur0, double *lp0, double *state0, int n_walkers, hipStream_t stream);
 // the block's last decision only (one workgroup per walker)

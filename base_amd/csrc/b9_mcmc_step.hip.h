@@ -287,11 +287,9 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
 // derivation workgroups trail the grid -- nobody in this launch waits for their output, so they
 // fill the slots the last hot workgroups leave free.  (B9_DERIVE_FIRST=1 puts them in front.)
 template <int NFP, int NPOPS>
-__global__ __launch_bounds__(256, (NPOPS == 2 && B9_K1_MIN_WAVES > B9_K1_MIN_WAVES_2POP) ? B9_K1_MIN_WAVES_2POP : B9_K1_MIN_WAVES)
-void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_per_block, int n_groups,
-                 int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first)
+__device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, int tiles_per_block, int n_groups,
+                 int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first, double *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int W = sd.n_walkers, n_heavy = W * heavy_parts, n_derive = W * 2 * NPOPS * derive_parts;
     int b = blockIdx.x;
     // role of this workgroup: 0 hot, 1 heavy, 2 derivation (index b within the role), 3 none (padding)
@@ -313,10 +311,21 @@ void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_pe
             role = (b < n_derive && !writer && sd.derive_next) ? 2 : 3;
         }
     }
-    if (role == 0) { step_hot<NFP, NPOPS>(pk, st, sd, b, tiles_per_block, n_groups, smem); return; }
+    if (role == 0) {
+        B9_MARK("hot-begin");
+        step_hot<NFP, NPOPS>(pk, st, sd, b, tiles_per_block, n_groups, smem);
+        B9_MARK("hot-end");
+        return role;
+    }
+#ifndef B9_STEP_NO_HEAVY     // (diagnostic builds only: what the hot + derivation roles need in registers on their own)
     if (role == 1) {
         const int w = b / heavy_parts, part = b - w * heavy_parts;
         double lp_new;
+        // the role is ONE long dependent chain per lane on a few workgroups; the hot waves it shares its SIMDs with are
+        // throughput work: let its instructions issue first
+        __builtin_amdgcn_s_setprio(3);
+        HSTAMP(0);
+        B9_MARK("heavy-begin");
         const int sel = step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0;
         const size_t rows = (size_t)W * NPOPS, cs = (size_t)(sd.set * 2 + sel);
         heavy_stars<NFP, NPOPS>(pk, st, sd.cand_hdr + cs * rows, sd.cand_iso + cs * rows * sd.iso_stride, sd.iso_stride,
@@ -324,13 +333,39 @@ void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_pe
                                 sd.partial + (size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) +
                                     (size_t)n_groups * 4 + part,
                                 nullptr, smem);
-        return;
+        B9_MARK("heavy-end");
+        return role;
     }
+#endif
     if (role == 2) {       // b = ((w * 2 + cand) * NPOPS + pop) * derive_parts + part
         const int part = b % derive_parts; b /= derive_parts;
         const int pop = b % NPOPS; b /= NPOPS;
         step_derive(pk, sd, pr, b >> 1, b & 1, pop, part, derive_parts);
     }
+    return role;
+}
+
+template <int NFP, int NPOPS>
+__global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS))
+void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_per_block, int n_groups,
+                 int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef B9_GANTT
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int role = step_body<NFP, NPOPS>(pk, st, sd, pr, tiles_per_block, n_groups, front_blocks, hot_blocks, heavy_parts, derive_parts, derive_first, smem);
+#ifdef B9_GANTT
+    __syncthreads();          // the workgroup's last wave
+    if (threadIdx.x == 0 && blockIdx.x < B9_GANTT_WG) {
+        unsigned long long *g = g_gantt + ((sd.step & 7ull) * B9_GANTT_WG + blockIdx.x) * 4;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g[0] = t_in; g[1] = __builtin_amdgcn_s_memrealtime(); g[2] = (unsigned long long)role | ((unsigned long long)(xcc & 15u) << 8); g[3] = sd.step;
+    }
+#else
+    (void)role;
+#endif
 }
 
 // the block's last decision: one workgroup per walker, writer role only

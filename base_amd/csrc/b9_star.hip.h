@@ -22,6 +22,78 @@ __device__ __forceinline__ void fill(double (&out)[NFP], double v)
     for (int f = 0; f < NFP; ++f) out[f] = v;
 }
 
+// Bracket of mass m in a mass column (LDS-resident in the hot roles; any pointer works): the largest i in [0, n-2] with mass[i] <= m
+// (what the oracle's binary search returns -- the bracket is unique for a sorted column, so any
+// correct search yields the same i and hence bit-identical weights).  8-ary: every step issues 7
+// independent ds_reads and narrows the range eightfold, so a 400-point column takes 3 dependent
+// LDS round trips instead of the 9 of a binary search (measured: the binary search was 19 % of the
+// kernel's VALU instructions but 3.3 of its 20.5 us).
+// The index alone, for an ascending (DESC = false: largest i <= n-2 with ax[i] <= x) or descending (DESC = true:
+// largest i <= n-2 with ax[i] >= x) axis; equal to the oracle's binary searches, which return the same unique index.
+template <bool DESC>
+__device__ __forceinline__ int bracket8(const double *ax, int n, double x)
+{
+    int lo = 0, len = n - 1;                 // the answer lies in [lo, lo + len)
+    if (n < 2) return 0;
+    while (len >= 8) {                       // 7 probes at lo + j*step, all inside the range (7*step < len)
+        const int step = len >> 3;
+        const double *p = ax + lo;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) c += (DESC ? p[j * step] >= x : p[j * step] <= x) ? 1 : 0;
+        lo += c * step;
+        len = (c == 7) ? len - 7 * step : step;
+    }
+    {                                        // fewer than 8 candidates left: probe them all at once
+        const double *p = ax + lo;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            const double v = j < len ? p[j] : p[0];             // never reads past the axis
+            c += (j < len && (DESC ? v >= x : v <= x)) ? 1 : 0;
+        }
+        lo += c;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void find_bracket(const double *mass, int n, double m, int &lo_out, double &t_out)
+{
+    int lo = 0, len = n - 1;                 // the answer lies in [lo, lo + len)
+    while (len >= 8) {                       // 7 probes at lo + j*step, all inside the range (7*step < len)
+        const int step = len >> 3;
+        const double *p = mass + lo;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) c += (p[j * step] <= m) ? 1 : 0;
+        lo += c * step;
+        len = (c == 7) ? len - 7 * step : step;
+    }
+    {                                        // fewer than 8 candidates left: probe them all at once
+        const double *p = mass + lo;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) c += (j < len && p[j] <= m) ? 1 : 0;     // reads stay inside the column: lo + 7 <= n + 6 < capacity
+        lo += c;
+    }
+    const double a = mass[lo], d = mass[lo + 1] - a;
+#ifdef B9_EXACT_DIV
+    t_out = (d > 0.0) ? (m - a) / d : 0.0;
+#else
+    // (m - a) / d by a v_rcp_f64 seed, two Newton steps and a residual correction: within 1 ulp of
+    // the IEEE quotient (the weight is then off by <= 1e-16 relative -- seven orders inside the
+    // stated tolerance) at a third of the instructions and latency of the exact division sequence
+    const double num = m - a;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double tq = num * r;
+    tq = fma(fma(-d, tq, num), r, tq);
+    t_out = (d > 0.0) ? tq : 0.0;
+#endif
+    lo_out = lo;
+}
+
 // binary search in the isochrone's mass column + linear interpolation.
 template <int NFP>
 __device__ __forceinline__ void msrgb_mags(const IsoView<NFP> &iso, double m, double (&out)[NFP])
@@ -70,21 +142,20 @@ struct WdAxes {
     const double *wc_log_age, *wc_mass, *wc_carb, *at_log_teff, *at_logg;
 };
 
-__device__ inline double prec_log_age_corner(const DevPack &pk, const WdAxes &ax, int corner, double m)
+__device__ inline double prec_log_age_corner(const DevPack &pk, const double *tips, const double *log_age, double m)
 {
     const int na = pk.n_age;
-    const double *tips = ax.tips[corner];
     const double tip0 = tips[0];
-    if (m > tip0) return ax.log_age[0] - 2.7 * log10(m / tip0);
-    if (m <= tips[na - 1]) return ax.log_age[na - 1];
-    int lo = 0, hi = na - 1;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (tips[mid] >= m) lo = mid; else hi = mid;
-    }
+#ifdef B9_ABL_HEAVY_CHEAPMATH
+    if (m > tip0) return log_age[0] - 2.7 * 0.43 * (m - tip0);
+#else
+    if (m > tip0) return log_age[0] - 2.7 * log10(m / tip0);
+#endif
+    if (m <= tips[na - 1]) return log_age[na - 1];
+    const int lo = bracket8<true>(tips, na, m);              // (here tips[0] >= m > tips[na-1])
     const double a = tips[lo], b = tips[lo + 1];
     const double t = (b != a) ? (m - a) / (b - a) : 0.0;
-    return lerp(ax.log_age[lo], ax.log_age[lo + 1], t);
+    return lerp(log_age[lo], log_age[lo + 1], t);
 }
 
 // IFMR -> WD cooling model -> atmosphere table.  Only the stars above the AGB
@@ -96,13 +167,14 @@ __device__ __forceinline__ void wd_mags(const DevPack &pk, const WdAxes &ax, con
 {
     if (pk.n_wc_mass < 2 || pk.n_at_teff < 2) { fill<NFP>(out, B9_MAG_NOFLUX); return; }
     const int ny = pk.n_y > 1 ? 2 : 1;
-    double vf[2];
-    for (int df = 0; df < 2; ++df) {
-        double vy[2] = {0.0, 0.0};
-        for (int dy = 0; dy < ny; ++dy) vy[dy] = prec_log_age_corner(pk, ax, df * 2 + dy, m);
-        vf[df] = (ny == 2) ? lerp(vy[0], vy[1], iso.t_y) : vy[0];
+    // (fully unrolled: a run-time index into ax.tips[] would put the pointer array in scratch memory)
+    const double v00 = prec_log_age_corner(pk, ax.tips[0], ax.log_age, m), v10 = prec_log_age_corner(pk, ax.tips[2], ax.log_age, m);
+    double vf0 = v00, vf1 = v10;
+    if (ny == 2) {
+        vf0 = lerp(v00, prec_log_age_corner(pk, ax.tips[1], ax.log_age, m), iso.t_y);
+        vf1 = lerp(v10, prec_log_age_corner(pk, ax.tips[3], ax.log_age, m), iso.t_y);
     }
-    const double prec = lerp(vf[0], vf[1], iso.t_feh);
+    const double prec = lerp(vf0, vf1, iso.t_feh);
     const double log_age = par[B9_P_LOGAGE];
     if (prec >= log_age) { fill<NFP>(out, -4.0); return; }
     const double wd_mass = ifmr(pk.ifmr_id, par, m);
@@ -190,6 +262,163 @@ __device__ __forceinline__ double chi2_system(const DevPack &pk, const WdAxes &a
     // a non-finite predicted magnitude (NaN or inf, also under a zero weight: 0 * inf = NaN)
     // leaves chi2 non-finite: the star is impossible under this isochrone
     return isfinite(chi2) ? chi2 : __builtin_inf();
+}
+
+// ------------------------------------------------------------------------------------------
+// Lean form of the general per-star evolution, used by the heavy-star role (stars above a walker's AGB tip).
+// A component (primary or secondary) is first reduced to a DESCRIPTOR of what its magnitudes are interpolated
+// from -- nothing, one pair of isochrone rows, four atmosphere rows, or a constant -- and the filters are then
+// walked once, each magnitude formed where it is used.  Same operations in the same order as star_mags /
+// chi2_system above (identical bits), but no per-filter arrays: the role needs a third of the registers, so it
+// neither spills nor sets the register budget of the kernel it shares with the hot role.
+// ------------------------------------------------------------------------------------------
+#ifndef B9_HEAVY_UNROLL
+#define B9_HEAVY_UNROLL 4          // filters per batch of table-row loads (a batch = one memory round trip; 8 costs 15 more VGPRs)
+#endif
+struct Comp {
+    int kind;               // 0: no flux (99.999)   1: two rows, lerp t   2: four rows, lerp t then tg   3: constant -4
+    const double *r0, *r1;  // kind 1: r0 = lower isochrone row (upper = r0 + NFP); kind 2: r0 / r1 = the two log g rows
+    double t, tg;
+};
+
+template <int NFP>
+__device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, const double *is_mass, const double *is_mags,
+                                          int is_n, double is_tip, double t_feh, double t_y,
+                                          const double *__restrict__ par, double m, int wd_type)
+{
+    Comp c; c.kind = 0; c.r0 = is_mags; c.r1 = is_mags; c.t = 0.0; c.tg = 0.0;
+    if (!(m > 0.0)) return c;
+    if (m <= is_tip) {                                           // MS / RGB (msrgb_mags)
+        if (m < is_mass[0]) return c;
+        int lo; double t;
+        find_bracket(is_mass, is_n, m, lo, t);
+#ifndef B9_HEAVY_FAST_DIV
+        { const double a = is_mass[lo], d = is_mass[lo + 1] - a; t = (d > 0.0) ? (m - a) / d : 0.0; }   // the oracle's exact quotient
+#endif
+        c.kind = 1; c.r0 = is_mags + (size_t)lo * NFP; c.t = t;
+        return c;
+    }
+    if (!(m <= pk.m_wd_up)) return c;                            // NS / BH
+    if (pk.n_wc_mass < 2 || pk.n_at_teff < 2) return c;          // no WD models loaded
+    // WD (wd_mags): precursor age -> cooling age -> (Teff, radius) -> atmosphere rows
+    const int ny = pk.n_y > 1 ? 2 : 1;
+    const double v00 = prec_log_age_corner(pk, ax.tips[0], ax.log_age, m), v10 = prec_log_age_corner(pk, ax.tips[2], ax.log_age, m);
+    double vf0 = v00, vf1 = v10;
+    if (ny == 2) {
+        vf0 = lerp(v00, prec_log_age_corner(pk, ax.tips[1], ax.log_age, m), t_y);
+        vf1 = lerp(v10, prec_log_age_corner(pk, ax.tips[3], ax.log_age, m), t_y);
+    }
+    const double prec = lerp(vf0, vf1, t_feh);
+    const double log_age = par[B9_P_LOGAGE];
+    if (prec >= log_age) { c.kind = 3; return c; }
+    const double wd_mass = ifmr(pk.ifmr_id, par, m);
+#ifdef B9_ABL_HEAVY_CHEAPMATH      // ablation build only (wrong results): what the library transcendentals cost the chain
+    const double log_cool = fma(log_age, 0.99, -0.01 * prec);
+#else
+    const double log_cool = log10(exp10(log_age) - exp10(prec));
+#endif
+    const int ia = bracket8<false>(ax.wc_log_age, pk.n_wc_age, log_cool);
+    const double ta = (log_cool - ax.wc_log_age[ia]) / (ax.wc_log_age[ia + 1] - ax.wc_log_age[ia]);
+    const int im = bracket8<false>(ax.wc_mass, pk.n_wc_mass, wd_mass);
+    const double tm = (wd_mass - ax.wc_mass[im]) / (ax.wc_mass[im + 1] - ax.wc_mass[im]);
+    const int nc = pk.n_wc_carb > 1 ? 2 : 1;
+    int ic = 0; double tc = 0.0;
+    if (nc == 2) {
+        ic = bracket8<false>(ax.wc_carb, pk.n_wc_carb, par[B9_P_CARBONICITY]);
+        tc = (par[B9_P_CARBONICITY] - ax.wc_carb[ic]) / (ax.wc_carb[ic + 1] - ax.wc_carb[ic]);
+    }
+    // the 8 (16 with a carbonicity axis) table words of both quantities are requested together
+    const size_t b00 = ((size_t)ic * pk.n_wc_mass + im) * pk.n_wc_age + ia, b01 = b00 + pk.n_wc_age;
+    const size_t c_step = (size_t)pk.n_wc_mass * pk.n_wc_age;
+    double tr[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double *tab = q ? pk.wc_log_radius : pk.wc_log_teff;
+        double v = lerp(lerp(tab[b00], tab[b00 + 1], ta), lerp(tab[b01], tab[b01 + 1], ta), tm);
+        if (nc == 2) {
+            const double v1 = lerp(lerp(tab[b00 + c_step], tab[b00 + c_step + 1], ta), lerp(tab[b01 + c_step], tab[b01 + c_step + 1], ta), tm);
+            v = lerp(v, v1, tc);
+        }
+        tr[q] = v;
+    }
+    const double log_teff = tr[0];
+#ifdef B9_ABL_HEAVY_CHEAPMATH
+    const double logg = LOG_G_PLUS_LOG_MSUN + (wd_mass - 1.0) * 0.43 - 2.0 * tr[1];
+#else
+    const double logg = LOG_G_PLUS_LOG_MSUN + log10(wd_mass) - 2.0 * tr[1];
+#endif
+    const int ty = (wd_type > 0 && pk.n_at_type > 1) ? 1 : 0;
+    const int it = bracket8<false>(ax.at_log_teff, pk.n_at_teff, log_teff);
+    c.t = (log_teff - ax.at_log_teff[it]) / (ax.at_log_teff[it + 1] - ax.at_log_teff[it]);
+    const int ig = bracket8<false>(ax.at_logg, pk.n_at_logg, logg);
+    c.tg = (logg - ax.at_logg[ig]) / (ax.at_logg[ig + 1] - ax.at_logg[ig]);
+    c.r0 = pk.at_mags + (((size_t)ty * pk.n_at_logg + ig) * pk.n_at_teff + it) * NFP;
+    c.r1 = c.r0 + (size_t)pk.n_at_teff * NFP;
+    c.kind = 2;
+    return c;
+}
+
+// Magnitude of a component in filter f.  Branch-free on purpose: the four table words are requested whatever the
+// kind (kinds 0, 1 and 3 point r0 / r1 at valid rows and ignore what comes back), so the loads of a whole batch of
+// filters -- both components, every population -- are in flight together; under per-kind branches every filter
+// paid its own memory round trip.  The selected value is formed by exactly star_mags' operations.
+template <int NFP>
+__device__ __forceinline__ double comp_mag(const Comp &c, int f)
+{
+    const double a = c.r0[f], b = c.r0[NFP + f], e = c.r1[f], g = c.r1[NFP + f];
+    const double v0 = lerp(a, b, c.t), v1 = lerp(e, g, c.t);
+    const double two = lerp(v0, v1, c.tg);
+    return c.kind == 1 ? v0 : (c.kind == 2 ? two : (c.kind == 3 ? -4.0 : B9_MAG_NOFLUX));
+}
+
+// One star through the descriptors, spread over 2 NPOPS neighbouring lanes: lane `sub` of the star's group evaluates
+// component (sub & 1) in population (sub >> 1).  The heavy role is a latency chain (a WD descriptor is ~30 dependent LDS
+// search steps, three library transcendentals and two memory round trips); laid end to end in one lane a two-population
+// binary cost four of them (22-30 us measured), side by side they cost one.  The lanes meet three times, by wave shuffles:
+// the secondary's magnitude (per filter), the other population's log-likelihood, and nothing else.  Every value is
+// formed by star_value's operations in star_value's order (same bits).  All lanes of a group must call (full EXEC);
+// the result is valid in the group's lane 0.
+template <int NFP, int NPOPS>
+__device__ __forceinline__ double star_value_lanes(const DevPack &pk, const WdAxes (&ax)[NPOPS], const IsoView<NFP> (&iso)[NPOPS],
+                                                   const double *__restrict__ par, const DevStars &st, int j /* index in the descending-mass list */,
+                                                   int sub, double log_lam, double log_1ml)
+{
+    const int comp = sub & 1;
+    const bool B = NPOPS == 2 && (sub >> 1) != 0;                    // this lane's population
+    // everything the star needs from memory is requested here, in one round trip (heavy-order arrays: DevStars::hv_*)
+    const double m1 = st.heavy_mass[j], q = st.hv_q[j], c0 = st.hv_c0[j], la = st.hv_la[j];
+    const int wd_type = st.hv_flags[j] & 1;
+    double obs[NFP], wgt[NFP];
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) { obs[f] = st.hv_obs[(size_t)f * st.hv_pad + j]; wgt[f] = st.hv_w[(size_t)f * st.hv_pad + j]; }
+    const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
+    const bool binary = q > 0.0;
+    // (field-by-field selects: indexing the local arrays with a per-lane population would put them in scratch memory)
+    const double *is_mass = B ? iso[NPOPS - 1].mass : iso[0].mass, *is_mags = B ? iso[NPOPS - 1].mags : iso[0].mags;
+    const int is_n = B ? iso[NPOPS - 1].n : iso[0].n;
+    const double is_tip = B ? iso[NPOPS - 1].tip : iso[0].tip, t_feh = B ? iso[NPOPS - 1].t_feh : iso[0].t_feh,
+                 t_y = B ? iso[NPOPS - 1].t_y : iso[0].t_y;
+    WdAxes axk = ax[0];                                               // only the four AGB-tip columns differ between populations
+#pragma unroll
+    for (int c = 0; c < 4; ++c) axk.tips[c] = B ? ax[NPOPS - 1].tips[c] : ax[0].tips[c];
+    Comp d; d.kind = 0; d.r0 = is_mags; d.r1 = is_mags; d.t = 0.0; d.tg = 0.0;
+    if (comp == 0 || binary) d = comp_desc<NFP>(pk, axk, is_mass, is_mags, is_n, is_tip, t_feh, t_y, par, comp ? q * m1 : m1, wd_type);
+    double chi2 = 0.0;
+#pragma unroll B9_HEAVY_UNROLL
+    for (int f = 0; f < NFP; ++f) {
+        double p = comp_mag<NFP>(d, f);
+        const double p2 = __shfl_xor(p, 1, 64);                       // the secondary's magnitude, in the primary's lane
+        if (binary) p -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (p2 - p));
+        const double dd = (p + (mod + pk.abs_m1[f] * av)) - obs[f];
+        chi2 = fma(wgt[f] * dd, dd, chi2);
+    }
+    const double ll = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
+    double l = ll;
+    if (NPOPS == 2) {
+        const double ll_b = __shfl_xor(ll, 2, 64);                    // population B's, in population A's lanes
+        l = logaddexp(log_lam + ll, log_1ml + ll_b);
+    }
+    return logaddexp(la, l);
 }
 
 // one star, all populations, field-star mixture: log( (1-p) fsLike + p L_i )

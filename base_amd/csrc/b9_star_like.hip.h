@@ -16,52 +16,12 @@
 #ifndef B9_K1_MIN_WAVES
 #define B9_K1_MIN_WAVES 3
 #endif
-#ifndef B9_K1_MIN_WAVES_2POP
-#define B9_K1_MIN_WAVES_2POP 2      // two populations: the loop-carried state pushes the body past 168 VGPRs
+#ifndef B9_K1_MIN_WAVES_16F
+#define B9_K1_MIN_WAVES_16F 2       // 16 padded filters: the body needs ~250 VGPRs; built for three waves it spills 230-330 B per lane
+                                    // and runs 30 % slower (50k x 16 x 8 walkers: 43.9 vs 30.6 us per step)
 #endif
-
-// Bracket of mass m in an LDS-resident mass column: the largest i in [0, n-2] with mass[i] <= m
-// (what the oracle's binary search returns -- the bracket is unique for a sorted column, so any
-// correct search yields the same i and hence bit-identical weights).  8-ary: every step issues 7
-// independent ds_reads and narrows the range eightfold, so a 400-point column takes 3 dependent
-// LDS round trips instead of the 9 of a binary search (measured: the binary search was 19 % of the
-// kernel's VALU instructions but 3.3 of its 20.5 us).
-__device__ __forceinline__ void find_bracket(const double *mass, int n, double m, int &lo_out, double &t_out)
-{
-    int lo = 0, len = n - 1;                 // the answer lies in [lo, lo + len)
-    while (len >= 8) {                       // 7 probes at lo + j*step, all inside the range (7*step < len)
-        const int step = len >> 3;
-        const double *p = mass + lo;
-        int c = 0;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) c += (p[j * step] <= m) ? 1 : 0;
-        lo += c * step;
-        len = (c == 7) ? len - 7 * step : step;
-    }
-    {                                        // fewer than 8 candidates left: probe them all at once
-        const double *p = mass + lo;
-        int c = 0;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) c += (j < len && p[j] <= m) ? 1 : 0;     // reads stay inside the column: lo + 7 <= n + 6 < capacity
-        lo += c;
-    }
-    const double a = mass[lo], d = mass[lo + 1] - a;
-#ifdef B9_EXACT_DIV
-    t_out = (d > 0.0) ? (m - a) / d : 0.0;
-#else
-    // (m - a) / d by a v_rcp_f64 seed, two Newton steps and a residual correction: within 1 ulp of
-    // the IEEE quotient (the weight is then off by <= 1e-16 relative -- seven orders inside the
-    // stated tolerance) at a third of the instructions and latency of the exact division sequence
-    const double num = m - a;
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    double tq = num * r;
-    tq = fma(fma(-d, tq, num), r, tq);
-    t_out = (d > 0.0) ? tq : 0.0;
-#endif
-    lo_out = lo;
-}
+// waves per SIMD the star kernels are built for (launch bounds): 3 = up to 168 VGPRs, 2 = up to 256
+#define B9_K1_WAVES(NFP, NPOPS) (((NFP) > 8 && B9_K1_MIN_WAVES > B9_K1_MIN_WAVES_16F) ? B9_K1_MIN_WAVES_16F : B9_K1_MIN_WAVES)
 
 #ifndef B9_EARLY_OBS
 #define B9_LATE_OBS 1        // measured: 20.3 us vs 22.3 us (early) on the 50k x 8 x 8 bench shape
@@ -92,6 +52,14 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
     // The isochrone view is picked with wave-uniform selects.
 #pragma unroll 1
     for (int k = 0; k < NPOPS; ++k) {
+#ifndef B9_NO_POP_LAUNDER
+        // Two populations: everything the second pass could share with the first (observations, weights, the
+        // per-filter shifts, both brackets' inputs) would be hoisted out of this loop and kept in registers across
+        // BOTH passes -- ~60 VGPRs, the difference between two and three waves per SIMD.  The star index and the
+        // absorption are passed through an empty asm so that each pass re-derives them (the re-read observations
+        // come from the L1 the first pass filled).
+        if (NPOPS == 2) { asm volatile("" : "+v"(il)); asm volatile("" : "+v"(av)); }
+#endif
         const double *is_mass = (NPOPS == 2 && k) ? iso[NPOPS - 1].mass : iso[0].mass;
         const double *is_mags = (NPOPS == 2 && k) ? iso[NPOPS - 1].mags : iso[0].mags;
         const int is_n = (NPOPS == 2 && k) ? iso[NPOPS - 1].n : iso[0].n;
@@ -269,6 +237,9 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
 // (heavy_mass / heavy_slot), that set is a prefix whose length each heavy workgroup finds with a
 // 256-ary search (two rounds for 50k stars).  The WD axes are staged in LDS.  `parts` workgroups
 // share a walker's heavy stars; each writes one partial.
+#ifndef B9_HEAVY_STAGE_E
+#define B9_HEAVY_STAGE_E 4          // staged axis elements a thread carries in registers across the count search (4 x 256 covers every pack here)
+#endif
 template <int NFP, int NPOPS>
 __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *__restrict__ hdr,
                                          const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
@@ -284,6 +255,42 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     double tip_min;
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
     if (!valid) { if (tid == 0) *out_partial = 0.0; return; }
+    // Everything the role stages in LDS -- the six WD axes and, per population, the AGB-tip columns of the four
+    // (FeH, Y) corners -- is ONE flat list of doubles; each thread requests its elements (<= B9_HEAVY_STAGE_E each)
+    // here, all loads independent, BEFORE the search for the number of heavy stars below, so that the whole staging
+    // costs one memory round trip that overlaps the search's (it used to be 6 + 4 NPOPS dependent trips).
+    HSTAMP(1);
+    constexpr int NSEG = 6 + 4 * NPOPS, E = B9_HEAVY_STAGE_E;
+    const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1;
+    const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
+    const double *seg_src[NSEG];
+    int seg_off[NSEG + 1];
+    {
+        const double *src6[6] = {pk.log_age, pk.wc_log_age, pk.wc_mass, pk.wc_carb, pk.at_log_teff, pk.at_logg};
+        const int len6[6] = {na, has_wd ? pk.n_wc_age : 0, has_wd ? pk.n_wc_mass : 0, has_wd ? pk.n_wc_carb : 0,
+                             has_wd ? pk.n_at_teff : 0, has_wd ? pk.n_at_logg : 0};
+        seg_off[0] = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { seg_src[a] = src6[a]; seg_off[a + 1] = seg_off[a] + len6[a]; }
+#pragma unroll
+        for (int kp = 0; kp < NPOPS; ++kp)               // each population brackets (FeH, Y) on its own
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int df = c >> 1, dy = c & 1, k = 6 + kp * 4 + c;
+                seg_src[k] = pk.tips + (size_t)((iso[kp].i_feh + df) * pk.n_y + (iso[kp].i_y + (dy < ny ? dy : 0))) * na;
+                seg_off[k + 1] = seg_off[k] + na;
+            }
+    }
+    const int n_stage = seg_off[NSEG];
+    double sv[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int e = tid + k * 256;
+        const double *src = seg_src[0] + e;
+#pragma unroll
+        for (int g = 1; g < NSEG; ++g) src = e >= seg_off[g] ? seg_src[g] + (e - seg_off[g]) : src;
+        sv[k] = e < n_stage ? *src : 0.0;
+    }
     int lo = 0, hi = st.n;                               // count = first k with heavy_mass[k] <= tip_min
     while (lo < hi) {
         const int span = hi - lo, step = (span + 255) / 256;
@@ -294,50 +301,72 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         else { const int nlo = lo + (c - 1) * step + 1, nhi = lo + c * step; lo = nlo; hi = nhi < hi ? nhi : hi; }
     }
     const int count = lo;
+    HSTAMP(2);
+#ifdef B9_GANTT
+    if (threadIdx.x == 0 && blockIdx.x < 64) g_gantt_heavy[blockIdx.x * 8 + 7] = (unsigned long long)count;
+#endif
     double acc = 0.0;
     if (count > 0) {
-        WdAxes ax[NPOPS];
-        const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1;
-        double *d = s_axes;
-        const double *src[6] = {pk.log_age, pk.wc_log_age, pk.wc_mass, pk.wc_carb, pk.at_log_teff, pk.at_logg};
-        const int len[6] = {na, pk.n_wc_age, pk.n_wc_mass, pk.n_wc_carb, pk.n_at_teff, pk.n_at_logg};
-        const double *dst[6];
-        for (int a = 0; a < 6; ++a) {
-            dst[a] = d;
-            for (int j = tid; j < len[a]; j += 256) d[j] = src[a][j];
-            d += len[a];
+#pragma unroll
+        for (int k = 0; k < E; ++k) { const int e = tid + k * 256; if (e < n_stage) s_axes[e] = sv[k]; }
+        for (int e = tid + E * 256; e < n_stage; e += 256) {       // very long axes only
+            const double *src = seg_src[0] + e;
+#pragma unroll
+            for (int g = 1; g < NSEG; ++g) src = e >= seg_off[g] ? seg_src[g] + (e - seg_off[g]) : src;
+            s_axes[e] = *src;
         }
-        for (int kp = 0; kp < NPOPS; ++kp)               // each population brackets (FeH, Y) on its own
-            for (int c = 0; c < 4; ++c) {
-                const int df = c >> 1, dy = c & 1;
-                const double *tips = pk.tips + (size_t)((iso[kp].i_feh + df) * pk.n_y + (iso[kp].i_y + (dy < ny ? dy : 0))) * na;
-                for (int j = tid; j < na; j += 256) d[j] = tips[j];
-                ax[kp].tips[c] = d;
-                d += na;
-            }
         __syncthreads();
+        HSTAMP(3);
+        WdAxes ax[NPOPS];
+#pragma unroll
         for (int kp = 0; kp < NPOPS; ++kp) {
-            ax[kp].log_age = dst[0]; ax[kp].wc_log_age = dst[1]; ax[kp].wc_mass = dst[2]; ax[kp].wc_carb = dst[3];
-            ax[kp].at_log_teff = dst[4]; ax[kp].at_logg = dst[5];
+            ax[kp].log_age = s_axes + seg_off[0]; ax[kp].wc_log_age = s_axes + seg_off[1]; ax[kp].wc_mass = s_axes + seg_off[2];
+            ax[kp].wc_carb = s_axes + seg_off[3]; ax[kp].at_log_teff = s_axes + seg_off[4]; ax[kp].at_logg = s_axes + seg_off[5];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ax[kp].tips[c] = s_axes + seg_off[6 + kp * 4 + c];
         }
         const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
         const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
-        for (int j = part * 256 + tid; j < count; j += parts * 256) {
-            const int i = st.heavy_slot[j];
-            const double v = star_value<NFP, NPOPS>(pk, ax, iso, par, st, i, log_lam, log_1ml);
-            if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
-            acc += v;
+        // A star occupies G = 2 NPOPS neighbouring lanes (star_value_lanes).  Chunks of 64 / G stars of the descending-mass
+        // list are dealt round-robin over the walker's workgroups first and over a workgroup's four waves second: a
+        // short list spreads over as many CUs as there are parts.
+        const int lane = tid & 63, wave = tid >> 6;
+#ifdef B9_HEAVY_ARRAYS      // (one lane per star, per-filter arrays: kept for comparison builds)
+        for (int c = part + parts * wave; c * 64 < count; c += parts * 4) {
+            const int j = c * 64 + lane;
+            if (j < count) {
+                const int i = st.heavy_slot[j];
+                const double v = star_value<NFP, NPOPS>(pk, ax, iso, par, st, i, log_lam, log_1ml);
+                if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
+                acc += v;
+            }
         }
+#else
+        constexpr int G = 2 * NPOPS, PER = 64 / G;
+        const int sub = lane % G;
+        for (int c = part + parts * wave; c * PER < count; c += parts * 4) {          // wave-uniform trip count: the shuffles see full EXEC
+            const int j = c * PER + lane / G;
+            const bool live = j < count;
+            const int jj = live ? j : count - 1;
+            const double v = star_value_lanes<NFP, NPOPS>(pk, ax, iso, par, st, jj, sub, log_lam, log_1ml);
+            if (live && sub == 0) {
+                if (perstar) perstar[(size_t)w * st.n + st.hv_perm[jj]] = v;
+                acc += v;
+            }
+        }
+#endif
     }
+    HSTAMP(4);
     const double sum = wave_sum(acc);
     __syncthreads();
+    HSTAMP(5);
     if ((tid & 63) == 0) s_red[tid >> 6] = sum;
     __syncthreads();
     if (tid == 0) *out_partial = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
 template <int NFP, int NPOPS, int WB>
-__global__ __launch_bounds__(256, (NPOPS == 2 && B9_K1_MIN_WAVES > B9_K1_MIN_WAVES_2POP) ? B9_K1_MIN_WAVES_2POP : B9_K1_MIN_WAVES) void k_star_like(DevPack pk, DevStars st,
+__global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevPack pk, DevStars st,
                                                     const IsoHdr *__restrict__ hdr,
                                                     const double *__restrict__ iso_data,
                                                     long long iso_stride, int mass_cap,

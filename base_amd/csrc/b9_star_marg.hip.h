@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, B9_MARG_MIN_WAVES) void k_star_marg(DevPack pk
                                                     int K, int Q, MargSample ms, int chunk_cap)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), w = blockIdx.y;
     const double *par = params + (size_t)w * B9_NPARAM;
     IsoView<NFP> iso[NPOPS];
     double tip_min;

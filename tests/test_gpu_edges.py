@@ -111,6 +111,57 @@ def test_reload_pack_then_same_stars():
     assert abs(b - want) <= 1e-9 * abs(want) and a != b
 
 
+def test_reload_pack_with_more_filters_same_eep_count():
+    """A context that has already evaluated with a 3-filter pack (rows of 4 + 1 doubles) gets an 8-filter pack of
+    the SAME isochrone length (rows of 8 + 1): the per-walker isochrone buffers must be re-sized, not re-used."""
+    from base_amd import engine
+    p3, cl3, pack3, stars3, priors3, options = build_problem("parsec", 3, n_stars=300)
+    eng = engine.Engine(pack3, stars3, priors3, options)
+    par3 = synth.walker_params(cl3["truth"], 6)
+    a = eng.logpost(par3)
+    assert _err(a, oracle.Oracle(pack3, stars3, priors3, options).logpost(par3)) <= 1e-9
+    p8, cl8, pack8, stars8, priors8, _ = build_problem("parsec", 8, n_stars=300)
+    assert p8["iso_n_eep"].max() == p3["iso_n_eep"].max()
+    eng.load_pack(pack8)
+    eng.load_stars(stars8)
+    eng.set_priors(priors8)
+    par8 = synth.walker_params(cl8["truth"], 6)
+    got, want = eng.logpost(par8, perstar=True), oracle.Oracle(pack8, stars8, priors8, options).logpost(par8, perstar=True)
+    assert _err(got[1], want[1]) <= 1e-9 and _err(got[0], want[0]) <= 1e-9
+    # and a sampler block on the re-sized buffers reproduces a fresh context's chain
+    free = np.array([abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS], dtype=np.int32)
+    chol = np.diag([2e-4, 1e-3, 5e-4, 3e-4])
+    ids = np.arange(6, dtype=np.int32)
+    r1 = eng.mcmc_run_block(par8, got[0], ids, free, chol, 5, 0, 12)
+    fresh = engine.Engine(pack8, stars8, priors8, options)
+    r2 = fresh.mcmc_run_block(par8, fresh.logpost(par8), ids, free, chol, 5, 0, 12)
+    np.testing.assert_array_equal(r1[2], r2[2])
+    np.testing.assert_array_equal(r1[3], r2[3])
+
+
+def test_load_stars_mass_validation():
+    """NaN / infinite mass1 and mass ratios outside [0, 1] are input errors; mass1 <= 0 is an error in given-mass mode
+    only (the marginalised mode takes mass1 as a hint)."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("dsed", 8, n_stars=40)
+    for key, idx, val in (("mass1", 3, np.nan), ("mass1", 4, np.inf), ("mass_ratio", 5, -0.1), ("mass_ratio", 6, 1.5), ("mass_ratio", 7, np.nan)):
+        bad = dict(cl); v = np.array(cl[key]).copy(); v[idx] = val; bad[key] = v
+        with pytest.raises(engine.B9Error) as e:
+            engine.Engine(pack, abi.make_stars(bad), priors, options)
+        assert e.value.code == abi.B9_ERR_INVALID
+    zero = dict(cl); v = np.array(cl["mass1"]).copy(); v[9] = 0.0; zero["mass1"] = v
+    zs = abi.make_stars(zero)
+    eng = engine.Engine(pack, zs, priors, options)                      # loading is fine ...
+    with pytest.raises(engine.B9Error) as e:
+        eng.logpost(cl["truth"][None, :])                                # ... evaluating in given-mass mode is not
+    assert e.value.code == abi.B9_ERR_INVALID
+    marg = abi.make_options(abi.MODE_MARGINALISED, 1, 2, 2)
+    eng.set_options(marg)
+    got = eng.logpost(cl["truth"][None, :], perstar=True)
+    want = oracle.Oracle(pack, zs, priors, marg).logpost(cl["truth"][None, :], perstar=True)
+    assert np.isfinite(got[0][0]) and _err(got[1], want[1]) <= 1e-9 and _err(got[0], want[0]) <= 1e-9
+
+
 def test_all_stars_heavy_and_all_unused():
     """Every star above the AGB tip (old walker), and a star with no usable filter."""
     from base_amd import engine

@@ -71,13 +71,19 @@ CASES = [
     ("dsed", 8, 1, 0.0, 1, 1, True),            # a single star
     ("dsed", 8, 63, 0.0, 1, 1, True),
     ("dsed", 8, 257, 0.3, 1, 1, True),
+    ("parsec", 8, 20000, 0.05, 1, 1, False),    # config 3 at FULL size (20k mixed MS + WD)
+    ("parsec", 8, 30000, 0.02, 3, 2, False),    # config 4 at FULL size (30k stars, two populations)
+    ("parsec", 8, 50000, 0.0, 1, 1, False),     # config 2 at FULL size (the bench.py cluster shape)
 ]
+FULL_SIZE = 20000       # cases from this size on run under the automatic launch plan only
 
 
 @pytest.mark.parametrize("name,n_filt,n_stars,wd_frac,n_y,n_pops,small", CASES)
 @pytest.mark.parametrize("plan", ["auto", "tpb3", "tpb8"])
 def test_logpost_matches_oracle(hip, monkeypatch, name, n_filt, n_stars, wd_frac, n_y, n_pops, small, plan):
     if plan != "auto":
+        if n_stars >= FULL_SIZE:
+            pytest.skip("full-size cases run under the automatic launch plan only")
         monkeypatch.setenv("B9_TILES_PER_BLOCK", plan[3:])
     pack_d, cl, pack, stars, priors, options = build_problem(name, n_filt, n_stars=n_stars, wd_frac=wd_frac,
                                                              n_y=n_y, n_pops=n_pops, small=small)

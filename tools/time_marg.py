@@ -12,7 +12,7 @@ opt = abi.make_options(abi.MODE_MARGINALISED, 1, K, Q)
 eng = engine.Engine(pack, stars, synth.default_priors(pack_d, truth), opt)
 params = synth.walker_params(truth, W, seed=42, scale=0.05)
 eng.logpost(params)
-t0 = time.perf_counter(); reps = 3
+t0 = time.perf_counter(); reps = 10
 for _ in range(reps): lp = eng.logpost(params)
 dt = (time.perf_counter() - t0) / reps
 nodes = 399 * K * Q
