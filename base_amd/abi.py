@@ -73,7 +73,13 @@ class b9_mcmc_block(C.Structure):
                 ("seed", C.c_uint64), ("step0", C.c_int64),
                 ("n_steps", C.c_int32), ("flags", C.c_int32),
                 ("params", _dp), ("logpost", _dp), ("samples", _dp), ("lps", _dp),
-                ("n_accept", C.c_int64)]
+                ("n_accept", C.c_int64),
+                ("row_origin", _dp), ("rows", _dp), ("d_rows", C.c_void_p), ("rows_ready", C.c_void_p)]
+
+
+def row_doubles(d: int) -> int:
+    """B9_ROW_DOUBLES(d): length of a walker's block summary row."""
+    return 15 + d + d * d
 
 
 def _f64(a) -> np.ndarray:

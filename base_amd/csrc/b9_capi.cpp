@@ -66,7 +66,9 @@ struct b9_ctx {
         bool in_flight = false;
         const void *owner = nullptr; // the b9_mcmc_block it was enqueued for
         int W = 0, final_parity = 0;
-        size_t o_nacc = 0, o_st0 = 0, o_st1 = 0, o_samp = 0, o_lps = 0, n_samp = 0, n_lps = 0;
+        size_t o_nacc = 0, o_st0 = 0, o_st1 = 0, o_samp = 0, o_lps = 0, o_rows = 0, n_samp = 0, n_lps = 0, n_rows = 0;
+        bool host_samples = false; // the caller asked for the chain record (else it only exists on the device, for the rows)
+        hipEvent_t rows_ready = nullptr;   // recorded right after the block's last kernel: the summary rows are in HBM
     } slot[2];
     int next_slot = 0, last_slot = -1;
     double *h_lp = nullptr, *h_lp_dev = nullptr;   // b9_logpost: 8 log-posteriors in mapped pinned host memory (host / device view)
@@ -440,6 +442,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
         if (sl.d) (void)hipFree(sl.d);
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.rows_ready) (void)hipEventDestroy(sl.rows_ready);
     }
     if (ctx->h_lp) (void)hipHostFree(ctx->h_lp);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
@@ -739,7 +742,8 @@ static int collect_block(b9_ctx *ctx, b9_ctx::McmcSlot &sl, b9_mcmc_block *blk)
         std::memcpy(blk->params + (size_t)w * B9_NPARAM, fin + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, sizeof(double) * B9_NPARAM);
         blk->logpost[w] = fin[(size_t)w * B9_STATE_STRIDE + B9_ST_LP];
     }
-    if (sl.n_samp && blk->samples) std::memcpy(blk->samples, stage + sl.o_samp, sl.n_samp * 8);
+    if (sl.n_samp && sl.host_samples && blk->samples) std::memcpy(blk->samples, stage + sl.o_samp, sl.n_samp * 8);
+    if (sl.n_rows && blk->rows) std::memcpy(blk->rows, stage + sl.o_rows, sl.n_rows * 8);
     if (sl.n_lps && blk->lps) std::memcpy(blk->lps, stage + sl.o_lps, sl.n_lps * 8);
     unsigned long long n_acc;
     std::memcpy(&n_acc, stage + sl.o_nacc, 8);
@@ -760,18 +764,21 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     if (sl.in_flight) return fail(ctx, B9_ERR_STATE, "two blocks are already outstanding: collect one with b9_mcmc_wait first");
     if (cont && (ctx->last_slot < 0 || ctx->slot[ctx->last_slot].W != W))
         return fail(ctx, B9_ERR_STATE, "B9_BLOCK_CONTINUE needs a previous block of this context with the same n_walkers");
+    const bool want_rows = blk->row_origin != nullptr;
     const size_t n_state = (size_t)W * B9_STATE_STRIDE, n_cur = (size_t)W * B9_NPARAM,
-                 n_samp = blk->samples ? (size_t)S * W * d : 0, n_lps = blk->lps ? (size_t)S * W : 0;
+                 n_samp = (blk->samples || want_rows) ? (size_t)S * W * d : 0, n_lps = blk->lps ? (size_t)S * W : 0,
+                 n_rows = want_rows ? (size_t)W * B9_ROW_LEN(d) : 0;
     // One device allocation, laid out so that the block needs ONE upload and ONE download (each small
     // pageable copy costs 10-20 us of host time, a block used to make six + four of them):
-    //   [cur0][lp0][chol][decided][free, ids][n_acc][state 0] | [state 1][samples][lps]
-    //   upload   = cur0 .. state 0        (starting state, proposal factor, RNG streams, cleared counters)
-    //   download = n_acc .. lps           (acceptance count, both state parities, chain record)
+    //   [cur0][lp0][chol][origin][decided][free, ids][n_acc][state 0] | [state 1][rows][lps][samples]
+    //   upload   = cur0 .. state 0        (starting state, proposal factor, moment origin, RNG streams, cleared counters)
+    //   download = n_acc .. lps (.. samples when the caller wants the chain)   (acceptance count, both state parities,
+    //              summary rows, log-posterior record, chain record)
     const size_t n_int = ((size_t)(d + W) + 1) / 2;                       // ints, in units of 8 bytes
-    const size_t o_cur0 = 0, o_lp0 = o_cur0 + n_cur, o_chol = o_lp0 + W, o_dec = o_chol + (size_t)d * d,
+    const size_t o_cur0 = 0, o_lp0 = o_cur0 + n_cur, o_chol = o_lp0 + W, o_org = o_chol + (size_t)d * d, o_dec = o_org + d,
                  o_int = o_dec + W, o_nacc = o_int + n_int, o_st0 = o_nacc + 1, o_st1 = o_st0 + n_state,
-                 o_samp = o_st1 + n_state, o_lps = o_samp + n_samp, n_total = o_lps + n_lps;
-    const size_t up_words = o_st1, down_words = n_total - o_nacc;
+                 o_rows = o_st1 + n_state, o_lps = o_rows + n_rows, o_samp = o_lps + n_lps, n_total = o_samp + n_samp;
+    const size_t up_words = o_st1, down_words = (blk->samples ? n_total : o_samp) - o_nacc;
     if (n_total * 8 > sl.cap) {
         // (a CONTINUE block reads the OTHER slot's final state, never this slot's old contents)
         if (sl.d) (void)hipFree(sl.d);
@@ -786,6 +793,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
         sl.hcap = n_total * 8;
     }
     if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.rows_ready) HIPCHK(ctx, hipEventCreateWithFlags(&sl.rows_ready, hipEventDisableTiming));
     double *const dev = static_cast<double *>(sl.d), *const stage = static_cast<double *>(sl.h);
     double *d_state = dev + o_st0;                   // [2][W][stride]; the block's first launch has parity 1 and reads parity 0
     double *d_cur0 = dev + o_cur0, *d_lp0 = dev + o_lp0, *d_chol = dev + o_chol;
@@ -801,6 +809,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
             std::memcpy(stage + o_lp0, blk->logpost, (size_t)W * 8);
         }
         std::memcpy(stage + o_chol, blk->chol, (size_t)d * d * 8);
+        if (want_rows) std::memcpy(stage + o_org, blk->row_origin, (size_t)d * 8); else std::memset(stage + o_org, 0, (size_t)d * 8);
         std::memset(stage + o_dec, 0xFF, (size_t)W * 8);                 // no step published yet
         int *hi = reinterpret_cast<int *>(stage + o_int);
         std::memcpy(hi, blk->free_idx, d * sizeof(int));
@@ -830,6 +839,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     sd.cand_par = ctx->d_params; sd.cand_hdr = ctx->d_hdr; sd.cand_iso = ctx->d_iso;
     sd.chol = d_chol; sd.free_idx = d_free; sd.walker_ids = d_ids;
     sd.samples = d_samples; sd.lps = d_lps; sd.n_acc = d_nacc; sd.decided = d_decided;
+    sd.rows = nullptr; sd.row_origin = dev + o_org; sd.n_steps = S;
     if (2 * (long long)sd.n_partial > sd.partial_stride) return fail(ctx, B9_ERR_CAPACITY, "partial buffer too small for two parities");
     {   // D0: proposal of step 0 and its isochrones -> candidate 0 of parity 1 (K(t) has parity (t + 1) & 1)
         McmcDev mc{};
@@ -864,11 +874,16 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     }
     sd.set = (S + 1) & 1; sd.has_prev = 1; sd.derive_next = 0; sd.row = S - 1;
     sd.step = (unsigned long long)(blk->step0 + S);
+    sd.rows = want_rows ? dev + o_rows : nullptr;
     HIPCHK(ctx, b9k_mcmc_finish(ctx->pk, sd, ctx->pr, s));
+    HIPCHK(ctx, hipEventRecord(sl.rows_ready, s));
+    blk->d_rows = want_rows ? (void *)(dev + o_rows) : nullptr;
+    blk->rows_ready = want_rows ? (void *)sl.rows_ready : nullptr;
     HIPCHK(ctx, hipMemcpyAsync(stage + o_nacc, dev + o_nacc, down_words * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipEventRecord(sl.done, s));
     sl.W = W; sl.final_parity = (S + 1) & 1;
     sl.o_nacc = o_nacc; sl.o_st0 = o_st0; sl.o_st1 = o_st1; sl.o_samp = o_samp; sl.o_lps = o_lps; sl.n_samp = n_samp; sl.n_lps = n_lps;
+    sl.o_rows = o_rows; sl.n_rows = n_rows; sl.host_samples = blk->samples != nullptr;
     sl.in_flight = true; sl.owner = blk;
     ctx->last_slot = ctx->next_slot;
     ctx->next_slot ^= 1;
@@ -898,6 +913,7 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     if (rc) return rc;
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) return run_block_fused(ctx, blk);
     if (blk->flags) return fail(ctx, B9_ERR_INVALID, "B9_BLOCK_CONTINUE / B9_BLOCK_ASYNC need the fused step (given-mass mode)");
+    if (blk->row_origin) return fail(ctx, B9_ERR_INVALID, "device summary rows (row_origin) need the fused step (given-mass mode): condense the samples on the host");
     // marginalised mode (and B9_TWO_LAUNCH_STEPS=1): two launches per step
     // one device allocation for the block's state
     const size_t n_cur = (size_t)W * B9_NPARAM, n_samp = blk->samples ? (size_t)S * W * d : 0,

@@ -141,4 +141,16 @@ struct StepDev {
     double *lps;                     // [n_steps][W] or null
     unsigned long long *n_acc;
     unsigned long long *decided;     // [W]: (step << 1 | sel) once this launch's writer has taken walker w's decision
+    // summary rows of the block (k_mcmc_finish only; null = none): one row of B9_ROW_DOUBLES(d) per walker
+    double *rows;                    // [W][15 + d + d*d]
+    const double *row_origin;        // [d] common origin of the moments
+    int n_steps;                     // steps of the block = rows of `samples` the summary covers
 };
+
+// Summary row of one walker over one block (b9_mcmc_block::rows; include/base9_hip.h documents the layout).
+#define B9_ROW_LP 0
+#define B9_ROW_POS 1                 // [1..12] position after the block
+#define B9_ROW_MOVED 13              // steps after the block's first on which the walker moved
+#define B9_ROW_N 14                  // steps of the block
+#define B9_ROW_SUM 15                // [15 .. 15+d) sum of x,  then [15+d .. 15+d+d*d) sum of x x^T;  x = sample - origin
+#define B9_ROW_LEN(d) (15 + (d) + (d) * (d))

@@ -203,7 +203,7 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
 // Candidate-derivation role (and, for candidate 0 / population 0 / part 0 of each walker, the
 // WRITER of the new state and of the chain record).
 __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd, const DevPriors &pr,
-                                            int w, int cand, int pop, int part, int parts)
+                                            int w, int cand, int pop, int part, int parts, double *s_state_out = nullptr)
 {
     const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers, n_pops = sd.n_pops;
     __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_prop[B9_NPARAM];
@@ -241,6 +241,10 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
     if (tid < B9_NPARAM) {
         s_cur[tid] = ok ? prev_prop_v : cur_v;             // state after step t-1
         s_prop[tid] = ok ? pc1 : pc0;                      // the proposal THIS launch's star workgroups evaluate
+    }
+    if (s_state_out) {                                     // (k_mcmc_finish: the state after the block, for its summary row)
+        if (tid < B9_NPARAM) s_state_out[tid] = ok ? prev_prop_v : cur_v;
+        if (tid == 0) s_state_out[B9_NPARAM] = lp_new;
     }
     const bool writer = (cand == 0 && pop == 0 && part == 0);
     if (writer && tid == 0 && sd.has_prev)                 // publish the outcome for workgroups that start later
@@ -368,10 +372,62 @@ void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_pe
 #endif
 }
 
-// the block's last decision: one workgroup per walker, writer role only
+// Summary row of walker w over the block (the multi-GPU driver all-gathers these rows straight from HBM and pools
+// them into the adaptive proposal): [lp, position(12), #moves, n, sum x, sum x x^T], x = chain sample - origin.
+// Every sum runs over the steps in ascending order with a plain multiply and add (no fma), so a host loop in that
+// order (b9h::summary_rows) gives the same bits.  One workgroup; s_last = the walker's state after the block.
+#define B9_ROWS_CHUNK 128
+__device__ __forceinline__ void block_summary_row(const StepDev &sd, int w, const double *s_last /* LDS: [12] position, [12] lp */)
+{
+    const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers, S = sd.n_steps;
+    __shared__ double s_x[(B9_ROWS_CHUNK + 1) * 11];       // row 0 = the last sample of the previous chunk
+    __shared__ int s_moved;
+    __shared__ double s_org[11];
+    if (tid == 0) s_moved = 0;
+    if (tid < d) s_org[tid] = sd.row_origin[tid];
+    __syncthreads();
+    const int i = tid / d, j = tid - i * d;                // thread (i, j) of the first d*d: sum x_i x_j; threads 128.. : sum x_i
+    const bool pair = tid < d * d, single = tid >= 128 && tid < 128 + d;
+    double acc = 0.0;
+    for (int s0 = 0; s0 < S; s0 += B9_ROWS_CHUNK) {
+        const int ns = (S - s0) < B9_ROWS_CHUNK ? (S - s0) : B9_ROWS_CHUNK;
+        if (s0 > 0 && tid < d) s_x[tid] = s_x[B9_ROWS_CHUNK * 11 + tid];         // carry the previous chunk's last sample
+        __syncthreads();
+        for (int e = tid; e < ns * d; e += 256) {
+            const int s = e / d, k = e - s * d, step = s0 + s;
+            // the block's last sample is this kernel's own output: take it from the state in LDS, not from memory
+            const double v = (step == S - 1) ? s_last[sd.free_idx[k]] : sd.samples[((size_t)step * W + w) * d + k];
+            s_x[(s + 1) * 11 + k] = v - s_org[k];
+        }
+        __syncthreads();
+        if (pair) for (int s = 1; s <= ns; ++s) acc = acc + s_x[s * 11 + i] * s_x[s * 11 + j];
+        if (single) for (int s = 1; s <= ns; ++s) acc = acc + s_x[s * 11 + (tid - 128)];
+        int moved = 0;
+        for (int s = 1 + tid; s <= ns; s += 256) {
+            if (s0 + s - 1 == 0) continue;                 // the block's first step has no predecessor in the block
+            bool diff = false;
+            for (int k = 0; k < d; ++k) diff = diff || (s_x[s * 11 + k] != s_x[(s - 1) * 11 + k]);
+            moved += diff ? 1 : 0;
+        }
+        if (moved) atomicAdd(&s_moved, moved);
+        __syncthreads();
+    }
+    double *row = sd.rows + (size_t)w * B9_ROW_LEN(d);
+    if (pair) row[B9_ROW_SUM + d + tid] = acc;
+    if (single) row[B9_ROW_SUM + (tid - 128)] = acc;
+    if (tid >= 192 && tid < 192 + B9_NPARAM) row[B9_ROW_POS + (tid - 192)] = s_last[tid - 192];
+    if (tid == 255) { row[B9_ROW_LP] = s_last[B9_NPARAM]; row[B9_ROW_MOVED] = (double)s_moved; row[B9_ROW_N] = (double)S; }
+}
+
+// the block's last decision: one workgroup per walker, writer role only (+ the block's summary rows)
 __global__ __launch_bounds__(256) void k_mcmc_finish(DevPack pk, StepDev sd, DevPriors pr)
 {
-    step_derive(pk, sd, pr, blockIdx.x, 0, 0, 0, 1);
+    __shared__ double s_last[B9_NPARAM + 1];
+    step_derive(pk, sd, pr, blockIdx.x, 0, 0, 0, 1, sd.rows ? s_last : nullptr);
+    if (sd.rows) {                                           // (uniform over the grid)
+        __syncthreads();
+        block_summary_row(sd, blockIdx.x, s_last);
+    }
 }
 
 #ifdef B9_STAMPS

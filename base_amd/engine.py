@@ -103,10 +103,11 @@ class Engine:
                                                   cont=False, asynchronous=False))
 
     def mcmc_submit(self, params, logpost, walker_ids, free, chol, seed, step0, n_steps, record=True, cont=False,
-                    asynchronous=True):
+                    asynchronous=True, row_origin=None):
         """Enqueue a block (B9_BLOCK_ASYNC) -- with cont=True from the state the previous block left on the device
         (B9_BLOCK_CONTINUE; params / logpost then only give the shapes).  Returns a handle for mcmc_collect; at
-        most two handles may be outstanding and they are collected in submission order."""
+        most two handles may be outstanding and they are collected in submission order.  With `row_origin` the
+        handle's "rows" receive the block's per-walker summary rows (b9_mcmc_block::rows)."""
         params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, abi.B9_NPARAM).copy()
         W, d = params.shape[0], len(free)
         logpost = np.ascontiguousarray(logpost, dtype=np.float64).copy()
@@ -124,6 +125,11 @@ class Engine:
         blk.logpost = logpost.ctypes.data_as(_dp)
         blk.samples = keep["samples"].ctypes.data_as(_dp) if record else None
         blk.lps = keep["lps"].ctypes.data_as(_dp) if record else None
+        if row_origin is not None:      # the block's last launch also condenses every walker's chain into a summary row
+            keep["origin"] = np.ascontiguousarray(row_origin, dtype=np.float64)
+            keep["rows"] = np.empty((W, abi.row_doubles(d)))
+            blk.row_origin = keep["origin"].ctypes.data_as(_dp)
+            blk.rows = keep["rows"].ctypes.data_as(_dp)
         self._check(self.lib.b9_mcmc_run_block(self._ctx, C.byref(blk)))
         keep["blk"], keep["pending"] = blk, bool(asynchronous and n_steps > 0)
         return keep

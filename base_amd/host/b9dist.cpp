@@ -1,0 +1,219 @@
+// b9dist.cpp -- see b9dist.hpp.  Host-only code: HIP runtime API + RCCL; compiled with hipcc for their headers.
+#include "b9dist.hpp"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace b9h {
+
+namespace {
+
+[[noreturn]] void fail(const std::string &msg) { throw std::runtime_error("b9dist: " + msg); }
+
+#define HIPX(call)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) fail(std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+#define NCCLX(call)                                                                             \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess) fail(std::string(#call) + ": " + ncclGetErrorString(r_));        \
+    } while (0)
+
+class LocalExchange final : public Exchange {
+  public:
+    int rank() const override { return 0; }
+    int world() const override { return 1; }
+    void start_host(int slot, const double *rows, size_t count) override { buf[slot & 1].assign(rows, rows + count); }
+    const double *finish(int slot) override { return buf[slot & 1].data(); }
+    const char *name() const override { return "none (one rank)"; }
+
+  private:
+    std::vector<double> buf[2];
+};
+
+class RcclExchange final : public Exchange {
+  public:
+    RcclExchange(int rank, int world, const std::string &dir, int device, double timeout_s) : rank_(rank), world_(world), device_(device)
+    {
+        if (world < 1 || rank < 0 || rank >= world) fail("bad rank / world");
+        HIPX(hipSetDevice(device));
+        ncclUniqueId id;
+        const std::string path = dir + "/rccl_id";
+        if (rank == 0) {
+            NCCLX(ncclGetUniqueId(&id));
+            ::mkdir(dir.c_str(), 0700);                       // may exist already (the launcher made it)
+            const std::string tmp = path + ".tmp";
+            FILE *f = std::fopen(tmp.c_str(), "wb");
+            if (!f) fail("cannot write " + tmp);
+            const size_t n = std::fwrite(&id, 1, sizeof id, f);
+            std::fclose(f);
+            if (n != sizeof id || std::rename(tmp.c_str(), path.c_str()) != 0) fail("cannot publish " + path);
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                FILE *f = std::fopen(path.c_str(), "rb");
+                if (f) {
+                    const size_t n = std::fread(&id, 1, sizeof id, f);
+                    std::fclose(f);
+                    if (n == sizeof id) break;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                    fail("rank " + std::to_string(rank) + " timed out waiting for " + path);
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+        }
+        NCCLX(ncclCommInitRank(&comm_, world, id, rank));
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            HIPX(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest));
+        else
+            HIPX(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        for (auto &s : slot_) HIPX(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIPX(hipMalloc((void **)&d_scalar_, sizeof(double) * 2));
+        HIPX(hipHostMalloc((void **)&h_scalar_, sizeof(double) * 2, hipHostMallocDefault));
+        barrier();                                            // everyone has read the id
+        if (rank == 0) std::remove(path.c_str());
+    }
+
+    ~RcclExchange() override
+    {
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(stream_);
+        if (comm_) (void)ncclCommDestroy(comm_);
+        for (auto &s : slot_) {
+            if (s.d_send) (void)hipFree(s.d_send);
+            if (s.d_recv) (void)hipFree(s.d_recv);
+            if (s.h_send) (void)hipHostFree(s.h_send);
+            if (s.h_recv) (void)hipHostFree(s.h_recv);
+            if (s.done) (void)hipEventDestroy(s.done);
+        }
+        if (d_scalar_) (void)hipFree(d_scalar_);
+        if (h_scalar_) (void)hipHostFree(h_scalar_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+
+    int rank() const override { return rank_; }
+    int world() const override { return world_; }
+    const char *name() const override { return "RCCL all-gather (ncclAllGather over xGMI, device buffers, own high-priority stream)"; }
+
+    bool start_device(int slot, const double *d_rows, void *ready_event, size_t count) override
+    {
+        Slot &s = slot_[slot & 1];
+        ensure(s, count);
+        HIPX(hipSetDevice(device_));
+        if (ready_event) HIPX(hipStreamWaitEvent(stream_, static_cast<hipEvent_t>(ready_event), 0));
+        gather(s, d_rows, count);
+        return true;
+    }
+
+    void start_host(int slot, const double *rows, size_t count) override
+    {
+        Slot &s = slot_[slot & 1];
+        ensure(s, count);
+        HIPX(hipSetDevice(device_));
+        std::memcpy(s.h_send, rows, count * sizeof(double));
+        HIPX(hipMemcpyAsync(s.d_send, s.h_send, count * sizeof(double), hipMemcpyHostToDevice, stream_));
+        gather(s, s.d_send, count);
+    }
+
+    const double *finish(int slot) override
+    {
+        Slot &s = slot_[slot & 1];
+        HIPX(hipEventSynchronize(s.done));
+        return s.h_recv;
+    }
+
+    double all_reduce_max(double v) override
+    {
+        HIPX(hipSetDevice(device_));
+        h_scalar_[0] = v;
+        HIPX(hipMemcpyAsync(d_scalar_, h_scalar_, sizeof(double), hipMemcpyHostToDevice, stream_));
+        NCCLX(ncclAllReduce(d_scalar_, d_scalar_ + 1, 1, ncclDouble, ncclMax, comm_, stream_));
+        HIPX(hipMemcpyAsync(h_scalar_ + 1, d_scalar_ + 1, sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIPX(hipStreamSynchronize(stream_));
+        return h_scalar_[1];
+    }
+
+    void barrier() override { (void)all_reduce_max(0.0); }
+
+  private:
+    struct Slot {
+        double *d_send = nullptr, *d_recv = nullptr, *h_send = nullptr, *h_recv = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+    };
+
+    void ensure(Slot &s, size_t count)
+    {
+        if (count <= s.cap) return;
+        HIPX(hipSetDevice(device_));
+        HIPX(hipStreamSynchronize(stream_));
+        if (s.d_send) (void)hipFree(s.d_send);
+        if (s.d_recv) (void)hipFree(s.d_recv);
+        if (s.h_send) (void)hipHostFree(s.h_send);
+        if (s.h_recv) (void)hipHostFree(s.h_recv);
+        s.d_send = s.d_recv = s.h_send = s.h_recv = nullptr;
+        HIPX(hipMalloc((void **)&s.d_send, count * sizeof(double)));
+        HIPX(hipMalloc((void **)&s.d_recv, count * world_ * sizeof(double)));
+        HIPX(hipHostMalloc((void **)&s.h_send, count * sizeof(double), hipHostMallocDefault));
+        HIPX(hipHostMalloc((void **)&s.h_recv, count * world_ * sizeof(double), hipHostMallocDefault));
+        s.cap = count;
+    }
+
+    void gather(Slot &s, const double *d_src, size_t count)
+    {
+        NCCLX(ncclAllGather(d_src, s.d_recv, count, ncclDouble, comm_, stream_));
+        HIPX(hipMemcpyAsync(s.h_recv, s.d_recv, count * world_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIPX(hipEventRecord(s.done, stream_));
+    }
+
+    int rank_, world_, device_;
+    ncclComm_t comm_ = nullptr;
+    hipStream_t stream_ = nullptr;
+    Slot slot_[2];
+    double *d_scalar_ = nullptr, *h_scalar_ = nullptr;
+};
+
+}  // namespace
+
+std::unique_ptr<Exchange> make_local_exchange() { return std::unique_ptr<Exchange>(new LocalExchange()); }
+
+std::unique_ptr<Exchange> make_rccl_exchange(int rank, int world, const std::string &dir, int device, double timeout_s)
+{
+    return std::unique_ptr<Exchange>(new RcclExchange(rank, world, dir, device, timeout_s));
+}
+
+std::string default_bootstrap_dir()
+{
+    if (const char *d = std::getenv("B9_DIST_DIR")) return d;
+    const char *port = std::getenv("MASTER_PORT");
+    const char *tmp = std::getenv("TMPDIR");
+    return std::string(tmp && *tmp ? tmp : "/tmp") + "/b9dist_" + std::to_string((long)getppid()) + "_" + (port ? port : "0");
+}
+
+void rank_from_env(int &rank, int &world, int &local_rank)
+{
+    auto get = [](const char *a, const char *b, int def) {
+        const char *v = std::getenv(a);
+        if (!v) v = std::getenv(b);
+        return v ? std::atoi(v) : def;
+    };
+    rank = get("B9_RANK", "RANK", 0);
+    world = get("B9_WORLD_SIZE", "WORLD_SIZE", 1);
+    local_rank = get("B9_LOCAL_RANK", "LOCAL_RANK", rank);
+}
+
+}  // namespace b9h

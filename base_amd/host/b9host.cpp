@@ -2,7 +2,6 @@
 #include "b9host.hpp"
 
 #include <algorithm>
-#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -122,7 +121,8 @@ const std::map<std::string, std::string> &Settings::flag_map()
         {"burnIter", "singlePopMcmc.stage2IterMax"}, {"stage3Iter", "singlePopMcmc.stage3Iter"},
         {"runIter", "singlePopMcmc.runIter"}, {"thin", "singlePopMcmc.thin"},
         {"seed", "general.seed"}, {"verbose", "general.verbose"},
-        {"walkers", "gpu.walkers"}, {"device", "gpu.device"}, {"block", "gpu.block"},
+        {"walkers", "gpu.walkers"}, {"device", "gpu.device"}, {"block", "gpu.block"}, {"gpus", "gpu.gpus"},
+        {"mode", "gpu.mode"}, {"marginalise", "gpu.marginalise"},
         {"margIsoIncrem", "sampleMass.margIsoIncrem"}, {"nMassRatios", "sampleMass.nMassRatios"},
     };
     return m;
@@ -137,7 +137,7 @@ void Settings::parse_args(int argc, char **argv)
         std::string value;
         size_t eq = a.find('=');
         if (eq != std::string::npos) { value = a.substr(eq + 1); a = a.substr(0, eq); }
-        else if (a == "verbose") value = "1";
+        else if (a == "verbose" || a == "marginalise") value = "1";
         else { if (i + 1 >= argc) fail("flag --" + a + " needs a value"); value = argv[++i]; }
         if (a == "config") { load_yaml(value); continue; }
         auto it = flag_map().find(a);
@@ -463,181 +463,6 @@ const char *param_name(int idx)
     static const char *n[B9_NPARAM] = {"logAge", "Y", "FeH", "modulus", "absorption", "carbonicity",
                                        "IFMRconst", "IFMRlin", "IFMRquad", "YB", "lambda", "reserved"};
     return (idx >= 0 && idx < B9_NPARAM) ? n[idx] : "?";
-}
-
-// ---------------------------------------------------------------------------------------------
-// Sampler
-// ---------------------------------------------------------------------------------------------
-namespace {
-
-// multiplicative update of the global step scale from a block's acceptance rate (target 0.2-0.35;
-// far from it the correction is strong, so a badly scaled start is repaired within a few blocks)
-double step_scale_factor(double rate)
-{
-    if (rate < 0.02) return 0.2;
-    if (rate < 0.10) return 0.5;
-    if (rate < 0.20) return 0.8;
-    if (rate > 0.90) return 4.0;
-    if (rate > 0.70) return 2.0;
-    if (rate > 0.50) return 1.5;
-    if (rate > 0.35) return 1.2;
-    return 1.0;
-}
-
-bool cholesky(std::vector<double> &a, int d)      // in place, lower; false if not positive definite
-{
-    for (int j = 0; j < d; ++j) {
-        double s = a[j * d + j];
-        for (int k = 0; k < j; ++k) s -= a[j * d + k] * a[j * d + k];
-        if (!(s > 0.0)) return false;
-        a[j * d + j] = std::sqrt(s);
-        for (int i = j + 1; i < d; ++i) {
-            double t = a[i * d + j];
-            for (int k = 0; k < j; ++k) t -= a[i * d + k] * a[j * d + k];
-            a[i * d + j] = t / a[j * d + j];
-        }
-        for (int i = 0; i < j; ++i) a[i * d + j] = 0.0;
-    }
-    return true;
-}
-
-}  // namespace
-
-McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double> &start_row, int n_stars, ResultWriter *out)
-{
-    const int W = cfg.n_walkers, d = (int)cfg.free_idx.size();
-    if (W < 1 || d < 1 || d > 11) fail("run_mcmc: need 1..11 sampled parameters and at least one walker");
-    std::vector<double> params((size_t)W * B9_NPARAM), logpost(W);
-    for (int w = 0; w < W; ++w) std::copy(start_row.begin(), start_row.begin() + B9_NPARAM, params.begin() + (size_t)w * B9_NPARAM);
-    if (b9_logpost(ctx, params.data(), W, logpost.data(), nullptr) != B9_OK) fail(b9_last_error(ctx));
-    if (!std::isfinite(logpost[0])) fail("the starting parameters have zero posterior probability (outside the model grid or the prior support)");
-
-    std::vector<double> chol((size_t)d * d, 0.0), chol_scaled((size_t)d * d);
-    for (int i = 0; i < d; ++i) chol[i * d + i] = cfg.step[i];
-    std::vector<int32_t> ids(W);
-    for (int w = 0; w < W; ++w) ids[w] = w;
-    double scale = 1.0, n_mom = 0.0;
-    bool shaped = false;
-    constexpr double kForget = 0.9;
-    std::vector<double> mean(d, 0.0), m2((size_t)d * d, 0.0);
-    McmcResult res;
-    const long total = cfg.burn_iter + cfg.run_iter;
-    // the blocks of the run (burn-in and main run never share a block)
-    struct Blk { long start; int n; bool burning; };
-    std::vector<Blk> blocks;
-    for (long done = 0; done < total;) {
-        const bool burning = done < cfg.burn_iter;
-        const int n = (int)std::min<long>(cfg.block, (burning ? cfg.burn_iter : total) - done);
-        blocks.push_back({done, n, burning});
-        done += n;
-    }
-    // Blocks are pipelined on the device (B9_BLOCK_CONTINUE | B9_BLOCK_ASYNC): block b+1 is enqueued -- from the state
-    // block b will leave in HBM -- as soon as block b-1 has been collected, written out and used for the adaptation,
-    // so its proposal is adapted from blocks <= b-1 and the GPU's queue never drains.  The first block of the main
-    // run waits for the whole burn-in: the main run's proposal is frozen [RECALL].
-    struct Slot { std::vector<double> samples, lps, params, logpost, chol; b9_mcmc_block blk{}; };
-    Slot slot[2];
-    const auto t0 = std::chrono::steady_clock::now();
-
-    auto enqueue = [&](size_t b) {
-        Slot &s = slot[b & 1];
-        const Blk &k = blocks[b];
-        s.samples.assign((size_t)k.n * W * d, 0.0); s.lps.assign((size_t)k.n * W, 0.0);
-        s.params = params; s.logpost = logpost;                       // inputs only for the very first block
-        s.chol.resize(chol.size());
-        for (size_t i = 0; i < chol.size(); ++i) s.chol[i] = scale * chol[i];
-        s.blk = b9_mcmc_block{};
-        s.blk.n_walkers = W; s.blk.n_free = d; s.blk.free_idx = cfg.free_idx.data(); s.blk.chol = s.chol.data();
-        s.blk.walker_ids = ids.data(); s.blk.seed = cfg.seed; s.blk.step0 = k.start; s.blk.n_steps = k.n;
-        s.blk.flags = B9_BLOCK_ASYNC | (b > 0 ? B9_BLOCK_CONTINUE : 0);
-        s.blk.params = s.params.data(); s.blk.logpost = s.logpost.data(); s.blk.samples = s.samples.data(); s.blk.lps = s.lps.data();
-        if (b9_mcmc_run_block(ctx, &s.blk) != B9_OK) fail(b9_last_error(ctx));
-    };
-
-    auto finish = [&](size_t b) {
-        Slot &s = slot[b & 1];
-        const Blk &k = blocks[b];
-        if (b9_mcmc_wait(ctx, &s.blk) != B9_OK) fail(b9_last_error(ctx));
-        params = s.params; logpost = s.logpost;
-        const std::vector<double> &samples = s.samples, &lps = s.lps;
-        const int n = k.n;
-        const long done = k.start;
-        const bool burning = k.burning;
-        const b9_mcmc_block &blk = s.blk;
-        res.accepted += blk.n_accept; res.steps += n;
-        // output
-        if (out)
-            for (int st = 0; st < n; ++st) {
-                if ((done + st) % cfg.thin) continue;
-                for (int w = 0; w < W; ++w) {
-                    std::vector<double> v(samples.begin() + ((size_t)st * W + w) * d, samples.begin() + ((size_t)st * W + w + 1) * d);
-                    out->row(v, lps[(size_t)st * W + w], burning ? (done < cfg.burn_iter / 2 ? 1 : 2) : 3);
-                }
-            }
-        // adaptation (burn-in only, as the reference freezes the proposal for the main run [RECALL])
-        if (burning) {
-            // exponentially forgotten moments (window ~ 1/(1-kForget) blocks): the start-up transient and the
-            // part of a degeneracy ridge the chain has already left stop shaping the proposal
-            n_mom *= kForget;
-            for (double &v : m2) v *= kForget;
-            for (int st = 0; st < n; ++st) for (int w = 0; w < W; ++w) {
-                const double *x = &samples[((size_t)st * W + w) * d];
-                n_mom += 1.0;
-                std::vector<double> dl(d);
-                for (int i = 0; i < d; ++i) { dl[i] = x[i] - mean[i]; mean[i] += dl[i] / n_mom; }
-                for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) m2[i * d + j] += dl[i] * (x[j] - mean[j]);
-            }
-            const double rate = (double)blk.n_accept / ((double)n * W);
-            scale = std::min(std::max(scale * step_scale_factor(rate), 1e-8), 1e8);     // stays finite whatever the acceptance does
-            if (n_mom > 20.0 * d) {
-                std::vector<double> cov((size_t)d * d);
-                for (int i = 0; i < d * d; ++i) cov[i] = m2[i] / (n_mom - 1.0) * (2.38 * 2.38 / d);
-                // A chain that has hardly moved yet (bad starting scale) has a collapsed sample covariance:
-                // adopting it would freeze the sampler.  Only take it once no direction is more than
-                // 100x narrower than the current (scaled) proposal already is.
-                bool usable = true;
-                for (int i = 0; i < d; ++i) {
-                    double cur = 0.0;
-                    for (int j = 0; j <= i; ++j) cur += chol[i * d + j] * chol[i * d + j];
-                    if (!(cov[i * d + i] > 1e-4 * scale * scale * cur)) usable = false;
-                }
-                if (usable) {
-                    for (int i = 0; i < d; ++i) cov[i * d + i] *= 1.0 + 1e-9;
-                    if (cholesky(cov, d)) {
-                        if (!shaped) {
-                            // first switch from the diagonal start-up steps to a learnt shape: keep the volume of
-                            // the scaled proposal (the acceptance-tuned size carries over, only the shape changes)
-                            double lr = 0.0;
-                            for (int i = 0; i < d; ++i) lr += std::log(chol[i * d + i]) - std::log(cov[i * d + i]);
-                            scale *= std::exp(lr / d);
-                            shaped = true;
-                        }
-                        chol = cov;                          // `scale` keeps multiplying it and keeps adapting
-                    }
-                }
-            }
-        }
-        if (cfg.verbose) std::fprintf(stderr, "  step %ld/%ld  accept %.3f  scale %.3g  logPost[0] %.4f\n", done + n, total, (double)res.accepted / ((double)res.steps * W), scale, logpost[0]);
-    };
-
-    // e = next block to enqueue, f = next block to finish; at most two outstanding.  Block b may be enqueued once
-    // blocks <= b-2 are finished (its proposal is then adapted from them: one block of lag) -- or, when it opens the
-    // main run, once the whole burn-in is.
-    const size_t B = blocks.size();
-    size_t e = 0, f = 0;
-    auto may_enqueue = [&](size_t b) {
-        if (b == 0) return true;
-        const bool opens_main = !blocks[b].burning && blocks[b - 1].burning;
-        return opens_main ? f >= b : f + 1 >= b;
-    };
-    while (f < B) {
-        while (e < B && e - f < 2 && may_enqueue(e)) { enqueue(e); ++e; }
-        finish(f);
-        ++f;
-    }
-    res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    res.star_evals_per_s = (double)res.steps * W * n_stars / res.seconds;
-    return res;
 }
 
 }  // namespace b9h

@@ -81,28 +81,6 @@ class ResultWriter {
     void *fp;
 };
 
-// ---- the sampler ----------------------------------------------------------------------------------
-struct McmcConfig {
-    std::vector<int32_t> free_idx;        // sampled parameters (B9_P_*)
-    std::vector<double> step;             // initial step size per sampled parameter
-    int n_walkers = 1;
-    long burn_iter = 2000, run_iter = 10000, thin = 1, block = 50;
-    uint64_t seed = 73;
-    bool verbose = false;
-};
-
-struct McmcResult {
-    long accepted = 0, steps = 0;
-    double seconds = 0.0, star_evals_per_s = 0.0;
-};
-
-// Adaptive Metropolis ([RECALL] the staged burn-in of MpiMcmcApplication): device-resident blocks
-// (b9_mcmc_run_block); after every block the pooled covariance of all walkers' history and the
-// acceptance rate re-derive the proposal.  Burn-in rows are written with stage 1..2, the main run
-// with stage 3.  Only the walkers' samples and log-posteriors ever leave the GPU.
-McmcResult run_mcmc(b9_ctx *ctx, const McmcConfig &cfg, const std::vector<double> &start_row,
-                    int n_stars, ResultWriter *out);
-
 const char *param_name(int idx);          // "logAge", "Y", "FeH", "modulus", "absorption", ...
 
 }  // namespace b9h

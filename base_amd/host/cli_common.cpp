@@ -1,9 +1,16 @@
 #include "cli_common.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
 #include <stdexcept>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 namespace b9h {
 
@@ -96,8 +103,24 @@ void open_session(Session &s, int argc, char **argv, int n_pops, bool need_phot)
     s.mcmc.seed = (uint64_t)st.integer("general.seed", 73);
     s.mcmc.verbose = st.integer("general.verbose", 0) != 0;
 
-    // ---- GPU context ----------------------------------------------------------------------------
-    if (b9_ctx_create((int)st.integer("gpu.device", -1), &s.ctx) != B9_OK) throw std::runtime_error(b9_last_error(nullptr));
+    // ---- evaluation mode: every star at its catalogue (mass1, massRatio), or marginalised over both ---------------
+    {
+        std::string mode = st.str("gpu.mode", "givenMass");
+        std::transform(mode.begin(), mode.end(), mode.begin(), ::tolower);
+        if (st.integer("gpu.marginalise", 0) != 0 || mode == "marginalised" || mode == "marginalized" || mode == "marg")
+            s.options.mode = B9_MODE_MARGINALISED;
+        else if (mode != "givenmass" && mode != "given-mass" && mode != "given_mass")
+            throw std::runtime_error("gpu.mode must be givenMass or marginalised");
+        s.options.n_pops = n_pops;
+        s.options.marg_iso_increm = (int32_t)std::max<long>(1, st.integer("sampleMass.margIsoIncrem", 8));
+        s.options.marg_n_q = (int32_t)std::max<long>(1, st.integer("sampleMass.nMassRatios", 8));
+    }
+    // ---- GPU context (a rank of a --gpus N launch takes the GPU of its local rank) ------------------------------------
+    rank_from_env(s.rank, s.world, s.local_rank);
+    if (s.world > 1 && s.mcmc.n_walkers % s.world)
+        throw std::runtime_error("the number of walkers (--walkers) must be a multiple of the number of GPUs (--gpus)");
+    const int device = s.world > 1 ? s.local_rank : (int)st.integer("gpu.device", -1);
+    if (b9_ctx_create(device, &s.ctx) != B9_OK) throw std::runtime_error(b9_last_error(nullptr));
     auto check = [&](int rc) { if (rc != B9_OK) throw std::runtime_error(b9_last_error(s.ctx)); };
     b9_pack pv = s.pack.view();
     check(b9_load_pack(s.ctx, &pv));
@@ -106,8 +129,115 @@ void open_session(Session &s, int argc, char **argv, int n_pops, bool need_phot)
         check(b9_load_stars(s.ctx, &sv));
     }
     check(b9_set_priors(s.ctx, &s.priors));
-    b9_options opt{B9_MODE_GIVEN_MASS, n_pops, 8, 8};
-    check(b9_set_options(s.ctx, &opt));
+    check(b9_set_options(s.ctx, &s.options));
+}
+
+bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
+{
+    if (std::getenv("B9_RANK") || std::getenv("RANK")) return false;           // already a rank of some launcher
+    Settings st;
+    st.parse_args(argc, argv);                                                  // (flags and YAML only: nothing touches a GPU)
+    const int n = (int)st.integer("gpu.gpus", 1);
+    if (n <= 1) return false;
+    char dir[] = "/tmp/b9dist_XXXXXX";
+    if (!mkdtemp(dir)) throw std::runtime_error("cannot create a directory for the RCCL bootstrap");
+    std::vector<pid_t> kids;
+    for (int r = 0; r < n; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) throw std::runtime_error("fork failed");
+        if (pid == 0) {
+            setenv("B9_RANK", std::to_string(r).c_str(), 1);
+            setenv("B9_WORLD_SIZE", std::to_string(n).c_str(), 1);
+            setenv("B9_LOCAL_RANK", std::to_string(r).c_str(), 1);
+            setenv("B9_DIST_DIR", dir, 1);
+            setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      // dmabuf IPC (what this driver supports) unless the user chose
+            execv("/proc/self/exe", argv);
+            std::perror("execv");
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t k : kids) {
+        int status = 0;
+        if (waitpid(k, &status, 0) < 0) { worst = std::max(worst, 1); continue; }
+        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+        worst = std::max(worst, code);
+    }
+    std::remove((std::string(dir) + "/rccl_id").c_str());
+    rmdir(dir);
+    *exit_code = worst;
+    return true;
+}
+
+McmcResult run_mcmc(Session &s, Exchange &ex, const std::vector<std::string> &columns)
+{
+    const McmcConfig &cfg = s.mcmc;
+    const int W = cfg.n_walkers, d = (int)cfg.free_idx.size();
+    SamplerConfig sc;
+    sc.n_walkers = W; sc.free_idx = cfg.free_idx; sc.step = cfg.step; sc.seed = cfg.seed; sc.block = (int)cfg.block;
+    const int per = W / ex.world();
+    std::vector<int32_t> ids(per);
+    for (int k = 0; k < per; ++k) ids[k] = ex.rank() * per + k;
+    auto runner = make_device_runner(s.ctx, per, ids, cfg.free_idx, cfg.seed, s.options.mode);
+    WalkerSampler sampler(sc, runner.get(), &ex);
+    std::vector<double> start((size_t)W * B9_NPARAM);
+    for (int w = 0; w < W; ++w) std::copy(s.start.begin(), s.start.begin() + B9_NPARAM, start.begin() + (size_t)w * B9_NPARAM);
+    sampler.initialise(start.data());
+    if (!std::isfinite(sampler.all_logpost()[0]))
+        throw std::runtime_error("the starting parameters have zero posterior probability (outside the model grid or the prior support)");
+
+    const std::string final_path = s.output_base + ".res";
+    const std::string my_path = ex.world() > 1 ? final_path + ".part" + std::to_string(ex.rank()) : final_path;
+    std::unique_ptr<ResultWriter> out(new ResultWriter(my_path, columns));
+    const long total = cfg.burn_iter + cfg.run_iter;
+    std::vector<double> v(d);
+    auto sink = [&](const BlockRecord &r) {
+        for (int st = 0; st < r.n_steps; ++st) {
+            const long step = r.step0 + st;
+            if (step % cfg.thin) continue;
+            const int stage = r.adapting ? (step < cfg.burn_iter / 2 ? 1 : 2) : 3;
+            for (int w = 0; w < r.n_local; ++w) {
+                std::copy(r.samples + ((size_t)st * r.n_local + w) * d, r.samples + ((size_t)st * r.n_local + w + 1) * d, v.begin());
+                out->row(v, r.lps[(size_t)st * r.n_local + w], stage);
+            }
+        }
+        if (cfg.verbose && ex.rank() == 0)
+            std::fprintf(stderr, "  step %ld/%ld  scale %.3g  logPost[0] %.4f\n", r.step0 + r.n_steps, total, sampler.scale(), sampler.all_logpost()[0]);
+    };
+    ex.barrier();
+    const auto t0 = std::chrono::steady_clock::now();
+    sampler.run(cfg.burn_iter, true, sink);          // the proposal adapts (pooled over all walkers of all ranks) ...
+    sampler.run(cfg.run_iter, false, sink);          // ... and is frozen for the main run [RECALL]
+    McmcResult res;
+    res.seconds = ex.all_reduce_max(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    res.steps = sampler.steps();
+    res.accepted = sampler.accepted_local();
+    res.star_evals_per_s = (double)res.steps * W * s.phot.n_stars() / res.seconds;
+    out.reset();
+    if (ex.world() > 1) {
+        ex.barrier();                                 // every part file is complete
+        if (ex.rank() == 0) {
+            std::vector<std::ifstream> parts;
+            for (int r = 0; r < ex.world(); ++r) {
+                parts.emplace_back(final_path + ".part" + std::to_string(r));
+                if (!parts.back()) throw std::runtime_error("cannot read " + final_path + ".part" + std::to_string(r));
+            }
+            std::ofstream fin(final_path);
+            std::string line;
+            for (int r = 0; r < ex.world(); ++r) { std::getline(parts[r], line); if (r == 0) fin << line << "\n"; }     // header
+            for (bool more = true; more;)
+                for (int r = 0; r < ex.world() && more; ++r)
+                    for (int w = 0; w < per; ++w) {
+                        if (!std::getline(parts[r], line)) { more = false; break; }
+                        fin << line << "\n";
+                    }
+            parts.clear();
+            for (int r = 0; r < ex.world(); ++r) std::remove((final_path + ".part" + std::to_string(r)).c_str());
+        }
+        ex.barrier();
+    }
+    return res;
 }
 
 int report_and_exit_code(const char *prog, const std::exception &e)

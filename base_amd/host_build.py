@@ -25,14 +25,33 @@ def _stale(target: str, sources: List[str]) -> bool:
     return not os.path.exists(target) or any(os.path.getmtime(s) > os.path.getmtime(target) for s in sources)
 
 
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+
+
 def build_host(force: bool = False) -> None:
+    """libbase9host.so = parsers + sampler (g++) + the RCCL exchange and the C surface (hipcc as a host compiler, for the
+    HIP / RCCL headers: neither file holds device code); it links libbase9hip.so, librccl and libamdhip64."""
     os.makedirs(BIN, exist_ok=True)
-    hdrs = [os.path.join(HOST, f) for f in ("b9host.hpp", "cli_common.hpp")] + [os.path.join(HERE, "..", "include", "base9_hip.h")]
+    hdrs = [os.path.join(HOST, f) for f in ("b9host.hpp", "cli_common.hpp", "b9sampler.hpp", "b9dist.hpp")] + \
+        [os.path.join(HERE, "..", "include", f) for f in ("base9_hip.h", "base9_host.h")]
     lib = os.path.join(HOST, "libbase9host.so")
-    lib_src = [os.path.join(HOST, f) for f in ("b9host.cpp", "cli_common.cpp", "capi_host.cpp")]
+    gxx_src = ["b9host.cpp", "b9sampler.cpp", "cli_common.cpp"]
+    hip_src = ["b9dist.cpp", "capi_host.cpp"]
     link = ["-L" + CSRC, "-lbase9hip", "-Wl,-rpath," + CSRC, "-Wl,-rpath,$ORIGIN/../../csrc"]
-    if force or _stale(lib, lib_src + hdrs):
-        _run(CXX + ["-shared", "-o", lib] + lib_src + link)
+    if force or _stale(lib, [os.path.join(HOST, f) for f in gxx_src + hip_src] + hdrs):
+        objs = []
+        for f in gxx_src:
+            o = os.path.join(HOST, f.replace(".cpp", ".o"))
+            _run(CXX + ["-ffp-contract=off", "-c", "-o", o, os.path.join(HOST, f)])
+            objs.append(o)
+        for f in hip_src:
+            o = os.path.join(HOST, f.replace(".cpp", ".o"))
+            _run([HIPCC, "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
+                  "-c", "-o", o, os.path.join(HOST, f)])
+            objs.append(o)
+        _run(["g++", "-shared", "-o", lib] + objs + link + ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lamdhip64",
+                                                            "-Wl,-rpath," + os.path.join(ROCM, "lib")])
     progs = {"singlePopMcmc": ("mcmc_main.cpp", ["-DB9_N_POPS=1"]), "multiPopMcmc": ("mcmc_main.cpp", ["-DB9_N_POPS=2"]),
              "makeCMD": ("makecmd_main.cpp", []), "sampleMass": ("samplemass_main.cpp", [])}
     for name, (src, defs) in progs.items():

@@ -3,40 +3,79 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric: "star-likelihood evals/sec ... on synthetic 50k-star x 8-filter
-clusters at 1 GPU, with 1/2/4/8-GPU walker-parallel throughput"; configs[2] sharded 8 ways):
-50 000 stars x 8 filters, PARSEC-shaped synthetic pack, 8 walkers per GPU (weak scaling: 64
-walkers at 8 GPUs).  One "step" is one adaptive-Metropolis step of every walker: propose ->
-log-posterior of the rank's walkers -> accept/reject, all on the GPU (one HIP launch per step behind
-the C ABI, b9_mcmc_run_block); every 100 steps the ranks exchange one RCCL all-gather of
-per-walker rows and re-derive the pooled proposal covariance.  Star data and model tables are
-resident in HBM before the timed region starts.
+Workload (BASELINE.json metric: "star-likelihood evals/sec ... on synthetic 50k-star x 8-filter clusters at 1 GPU,
+with 1/2/4/8-GPU walker-parallel throughput"; configs[2] sharded 8 ways): 50 000 stars x 8 filters, PARSEC-shaped
+synthetic pack, 8 walkers per GPU (weak scaling: 64 walkers at 8 GPUs).  One "step" is one adaptive-Metropolis step of
+every walker: propose -> log-posterior of the rank's walkers -> accept/reject, all on the GPU (ONE HIP launch per step
+behind the C ABI, b9_mcmc_run_block); every 100 steps the ranks exchange one all-gather of per-walker summary rows --
+condensed on the GPU, gathered from HBM by RCCL over xGMI -- and re-derive the pooled proposal covariance.  The driver
+is the C++ host library (base_amd/host/b9sampler.cpp, b9dist.cpp): no torch, no Python in the timed loop beyond one
+ctypes call.  Star data and model tables are resident in HBM before the timed region starts.
 
-value     = n_stars x total walkers x K / max-over-ranks wall time   (whole job, all GPUs)
-roofline  = the dominant kernel (k_mcmc_step, the fused sampler step: star likelihood of the step's
-            proposal + the previous step's accept/reject + the next step's candidate isochrones): algorithmic bytes per launch / its mean launch
-            duration, measured with HIP events on the launch stream inside this run
-cpu_baseline = the CPU oracle ("port"; the reference itself is not mounted)
-            timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1)
+Launching.  `python bench.py --gpus N ...` invoked plainly starts its own N rank processes (one per GPU) before
+anything touches a GPU, waits for them and relays rank 0's JSON line.  Under a launcher that already exports RANK /
+WORLD_SIZE / LOCAL_RANK (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...) the process is a rank.
+
+value        = n_stars x total walkers x K / max-over-ranks wall time   (whole job, all GPUs)
+roofline     = the dominant kernel (k_mcmc_step, the fused sampler step).  The kernel is NOT HBM-bound: the walkers of
+               a GPU share every star tile through the XCD-local L2, and its waves spend their time in dependent
+               fp64 VALU chains.  Three figures are reported, each against its own peak: fp64 VALU issue (the bound
+               the counters name; `frac`), HBM traffic (counters), and the algorithmic byte rate of SURVEY.md 8(d).
+               Launch duration is measured live with HIP events on the launch stream; instruction and byte counts per
+               launch come from the committed rocprofv3 PMC passes of this same command (profiles/, tagged).
+cpu_baseline = the CPU oracle ("port"; the reference itself is not mounted) timed on this
+               box's host cores on a bounded sample of the same workload (rank 0, N=1)
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+CLOCK_GHZ, N_SIMD = 2.4, 1024   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock; an fp64 VALU wave-instruction issues in 4 cycles
 N_STARS, N_FILT, WALKERS_PER_GPU = 50000, 8, 8
-MCMC_BLOCK = 100       # steps between adaptation points (= between all-gathers)
+MCMC_BLOCK = 100        # steps between adaptation points (= between all-gathers)
 TIMING_EVERY = 25       # a HIP-event bracket opens at every 25th launch of the dominant kernel in the timed region and spans 8 launches
+PREWARM_STEPS = 300     # untimed, BEFORE the W warm-up steps: clocks, first touch of every buffer, RCCL channels
+PROFILE_TAG = "r02"     # profiles/<tag>_summary.json: rocprofv3 PMC passes of this command (tools/profile_round.sh)
+
+
+def launch_ranks(args) -> int:
+    """Plain `bench.py --gpus N`: start N rank processes (no GPU call has been made in this one), relay rank 0's line."""
+    dist_dir = tempfile.mkdtemp(prefix="b9dist_")
+    procs, logs = [], []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), B9_DIST_DIR=dist_dir,
+                   MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else open(os.path.join(dist_dir, f"rank{r}.log"), "w")
+        logs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out, stderr=subprocess.STDOUT if out else None))
+    rc = 0
+    for r, p in enumerate(procs):
+        rc = max(rc, abs(p.wait()))
+    for r, f in enumerate(logs):
+        if f:
+            f.close()
+            txt = open(f.name).read()
+            if txt.strip() and rc:
+                sys.stderr.write(f"---- rank {r} ----\n{txt}\n")
+            os.unlink(f.name)
+    try:
+        os.rmdir(dist_dir)
+    except OSError:
+        pass
+    return rc
 
 
 def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0, eng=None):
@@ -44,6 +83,7 @@ def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0, eng=None):
     (OpenMP over stars, as the reference's thread pool [RECALL]) and one thread.  With `eng`, the same
     leg also reports BASELINE.json's second figure, |delta logPost| of the HIP path against that CPU
     path, over 128 random in-grid parameter rows on the full 50k-star cluster."""
+    import numpy as np
     import oracle
     from base_amd import abi, synth
     try:
@@ -76,7 +116,6 @@ def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0, eng=None):
     best, best_cores = (v_all, cores) if v_all >= v_one else (v_one, 1)      # the CPU's best effort is the baseline
     delta = None
     if eng is not None:
-        import numpy as np
         orc.lib.b9o_set_threads(cores)
         rows = synth.walker_params(truth, 128, seed=4242, scale=1.0)      # a wide ball around the truth, all inside the grid
         want = orc.logpost(rows)
@@ -112,37 +151,41 @@ def marginalised_leg(pack, stars, priors, truth, local_rank, n_calls: int = 5):
             "ms_per_logpost_call": 1e3 * dt, "calls": n_calls}
 
 
+def profile_counters():
+    """Per-launch counters of k_mcmc_step from the committed rocprofv3 PMC passes of this command, with their provenance."""
+    pth = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_summary.json")
+    if not os.path.exists(pth):
+        return None
+    doc = json.load(open(pth))
+    for kname, c in doc.get("pmc", {}).items():
+        if kname.startswith("k_mcmc_step"):
+            return {"source": f"profiles/{PROFILE_TAG}_summary.json", "commit": doc.get("commit"), "command": doc.get("command"),
+                    "kernel": kname, "hbm_bytes_per_launch": c.get("hbm_bytes_per_launch"),
+                    "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "valu_active_quad_cycles_per_launch": c.get("SQ_ACTIVE_INST_VALU"),
+                    "wave_quad_cycles_per_launch": c.get("SQ_WAVE_CYCLES"), "waves_per_launch": c.get("SQ_WAVES")}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the HIP-event bracketing of k_mcmc_step")
+    ap.add_argument("--no-prewarm", action="store_true", help="diagnostic: skip the untimed pre-warm block")
     args = ap.parse_args()
 
-    import torch
-    from base_amd import abi, engine, mcmc, synth
+    is_rank = "RANK" in os.environ or "B9_RANK" in os.environ
+    if args.gpus > 1 and not is_rank:
+        raise SystemExit(launch_ranks(args))          # (nothing above touches a GPU)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    from base_amd import abi, engine, hostlib, mcmc, synth
+
+    rank, world, local_rank = hostlib.rank_from_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    local_rank = local_rank % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one GPU
-    torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or os.environ.get("B9_FORCE_DIST") == "1"     # the latter: 1-rank rehearsal of the collectives
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            torch.distributed.init_process_group(args.backend)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
 
     # ---- synthetic inputs (identical on every rank: fixed seeds) -----------------------------
     pack_d = synth.make_pack("parsec", N_FILT)
@@ -151,56 +194,50 @@ def main():
     pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
     priors, options = synth.default_priors(pack_d, truth), abi.make_options()
     eng = engine.Engine(pack, stars, priors, options, device=local_rank)
+    exchange = hostlib.Exchange.rccl(rank, world, eng.device_id()) if world > 1 else hostlib.Exchange.local()
     n_walkers = WALKERS_PER_GPU * world
     start = synth.walker_params(truth, n_walkers, seed=42, scale=0.02)
-    gather = mcmc.torch_all_gather("cuda" if args.backend == "nccl" else None) if use_dist else None
-    block = MCMC_BLOCK
-    sampler = mcmc.WalkerSampler(start, mcmc.DeviceBlockRunner(eng, record=True), rank, world, gather,
-                                 seed=2024, block=block)
-    sampler.initialise(eng.logpost)
+    free = mcmc.DEFAULT_FREE
+    sampler = hostlib.HostSampler(n_walkers, free, [mcmc.DEFAULT_STEP[k] for k in free], exchange, seed=2024,
+                                  block=MCMC_BLOCK, engine=eng)
+    sampler.initialise(start)
 
     def barrier():
-        if use_dist:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+        exchange.barrier()
+        hostlib._check(hostlib.load().b9h_device_synchronize())
 
-    sampler.run(args.warmup)
-    acc0 = sampler.accepted
+    prewarm = 0 if args.no_prewarm else PREWARM_STEPS
+    if prewarm:
+        sampler.run(prewarm)                # untimed and not part of W: clocks, first touch, RCCL channels
+    sampler.run(args.warmup)                # the W untimed warm-up steps
+    acc0 = sampler.state()["accepted_local"]
     eng.enable_timing(0 if args.no_kernel_timing else TIMING_EVERY)     # also pre-creates the HIP-event pool
     eng.kernel_time_ms(reset=True)
     barrier()
     t0 = time.perf_counter()
-    sampler.run(args.steps)             # exactly K steps, in device-resident blocks of <= MCMC_BLOCK
+    sampler.run(args.steps)                 # exactly K steps, in device-resident blocks of <= MCMC_BLOCK (one C++ call)
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     k_ms, k_n = eng.kernel_time_ms(reset=True)
     eng.enable_timing(0)
     bracket_ms = eng.calibrate_timing()     # event bracket around an empty kernel, same stream
-
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = exchange.max(dt_local)             # max over ranks (RCCL all-reduce)
+    st = sampler.state()
 
     if rank == 0:
         evals = float(N_STARS) * n_walkers * args.steps
-        bytes_eval = eng.bytes_per_star_eval()
-        bytes_launch = float(bytes_eval) * N_STARS * WALKERS_PER_GPU
-        # The HIP-event bracket includes one dispatch boundary, so it reads ~3 us above rocprofv3's
-        # kernel-only average of the same command (profiles/); it is used as is (conservative).  The
-        # same bracket around an EMPTY kernel is reported for scale, never subtracted.
+        star_evals_launch = float(N_STARS) * WALKERS_PER_GPU
+        # The HIP-event bracket spans 8 consecutive launches; its time / 8 is the kernel's launch PERIOD (duration +
+        # the ~1.5 us dispatch boundary), a little above rocprofv3's kernel-only average of the same command (profiles/).
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
-        achieved = bytes_launch / k_avg_s / 1e9 if k_n > 0 else 0.0
-        # HBM traffic per launch of the dominant kernel: from the committed PMC passes of this same
-        # command (profiles/<round>_summary.json, tools/profile_round.sh); null when absent
-        traffic = None
-        for tag in ("r01",):
-            pth = os.path.join(ROOT, "profiles", f"{tag}_summary.json")
-            if os.path.exists(pth):
-                pm = json.load(open(pth)).get("pmc", {})
-                for kname, c in pm.items():
-                    if kname.startswith("k_mcmc_step") and "hbm_bytes_per_launch" in c:
-                        traffic = c["hbm_bytes_per_launch"]
+        pc = profile_counters()
+        valu_cycles = 4.0 * pc["valu_active_quad_cycles_per_launch"] if pc and pc.get("valu_active_quad_cycles_per_launch") else None
+        valu_peak = N_SIMD * CLOCK_GHZ * 1e9                   # VALU issue cycles per second, whole chip
+        valu_rate = valu_cycles / k_avg_s if valu_cycles and k_n else None
+        hbm_bytes = pc["hbm_bytes_per_launch"] if pc else None
+        hbm_rate = hbm_bytes / k_avg_s / 1e9 if hbm_bytes and k_n else None
+        alg152, alg_layout = 152.0, float(eng.bytes_per_star_eval())
+        kernel_ms = 1e3 * k_avg_s * args.steps if k_n else None
         out = {
             "metric": "star-likelihood evals/sec", "value": evals / dt, "unit": "star-likelihood evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -208,17 +245,34 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3: 50k-star x 8-filter synthetic cluster, PARSEC-shaped synthetic pack "
-                                   "(10 FeH x 60 ages x 400 EEPs), given-mass mode, 8 walkers per GPU",
+                                   "(10 FeH x 60 ages x 400 EEPs), given-mass mode, 8 walkers per GPU; one LANE per star "
+                                   "(64-star chunks, per-wave shuffle reduction, fixed-order sum of the per-wave partials) -- "
+                                   "not one wavefront per star: with one interpolation per star a wave per star would idle 63 "
+                                   "lanes; the marginalised mode (marginalised_mode below) is one wavefront per star",
                        "n_stars": N_STARS, "n_filters": N_FILT, "walkers_per_gpu": WALKERS_PER_GPU,
-                       "walkers_total": n_walkers, "parallelism": f"walkers{world}",
-                       "mcmc_block": block,
-                       "collective": "one all_gather of [logpost, position, moments] rows per 100-step block" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "walkers_total": n_walkers, "parallelism": f"walkers{world}", "ranks": exchange.world,
+                       "mcmc_block": MCMC_BLOCK, "driver": "C++ host library (b9h::WalkerSampler), one call for the K steps",
+                       "collective": (exchange.name + "; one all-gather of [logpost, position, moments] rows per block") if world > 1 else "none",
+                       "prewarm_steps_untimed": prewarm},
+            "roofline": {"bound": "valu", "unit": "fp64 VALU issue cycles/s (all SIMDs)",
+                         "achieved": valu_rate, "peak": valu_peak, "frac": (valu_rate / valu_peak) if valu_rate else None,
+                         "traffic": hbm_bytes,
                          "kernel": "k_mcmc_step", "launches_timed": k_n, "timed_every": TIMING_EVERY, "launches_per_bracket": 8,
                          "avg_launch_us": 1e6 * k_avg_s, "empty_kernel_bracket_us": 1e3 * bracket_ms,
-                         "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_star_eval": bytes_eval},
-            "accept_rate": (sampler.accepted - acc0) / float(WALKERS_PER_GPU * args.steps),
+                         "hbm": {"achieved": hbm_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (hbm_rate / HBM_PEAK_GBS) if hbm_rate else None, "bytes_per_launch": hbm_bytes},
+                         "algorithmic": {"bytes_per_star_eval_survey_8d": alg152, "bytes_per_star_eval_layout": alg_layout,
+                                         "star_evals_per_launch": star_evals_launch,
+                                         "rate_GBps_8d": star_evals_launch * alg152 / k_avg_s / 1e9 if k_n else None,
+                                         "frac_of_hbm_peak_8d": star_evals_launch * alg152 / k_avg_s / 1e9 / HBM_PEAK_GBS if k_n else None,
+                                         "note": "an L2-served rate: the 8 walkers of a GPU re-read a star tile from the XCD-local L2, "
+                                                 "so these bytes never cross HBM 8 times; NOT an HBM fraction"},
+                         "counters": pc,
+                         "note": "launch duration measured live (HIP events on the launch stream); per-launch instruction and "
+                                 "byte counts from the committed rocprofv3 PMC passes of this command (counters.source / .commit)"},
+            "timed_region_breakdown": {"kernel_ms": kernel_ms, "host_and_block_fixed_ms": (1e3 * dt - kernel_ms) if kernel_ms else None,
+                                       "wall_ms": 1e3 * dt, "ms_per_step_over_launch_period": (1e3 * dt / args.steps) / (1e3 * k_avg_s) if k_n else None},
+            "accept_rate": (st["accepted_local"] - acc0) / float(WALKERS_PER_GPU * args.steps),
             "parity": "vs this repo's CPU oracle (BASE-9 parity unpinned: reference source not mounted)",
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -227,8 +281,10 @@ def main():
         if world == 1:
             out["marginalised_mode"] = marginalised_leg(pack, stars, priors, truth, local_rank)
         print(json.dumps(out), flush=True)
-    if use_dist:
-        torch.distributed.destroy_process_group()
+    exchange.barrier()
+    sampler.close()
+    exchange.close()
+    eng.close()
 
 
 if __name__ == "__main__":

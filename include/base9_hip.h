@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define B9_ABI_VERSION 1
+#define B9_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------ */
 typedef enum b9_status {
@@ -210,7 +210,22 @@ typedef struct b9_mcmc_block {
     double *samples;             /* out, nullable                                             */
     double *lps;                 /* out, nullable                                             */
     int64_t n_accept;            /* out                                                       */
+    /* ---- block summary rows (ABI 2; given-mass mode).  row_origin != NULL: the block's last launch also condenses
+     * every walker's chain into ONE row of B9_ROW_DOUBLES(n_free) doubles on the device,
+     *     [0] log-posterior after the block   [1..12] position after the block
+     *     [13] steps after the block's first on which the walker moved   [14] n_steps
+     *     [15 .. 15+d) sum_s x_s    [15+d .. 15+d+d*d) sum_s x_s x_s^T (row-major),   x_s = sample_s - row_origin,
+     * sums over the steps in ascending order, plain multiply and add.  These rows are what a walker-parallel driver
+     * exchanges between GPUs for the adaptive proposal: d_rows is their DEVICE address (valid until the second-next
+     * block of this context is enqueued) and rows_ready a hipEvent_t recorded on the context's stream once they are
+     * written, so a collective on another stream can read them from HBM without a host round trip.  `rows` (host,
+     * nullable) receives a copy when the block is collected. */
+    const double *row_origin;    /* [n_free] or NULL                                          */
+    double *rows;                /* out, nullable: [n_walkers][B9_ROW_DOUBLES(n_free)]         */
+    void *d_rows;                /* out: device pointer to the same rows                       */
+    void *rows_ready;            /* out: hipEvent_t                                            */
 } b9_mcmc_block;
+#define B9_ROW_DOUBLES(d) (15 + (d) + (d) * (d))
 int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk);
 
 /*

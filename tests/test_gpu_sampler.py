@@ -1,0 +1,142 @@
+"""GPU tests of the C++ walker-parallel driver on its product path: device-resident pipelined blocks, summary rows
+condensed by the block's last launch, RCCL exchange.  (Its host logic alone is covered on CPU by test_sampler_host.py.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from base_amd import abi, hostlib, mcmc, synth
+from conftest import build_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FREE = (abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS)
+STEP = [mcmc.DEFAULT_STEP[k] for k in FREE]
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("n_steps,d", [(1, 4), (37, 4), (128, 2), (300, 5)])
+def test_device_summary_rows_equal_the_host_statement(n_steps, d):
+    """b9_mcmc_block::rows (k_mcmc_finish) against b9h::summary_rows of the downloaded chain: the same bits."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=700, wd_frac=0.03, small=False, seed=5)
+    eng = engine.Engine(pack, stars, priors, options)
+    W = 6
+    free = np.array((abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS, abi.P_CARBONICITY)[:d], dtype=np.int32)
+    start = synth.walker_params(cl["truth"], W, seed=3, scale=0.05)
+    lp = eng.logpost(start)
+    chol = np.diag([mcmc.DEFAULT_STEP[int(k)] for k in free]) * 2.0
+    origin = start[:, free].mean(axis=0)
+    h = eng.mcmc_submit(start, lp, np.arange(W), free, chol, 21, 0, n_steps, record=True, asynchronous=False, row_origin=origin)
+    params, logpost, samples, lps, n_acc = eng.mcmc_collect(h)
+    want = hostlib.summary_rows(samples, params, logpost, origin)
+    np.testing.assert_array_equal(h["rows"], want)
+    assert h["rows"][:, 14].tolist() == [n_steps] * W
+    # rows without a host chain record: the samples exist on the device only
+    h2 = eng.mcmc_submit(start, lp, np.arange(W), free, chol, 21, 0, n_steps, record=False, asynchronous=False, row_origin=origin)
+    eng.mcmc_collect(h2)
+    np.testing.assert_array_equal(h2["rows"], want)
+
+
+def _device_run(eng, exchange, start, n_walkers=8, burn=150, main=50, block=50, seed=77):
+    s = hostlib.HostSampler(n_walkers, FREE, STEP, exchange, seed=seed, block=block, engine=eng)
+    s.initialise(start)
+    a = s.run(burn, adapt=True, record=True)
+    b = s.run(main, adapt=False, record=True)
+    return s.state(), np.concatenate([a[0], b[0]]), np.concatenate([a[1], b[1]])
+
+
+def test_device_sampler_equals_the_host_twin_and_one_rank_rccl():
+    """The C++ sampler on the GPU (fused steps, pipelined blocks, device rows) produces the chain of the same sampler
+    driven block by block through the numpy twin of the device step (HostBlockRunner over the engine's log-posterior):
+    same proposals, same decisions, same adaptation (to the ulp of the two normal generators).  A one-rank RCCL exchange (ncclAllGather reading the rows in
+    HBM) changes nothing."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=3000, wd_frac=0.02, small=False, seed=8)
+    eng = engine.Engine(pack, stars, priors, options)
+    start = synth.walker_params(cl["truth"], 8, seed=42, scale=0.05)
+    st_dev, samples_dev, lps_dev = _device_run(eng, hostlib.Exchange.local(), start)
+    assert 0.03 < st_dev["accepted_local"] / (200 * 8) < 0.97
+    twin = mcmc.HostBlockRunner(eng.logpost)
+    s = hostlib.HostSampler(8, FREE, STEP, hostlib.Exchange.local(), seed=77, block=50, run_block=twin.run, evaluate=eng.logpost)
+    s.initialise(start)
+    a = s.run(150, adapt=True, record=True)
+    b = s.run(50, adapt=False, record=True)
+    # (the twin's normals come from numpy's log / sin / cos, the device's from its own: equal to an ulp, as in test_gpu_mcmc)
+    np.testing.assert_allclose(np.concatenate([a[0], b[0]]), samples_dev, rtol=1e-12, atol=1e-13)
+    st_twin = s.state()
+    np.testing.assert_allclose(st_twin["chol"], st_dev["chol"], rtol=1e-8, atol=1e-14)
+    assert abs(st_twin["scale"] / st_dev["scale"] - 1.0) < 1e-8
+    # the chain's log-posteriors agree with the oracle at the visited points (spot check)
+    orc = oracle.Oracle(pack, stars, priors, options)
+    rows = np.repeat(start[:1], 5, axis=0)
+    rows[:, list(FREE)] = samples_dev[[10, 60, 110, 160, 199], 0]
+    want = orc.logpost(rows)
+    got = lps_dev[[10, 60, 110, 160, 199], 0]
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-9
+    # one-rank RCCL group
+    ex = hostlib.Exchange.rccl(0, 1, eng.device_id(), directory=None)
+    assert "RCCL" in ex.name
+    st_rccl, samples_rccl, _ = _device_run(eng, ex, start)
+    np.testing.assert_array_equal(samples_rccl, samples_dev)
+    np.testing.assert_array_equal(st_rccl["chol"], st_dev["chol"])
+
+
+def test_marginalised_mode_through_the_sampler():
+    """Marginalised mode has no fused step: synchronous two-launch blocks, rows condensed on the host from the chain."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, _ = build_problem("dsed", 8, n_stars=200, seed=4)
+    options = abi.make_options(abi.MODE_MARGINALISED, 1, 2, 2)
+    eng = engine.Engine(pack, stars, priors, options)
+    start = synth.walker_params(cl["truth"], 4, seed=1, scale=0.05)
+    s = hostlib.HostSampler(4, FREE, STEP, hostlib.Exchange.local(), seed=5, block=10, engine=eng)
+    s.initialise(start)
+    samples, lps = s.run(30, adapt=True, record=True)
+    orc = oracle.Oracle(pack, stars, priors, options)
+    rows = np.repeat(start[:1], 3, axis=0)
+    rows[:, list(FREE)] = samples[[3, 17, 29], 1]
+    want = orc.logpost(rows)
+    assert np.max(np.abs(lps[[3, 17, 29], 1] - want) / np.maximum(1.0, np.abs(want))) <= 1e-9
+    assert s.state()["steps"] == 30
+
+
+def test_bench_self_launch_two_ranks_on_one_box():
+    """`python bench.py --gpus 2` invoked plainly starts its own ranks and prints rank 0's line (needs 2 GPUs)."""
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and "RCCL" in line["config"]["collective"]
+    assert line["config"]["walkers_total"] == 16 and line["value"] > 0
+
+
+def test_cli_two_gpus_chains_equal_one_gpu(tmp_path):
+    """singlePopMcmc --gpus 2 (one process per GPU, RCCL all-gather of the rows in HBM): the merged .res is the
+    one-GPU run's, row for row (needs 2 GPUs)."""
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    from base_amd import host_build
+    host_build.build_host()
+    pack_d, cl, *_ = build_problem("parsec", 8, n_stars=2000, small=False, seed=12)
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    phot = synth.write_phot(cl, pack_d["filters"], str(tmp_path / "c.phot"))
+    outs = []
+    for gpus in (1, 2):
+        base = str(tmp_path / f"run{gpus}")
+        yml = synth.write_yaml(str(tmp_path / f"b{gpus}.yaml"), phot, root, base, cl["truth"])
+        exe = os.path.join(ROOT, "base_amd", "host", "bin", "singlePopMcmc")
+        r = subprocess.run([exe, "--config", yml, "--walkers", "4", "--gpus", str(gpus), "--burnIter", "120", "--runIter", "60",
+                            "--block", "30", "--seed", "5"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(open(base + ".res").read())
+    assert outs[0] == outs[1] and outs[0].count("\n") == 1 + 180 * 4
