@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""Condenses the rocprofv3 outputs of tools/profile_round.sh into gpurun_out/<tag>_summary.{md,json}."""
-import csv, glob, json, collections, sys
-tag = sys.argv[1]
-out = {"tag": tag, "kernels": {}, "pmc": {}}
+"""Condenses the rocprofv3 outputs of tools/profile_round.sh into gpurun_out/<tag>_summary.{md,json} (+ the kernel stats
+csv): per-kernel times, raw PMC means per dispatch, and -- for the dominant kernel -- the three roofline fractions
+bench.py reports (fp64 VALU issue, HBM traffic, algorithmic bytes), each reproduced here from the raw counters."""
+import csv, glob, json, collections, shutil, sys
+tag, commit, command = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "unknown"), (sys.argv[3] if len(sys.argv) > 3 else "")
+out = {"tag": tag, "commit": commit, "command": command + " (under rocprofv3: --kernel-trace --stats, and separate --pmc passes)", "kernels": {}, "pmc": {}}
 for f in glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True):
+    shutil.copy(f, f"gpurun_out/{tag}_kernel_stats.csv")
     for r in csv.DictReader(open(f)):
         name = r["Name"].split("(")[0].replace("void ", "")
         out["kernels"][name] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                 "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
                                 "pct": float(r["Percentage"])}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     for f in glob.glob(f"gpurun_out/{tag}_{d}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
@@ -19,18 +22,43 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
 for line in open(f"gpurun_out/{tag}_trace.log"):
     if line.startswith("{"):
         out["bench_line_under_profiler"] = json.loads(line)
-# HBM traffic per launch of the dominant kernel: MI355X_MICROARCH.md "HBM": FETCH_SIZE (KiB) reads exactly
-# 1/2 of a coalesced stream's bytes on gfx950 -> doubled; WRITE_SIZE is exact.
+# HBM traffic per launch: MI355X_MICROARCH.md "HBM": FETCH_SIZE (KiB) reads exactly 1/2 of a coalesced stream's bytes on
+# gfx950 -> doubled; WRITE_SIZE is exact.
 for k, c in out["pmc"].items():
     if "FETCH_SIZE" in c:
         c["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
+HBM_PEAK, CLOCK, N_SIMD = 8.0e12, 2.4e9, 1024
+roof = {}
+for k, c in out["pmc"].items():
+    if not k.startswith("k_mcmc_step") or k not in out["kernels"]:
+        continue
+    t = out["kernels"][k]["avg_us"] * 1e-6
+    cfg = out.get("bench_line_under_profiler", {}).get("config", {})
+    evals = cfg.get("n_stars", 50000) * cfg.get("walkers_per_gpu", 8)
+    roof = {"kernel": k, "avg_launch_us": out["kernels"][k]["avg_us"], "star_evals_per_launch": evals,
+            "valu_issue_frac": 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (N_SIMD * CLOCK * t),
+            "valu_issue_frac_note": "SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x 2.4 GHz x launch time); the chip clocks below 2.4 GHz under fp64 load, so this is a lower bound of the busy fraction",
+            "hbm_bytes_per_launch": c.get("hbm_bytes_per_launch"), "hbm_GBps": c.get("hbm_bytes_per_launch", 0.0) / t / 1e9,
+            "hbm_frac": c.get("hbm_bytes_per_launch", 0.0) / t / HBM_PEAK,
+            "algorithmic_GBps_152B": evals * 152.0 / t / 1e9, "algorithmic_frac_of_hbm_peak_152B": evals * 152.0 / t / HBM_PEAK,
+            "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(1.0, c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0)),
+            "valu_insts_per_wave": c.get("SQ_INSTS_VALU", 0.0) / max(1.0, c.get("SQ_WAVES", 1.0)),
+            "wave_cycles_busy_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0)),
+            "wave_cycles_waiting_frac": c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0))}
+out["roofline_k_mcmc_step"] = roof
 json.dump(out, open(f"gpurun_out/{tag}_summary.json", "w"), indent=1)
 with open(f"gpurun_out/{tag}_summary.md", "w") as md:
-    md.write(f"# rocprofv3 summary {tag}\n\ncommand: `python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline` under "
-             "`rocprofv3 --kernel-trace --stats` and three separate `--pmc` passes\n\n")
+    md.write(f"# rocprofv3 summary {tag} (commit {commit})\n\ncommand: `{command}` under `rocprofv3 --kernel-trace --stats` and separate `--pmc` passes\n\n")
     md.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["pct"]):
         md.write(f"| `{k}` | {v['calls']} | {v['avg_us']:.2f} | {v['min_us']:.2f} | {v['max_us']:.2f} | {v['pct']:.1f} |\n")
+    if roof:
+        md.write(f"\n## Roofline of `{roof['kernel']}` from the raw counters (what bench.py's `roofline` object reports)\n\n")
+        md.write(f"* launch: {roof['avg_launch_us']:.2f} us for {roof['star_evals_per_launch']} star-evals\n")
+        md.write(f"* **fp64 VALU issue (the bound)**: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz x t) = **{roof['valu_issue_frac']:.3f}** ({roof['valu_insts_per_wave']:.0f} VALU instructions per wave)\n")
+        md.write(f"* **HBM side**: (2 x FETCH_SIZE + WRITE_SIZE) = {roof['hbm_bytes_per_launch'] / 1e6:.2f} MB per launch -> {roof['hbm_GBps']:.0f} GB/s = **{roof['hbm_frac']:.3f}** of the 8 TB/s peak (L2 hit rate {roof['l2_hit_rate']:.2f})\n")
+        md.write(f"* **algorithmic bytes** (SURVEY 8d: 152 B per star-eval): {roof['algorithmic_GBps_152B']:.0f} GB/s = {roof['algorithmic_frac_of_hbm_peak_152B']:.3f} of the HBM peak -- an L2-served rate (the walkers of a GPU share a star tile through the XCD-local L2), NOT an HBM fraction\n")
+        md.write(f"* wave cycles: {roof['wave_cycles_busy_frac']:.2f} issuing, {roof['wave_cycles_waiting_frac']:.2f} waiting (s_waitcnt / barrier)\n")
     md.write("\n## PMC (mean per dispatch)\n\n")
     for k, c in out["pmc"].items():
         if "copyBuffer" in k: continue
