@@ -38,9 +38,9 @@ class b9_pack(C.Structure):
         ("iso_first_eep", _ip), ("iso_n_eep", _ip), ("iso_offset", _lp),
         ("n_points", C.c_int64),
         ("mass", _dp), ("mags", _dp), ("abs_coeff", _dp),
-        ("n_wc_carb", C.c_int32), ("n_wc_mass", C.c_int32), ("n_wc_age", C.c_int32),
-        ("wc_carb", _dp), ("wc_mass", _dp), ("wc_log_age", _dp),
-        ("wc_log_teff", _dp), ("wc_log_radius", _dp),
+        ("n_wc_carb", C.c_int32), ("n_wc_mass", C.c_int32),
+        ("wc_carb", _dp), ("wc_mass", _dp), ("wc_n_age", _ip), ("wc_offset", _lp), ("n_wc_points", C.c_int64),
+        ("wc_log_age", _dp), ("wc_log_teff", _dp), ("wc_log_radius", _dp),
         ("n_at_type", C.c_int32), ("n_at_logg", C.c_int32), ("n_at_teff", C.c_int32),
         ("at_logg", _dp), ("at_log_teff", _dp), ("at_mags", _dp),
         ("ifmr_id", C.c_int32), ("reserved0", C.c_int32),
@@ -107,6 +107,18 @@ def make_pack(d: Dict) -> Pinned:
     for name in ("feh", "y", "log_age", "mass", "mags", "abs_coeff", "wc_carb", "wc_mass",
                  "wc_log_age", "wc_log_teff", "wc_log_radius", "at_logg", "at_log_teff", "at_mags"):
         k[name] = _f64(d.get(name, np.zeros(0)))
+    # WD cooling tracks: ragged (wc_n_age / wc_offset given) or the older rectangular form (one shared age axis, tables
+    # [carb][mass][age]), which is expanded to one copy of the axis per track
+    n_tracks = max(1, len(k["wc_carb"])) * len(k["wc_mass"])
+    if "wc_n_age" in d:
+        k["wc_n_age"] = np.ascontiguousarray(d["wc_n_age"], dtype=np.int32).ravel()
+        k["wc_offset"] = np.ascontiguousarray(d["wc_offset"], dtype=np.int64).ravel()
+    else:
+        n_age = len(k["wc_log_age"])
+        k["wc_n_age"] = np.full(n_tracks, n_age, dtype=np.int32)
+        k["wc_offset"] = np.arange(n_tracks, dtype=np.int64) * n_age
+        k["wc_log_age"] = np.ascontiguousarray(np.tile(k["wc_log_age"], n_tracks))
+    assert k["wc_n_age"].size == n_tracks and k["wc_log_teff"].size == k["wc_log_age"].size == k["wc_log_radius"].size
     k["iso_first_eep"] = np.ascontiguousarray(d["iso_first_eep"], dtype=np.int32).ravel()
     k["iso_n_eep"] = np.ascontiguousarray(d["iso_n_eep"], dtype=np.int32).ravel()
     k["iso_offset"] = np.ascontiguousarray(d["iso_offset"], dtype=np.int64).ravel()
@@ -122,7 +134,9 @@ def make_pack(d: Dict) -> Pinned:
     p.iso_first_eep = _ptr(k["iso_first_eep"], _ip)
     p.iso_n_eep = _ptr(k["iso_n_eep"], _ip)
     p.iso_offset = _ptr(k["iso_offset"], _lp)
-    p.n_wc_carb, p.n_wc_mass, p.n_wc_age = len(k["wc_carb"]), len(k["wc_mass"]), len(k["wc_log_age"])
+    p.n_wc_carb, p.n_wc_mass, p.n_wc_points = len(k["wc_carb"]), len(k["wc_mass"]), int(k["wc_log_age"].size)
+    p.wc_n_age = _ptr(k["wc_n_age"], _ip)
+    p.wc_offset = _ptr(k["wc_offset"], _lp)
     p.n_at_logg, p.n_at_teff = len(k["at_logg"]), len(k["at_log_teff"])
     p.n_at_type = int(d.get("n_at_type", 0 if p.n_at_teff == 0 else k["at_mags"].size // max(1, p.n_at_logg * p.n_at_teff * p.n_filt)))
     p.ifmr_id = int(d.get("ifmr_id", IFMR_WILLIAMS))

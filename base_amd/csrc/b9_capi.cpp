@@ -476,14 +476,24 @@ int b9_load_pack(b9_ctx *ctx, const b9_pack *p)
         max_eep = std::max(max_eep, n);
         tips[k] = p->mass[off + n - 1];
     }
-    const bool has_wd = p->n_wc_mass >= 2 && p->n_wc_age >= 2 && p->n_at_teff >= 2 && p->n_at_logg >= 2 && p->n_at_type >= 1;
+    const bool has_wd = p->n_wc_mass >= 2 && p->n_at_teff >= 2 && p->n_at_logg >= 2 && p->n_at_type >= 1;
+    const int n_tracks = has_wd ? std::max(1, p->n_wc_carb) * p->n_wc_mass : 0;
+    std::vector<int> wc_n, wc_off;
     if (has_wd) {
-        if (!p->wc_mass || !p->wc_log_age || !p->wc_log_teff || !p->wc_log_radius || !p->at_logg || !p->at_log_teff || !p->at_mags)
+        if (!p->wc_mass || !p->wc_n_age || !p->wc_offset || !p->wc_log_age || !p->wc_log_teff || !p->wc_log_radius || !p->at_logg ||
+            !p->at_log_teff || !p->at_mags)
             return fail(ctx, B9_ERR_INVALID, "NULL WD table pointer in pack");
-        if (!ascending(p->wc_mass, p->n_wc_mass) || !ascending(p->wc_log_age, p->n_wc_age) ||
-            !ascending(p->at_logg, p->n_at_logg) || !ascending(p->at_log_teff, p->n_at_teff) ||
+        if (!ascending(p->wc_mass, p->n_wc_mass) || !ascending(p->at_logg, p->n_at_logg) || !ascending(p->at_log_teff, p->n_at_teff) ||
             (p->n_wc_carb > 1 && !ascending(p->wc_carb, p->n_wc_carb)))
             return fail(ctx, B9_ERR_INVALID, "WD table axes must be strictly ascending");
+        if (p->n_wc_points < 2 || p->n_wc_points > 0x7fffffffLL) return fail(ctx, B9_ERR_INVALID, "bad number of cooling-track points");
+        for (int t = 0; t < n_tracks; ++t) {       // every (carbonicity, mass) node is a track with its own age axis
+            const int n = p->wc_n_age[t];
+            const long long off = p->wc_offset[t];
+            if (n < 2 || off < 0 || off + n > p->n_wc_points) return fail(ctx, B9_ERR_INVALID, "cooling track index out of range");
+            if (!ascending(p->wc_log_age + off, n)) return fail(ctx, B9_ERR_INVALID, "the cooling ages of a track must be strictly ascending");
+            wc_n.push_back(n); wc_off.push_back((int)off);
+        }
     }
 
     free_all(ctx->pack_allocs);
@@ -510,15 +520,26 @@ int b9_load_pack(b9_ctx *ctx, const b9_pack *p)
     if ((rc = upload(ctx, A, tips.data(), tips.size(), &d.tips))) return rc;
     for (int f = 0; f < B9_MAX_FILT; ++f) d.abs_m1[f] = f < d.nf ? p->abs_coeff[f] - 1.0 : 0.0;
     if (has_wd) {
-        d.n_wc_carb = std::max(1, p->n_wc_carb); d.n_wc_mass = p->n_wc_mass; d.n_wc_age = p->n_wc_age;
+        d.n_wc_carb = std::max(1, p->n_wc_carb); d.n_wc_mass = p->n_wc_mass; d.n_wc_points = (int)p->n_wc_points;
+        d.wc_n0 = wc_n[0]; d.wc_off0 = wc_off[0];
+        d.wc_uniform = 1;                          // a rectangular table: every track repeats track 0's age axis
+        for (int t = 1; t < n_tracks && d.wc_uniform; ++t)
+            d.wc_uniform = wc_n[t] == wc_n[0] && std::memcmp(p->wc_log_age + wc_off[t], p->wc_log_age + wc_off[0], sizeof(double) * wc_n[0]) == 0;
         d.n_at_type = p->n_at_type; d.n_at_logg = p->n_at_logg; d.n_at_teff = p->n_at_teff;
         const double zero = 0.0;
         if ((rc = upload(ctx, A, p->n_wc_carb >= 1 ? p->wc_carb : &zero, (size_t)d.n_wc_carb, &d.wc_carb))) return rc;
         if ((rc = upload(ctx, A, p->wc_mass, p->n_wc_mass, &d.wc_mass))) return rc;
-        if ((rc = upload(ctx, A, p->wc_log_age, p->n_wc_age, &d.wc_log_age))) return rc;
-        size_t nwc = (size_t)d.n_wc_carb * d.n_wc_mass * d.n_wc_age;
-        if ((rc = upload(ctx, A, p->wc_log_teff, nwc, &d.wc_log_teff))) return rc;
-        if ((rc = upload(ctx, A, p->wc_log_radius, nwc, &d.wc_log_radius))) return rc;
+        {
+            std::vector<double> packed(wc_n.size());
+            for (size_t t = 0; t < wc_n.size(); ++t) {
+                const unsigned long long w = (unsigned long long)(unsigned)wc_n[t] | ((unsigned long long)(unsigned)wc_off[t] << 32);
+                std::memcpy(&packed[t], &w, sizeof w);
+            }
+            if ((rc = upload(ctx, A, packed.data(), packed.size(), &d.wc_track))) return rc;
+        }
+        if ((rc = upload(ctx, A, p->wc_log_age, (size_t)p->n_wc_points, &d.wc_log_age))) return rc;
+        if ((rc = upload(ctx, A, p->wc_log_teff, (size_t)p->n_wc_points, &d.wc_log_teff))) return rc;
+        if ((rc = upload(ctx, A, p->wc_log_radius, (size_t)p->n_wc_points, &d.wc_log_radius))) return rc;
         if ((rc = upload(ctx, A, p->at_logg, p->n_at_logg, &d.at_logg))) return rc;
         if ((rc = upload(ctx, A, p->at_log_teff, p->n_at_teff, &d.at_log_teff))) return rc;
         size_t nat = (size_t)d.n_at_type * d.n_at_logg * d.n_at_teff;
@@ -832,7 +853,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     }
     StepDev sd{};
     sd.d = d; sd.n_walkers = W; sd.n_pops = n_pops;
-    sd.n_partial = partial_count(ctx, plan); sd.mass_cap = ctx->mass_cap;
+    sd.n_partial = partial_count(ctx, plan); sd.mass_cap = ctx->mass_cap; sd.heavy_parts = ctx->heavy_parts;
     sd.k0 = (unsigned)(blk->seed & 0xFFFFFFFFull); sd.k1 = (unsigned)(blk->seed >> 32);
     sd.partial_stride = ctx->st.n_pad; sd.iso_stride = ctx->iso_stride;
     sd.state = d_state; sd.partial = ctx->d_partial;
@@ -840,7 +861,8 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     sd.chol = d_chol; sd.free_idx = d_free; sd.walker_ids = d_ids;
     sd.samples = d_samples; sd.lps = d_lps; sd.n_acc = d_nacc; sd.decided = d_decided;
     sd.rows = nullptr; sd.row_origin = dev + o_org; sd.n_steps = S;
-    if (2 * (long long)sd.n_partial > sd.partial_stride) return fail(ctx, B9_ERR_CAPACITY, "partial buffer too small for two parities");
+    // (a parity's row: the hot waves' partials + one set of heavy-star partials per candidate)
+    if (2 * ((long long)sd.n_partial + sd.heavy_parts) > sd.partial_stride) return fail(ctx, B9_ERR_CAPACITY, "partial buffer too small for two parities");
     {   // D0: proposal of step 0 and its isochrones -> candidate 0 of parity 1 (K(t) has parity (t + 1) & 1)
         McmcDev mc{};
         mc.enabled = 1; mc.d = d; mc.n_walkers = W; mc.has_prev = 0; mc.pin = 0; mc.row = 0;

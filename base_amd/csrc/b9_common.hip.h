@@ -50,8 +50,18 @@ extern "C" int b9_debug_read_gantt_heavy(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_heavy), sizeof(unsigned long long) * 64 * 8);
 }
+__device__ unsigned long long g_gantt_heavy2[64 * 16];        // stamps inside one star's evaluation (lane HS2_LANE of wave 0 of workgroups < 64)
+extern "C" int b9_debug_read_gantt_heavy2(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_heavy2), sizeof(unsigned long long) * 64 * 16);
+}
+#ifndef HS2_LANE
+#define HS2_LANE 0
+#endif
+#define HS2(k) do { if (threadIdx.x == HS2_LANE && blockIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_heavy2[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define HSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_heavy[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
+#define HS2(k) do {} while (0)
 #define HSTAMP(k) do {} while (0)
 #endif
 

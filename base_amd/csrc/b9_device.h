@@ -6,6 +6,8 @@
 
 #define B9_MAX_FILT 16          // padded filter count limit (NFP in {4, 8, 16})
 #define B9_WAVE 64
+#define B9_TIPS_LDS_MAX 2048       // the whole AGB-tip table (n_feh * n_y * n_age) is staged in LDS up to this many doubles
+#define B9_WC_AGE_LDS_MAX 6144     // cooling-track age axes (all tracks, concatenated) are staged in LDS up to this many doubles
 
 // Model pack, device view.  Passed to kernels by value (kernarg segment).
 struct DevPack {
@@ -20,8 +22,13 @@ struct DevPack {
     const double *tips;              // [n_iso] mass of each isochrone's last point
     double abs_m1[B9_MAX_FILT];      // abs_coeff[f] - 1   (0 in padded columns)
     // WD cooling
-    int n_wc_carb, n_wc_mass, n_wc_age;
-    const double *wc_carb, *wc_mass, *wc_log_age, *wc_log_teff, *wc_log_radius;
+    // WD cooling: one track per (carbonicity, mass) node with its own age axis (ragged); track t = ic * n_wc_mass + im
+    int n_wc_carb, n_wc_mass, n_wc_points;
+    int wc_uniform;                  // every track has the SAME age axis (a rectangular table): one bracket search serves all tracks
+    int wc_n0, wc_off0;              // ... of wc_n0 points, one copy of which starts at point wc_off0
+    const double *wc_track;          // [n_wc_carb * n_wc_mass] per track: (points | first point << 32) in the bits of a double, so that
+                                     // the heavy-star role stages it in LDS with its other (double) axes
+    const double *wc_carb, *wc_mass, *wc_log_age, *wc_log_teff, *wc_log_radius;   // the last three: [n_wc_points]
     // WD atmospheres, rows padded to nfp
     int n_at_type, n_at_logg, n_at_teff;
     const double *at_logg, *at_log_teff, *at_mags;
@@ -124,7 +131,9 @@ struct StepDev {
     int derive_next;                 // 0 for the launch that only finishes the block's last step
     int set;                         // parity of the step this launch evaluates
     int row;                         // chain row the decision of this launch appends (step t-1)
-    int n_partial, mass_cap;
+    int n_partial, mass_cap;         // n_partial: partials one decision adds = hot waves' + heavy_parts (of the evaluated candidate)
+    int heavy_parts;                 // heavy-star workgroups per walker; each writes one partial PER CANDIDATE: the partial row holds
+                                     // [hot: n_partial - heavy_parts][heavy, candidate 0: heavy_parts][heavy, candidate 1: heavy_parts]
     unsigned k0, k1;                 // Philox key
     unsigned long long step;         // global index of the step this launch evaluates
     long long partial_stride;        // doubles between walkers; the two parities sit partial_stride / 2 apart

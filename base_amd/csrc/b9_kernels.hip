@@ -99,11 +99,19 @@ hipError_t b9k_derive_iso_rows(const DevPack &pk, const double *host_rows, doubl
     return hipGetLastError();
 }
 
-static size_t heavy_lds_doubles(const DevPack &pk, int n_pops)
+// LDS of the heavy-star role: the WD axes (the cooling tracks' concatenated age axes only while they fit
+// B9_WC_AGE_LDS_MAX doubles; longer ones are searched in L2) + per (candidate, population) the four AGB-tip columns
+static size_t heavy_lds_doubles(const DevPack &pk, int n_pops, int n_cand, int mass_cap)
 {
+    auto blk = [](size_t n) { return (n + 255) & ~(size_t)255; };         // every segment starts at a multiple of 256 doubles
     const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
-    return 8 + (has_wd ? (size_t)(1 + 4 * n_pops) * pk.n_age + pk.n_wc_age + pk.n_wc_mass + pk.n_wc_carb + pk.n_at_teff + pk.n_at_logg
-                       : (size_t)(1 + 4 * n_pops) * pk.n_age);
+    const size_t wc_age = !has_wd ? 0 : (pk.wc_uniform ? (size_t)pk.wc_n0 : (pk.n_wc_points <= B9_WC_AGE_LDS_MAX ? (size_t)pk.n_wc_points : 0));
+    const size_t n_tips = (size_t)pk.n_feh * pk.n_y * pk.n_age;
+    const size_t tips = n_tips <= B9_TIPS_LDS_MAX ? n_tips : (size_t)4 * n_pops * n_cand * pk.n_age;       // the whole table, or the corner columns
+    size_t n = 8 + blk(pk.n_age) + blk(wc_age) + blk(tips) + (size_t)n_pops * n_cand * blk(mass_cap) + 8;
+    if (has_wd) n += blk(pk.n_wc_mass) + blk(pk.n_wc_carb) + blk(pk.n_at_teff) + blk(pk.n_at_logg) + blk((size_t)pk.n_wc_carb * pk.n_wc_mass);
+    else n += 5 * 0;
+    return n;
 }
 
 template <int NFP, int NPOPS, int WB>
@@ -114,7 +122,7 @@ static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const 
                                    hipStream_t stream)
 {
     // + 8: find_bracket's last stage may read up to 6 entries past a column's end (masked out)
-    const size_t lds = sizeof(double) * std::max((size_t)WB * NPOPS * mass_cap + 8, heavy_lds_doubles(pk, NPOPS));
+    const size_t lds = sizeof(double) * std::max((size_t)WB * NPOPS * mass_cap + 8, heavy_lds_doubles(pk, NPOPS, 1, mass_cap));
     auto kern = k_star_like<NFP, NPOPS, WB>;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
@@ -214,7 +222,7 @@ template <int NFP, int NPOPS>
 static size_t mcmc_step_lds(const DevPack &pk, int mass_cap)
 {
     const size_t stage = B9_LDS_STAGE(NFP) ? (size_t)4 * (2 * NFP + 1) * 64 : 0;      // per-wave observation stage of the hot role
-    return sizeof(double) * std::max((size_t)2 * NPOPS * mass_cap + 8 + stage, heavy_lds_doubles(pk, NPOPS));
+    return sizeof(double) * std::max((size_t)2 * NPOPS * mass_cap + 8 + stage, heavy_lds_doubles(pk, NPOPS, 2, mass_cap));
 }
 
 template <int NFP, int NPOPS>

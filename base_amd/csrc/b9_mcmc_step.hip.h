@@ -36,8 +36,11 @@ __device__ __forceinline__ bool step_decide(const StepDev &sd, int w, double &lp
         if ((f >> 1) == sd.step) { lp_new = 0.0; return (f & 1ull) != 0; }      // wave-uniform: one word per walker
     }
     const double *part = sd.partial + (size_t)w * sd.partial_stride + (size_t)(sd.set ^ 1) * (sd.partial_stride / 2);
+    // the hot waves' partials, then the heavy-star partials of the candidate that step evaluated (the heavy role wrote one
+    // set per candidate without waiting for its decision)
+    const int n_hot = sd.n_partial - sd.heavy_parts, skip = in[B9_ST_SEL] != 0.0 ? sd.heavy_parts : 0;
     double acc = 0.0;
-    for (int j = lane; j < sd.n_partial; j += 64) acc += part[j];
+    for (int j = lane; j < sd.n_partial; j += 64) acc += part[j < n_hot ? j : j + skip];
     const double lpr = in[B9_ST_LPRIOR], lu = in[B9_ST_LOGU];
     STAMP(9);
     const double t = __shfl(wave_sum(acc), 0, 64);
@@ -324,19 +327,21 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
 #ifndef B9_STEP_NO_HEAVY     // (diagnostic builds only: what the hot + derivation roles need in registers on their own)
     if (role == 1) {
         const int w = b / heavy_parts, part = b - w * heavy_parts;
-        double lp_new;
         // the role is ONE long dependent chain per lane on a few workgroups; the hot waves it shares its SIMDs with are
         // throughput work: let its instructions issue first
+#ifndef B9_NO_HEAVY_PRIO
         __builtin_amdgcn_s_setprio(3);
+#endif
         HSTAMP(0);
         B9_MARK("heavy-begin");
-        const int sel = step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0;
-        const size_t rows = (size_t)W * NPOPS, cs = (size_t)(sd.set * 2 + sel);
-        heavy_stars<NFP, NPOPS>(pk, st, sd.cand_hdr + cs * rows, sd.cand_iso + cs * rows * sd.iso_stride, sd.iso_stride,
-                                sd.mass_cap, sd.cand_par + cs * W * B9_NPARAM, w, part, heavy_parts,
-                                sd.partial + (size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) +
-                                    (size_t)n_groups * 4 + part,
-                                nullptr, smem);
+        const size_t rows = (size_t)W * NPOPS, c0 = (size_t)(sd.set * 2);
+        const IsoHdr *const hd[2] = {sd.cand_hdr + c0 * rows, sd.cand_hdr + (c0 + 1) * rows};
+        const double *const is[2] = {sd.cand_iso + c0 * rows * sd.iso_stride, sd.cand_iso + (c0 + 1) * rows * sd.iso_stride};
+        const double *const pr2[2] = {sd.cand_par + c0 * W * B9_NPARAM, sd.cand_par + (c0 + 1) * W * B9_NPARAM};
+        double *const base = sd.partial + (size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) + (size_t)n_groups * 4;
+        double *const out[2] = {base + part, base + heavy_parts + part};
+        auto decide = [&] { double lp_new; return step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0; };
+        heavy_stars<NFP, NPOPS, 2>(pk, st, hd, is, sd.iso_stride, sd.mass_cap, pr2, decide, w, part, heavy_parts, out, nullptr, smem);
         B9_MARK("heavy-end");
         return role;
     }

@@ -22,6 +22,23 @@ __device__ __forceinline__ void fill(double (&out)[NFP], double v)
     for (int f = 0; f < NFP; ++f) out[f] = v;
 }
 
+// num / den for the heavy-star role's interpolation weights: a v_rcp_f64 seed, two Newton steps and a residual
+// correction -- within 1 ulp of the IEEE quotient (weights then differ from the oracle's by <= 1e-16 relative, seven
+// orders inside the stated tolerance) in a third of the dependent instructions of the exact division sequence.  The
+// role is one long dependent chain: every instruction on it is latency.
+__device__ __forceinline__ double fdiv(double num, double den)
+{
+#ifdef B9_EXACT_DIV
+    return num / den;
+#else
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    const double q = num * r;
+    return fma(fma(-den, q, num), r, q);
+#endif
+}
+
 // Bracket of mass m in a mass column (LDS-resident in the hot roles; any pointer works): the largest i in [0, n-2] with mass[i] <= m
 // (what the oracle's binary search returns -- the bracket is unique for a sorted column, so any
 // correct search yields the same i and hence bit-identical weights).  8-ary: every step issues 7
@@ -139,7 +156,9 @@ __device__ __forceinline__ double ifmr(int id, const double *__restrict__ par, d
 struct WdAxes {
     const double *log_age;        // [n_age]
     const double *tips[4];        // [(df*2+dy)][n_age] AGB-tip mass of the corner (FeH, Y) columns
-    const double *wc_log_age, *wc_mass, *wc_carb, *at_log_teff, *at_logg;
+    const double *wc_mass, *wc_carb, *at_log_teff, *at_logg;
+    const double *wc_log_age_lds; // LDS copy of the cooling tracks' concatenated age axes, or null (then pk.wc_log_age, in L2, is searched)
+    const double *wc_track;       // per track: (points | first point << 32) packed in the bits of a double (DevPack::wc_track, or its LDS copy)
 };
 
 __device__ inline double prec_log_age_corner(const DevPack &pk, const double *tips, const double *log_age, double m)
@@ -156,6 +175,165 @@ __device__ inline double prec_log_age_corner(const DevPack &pk, const double *ti
     const double a = tips[lo], b = tips[lo + 1];
     const double t = (b != a) ? (m - a) / (b - a) : 0.0;
     return lerp(log_age[lo], log_age[lo + 1], t);
+}
+
+// Several 8-ary bracket searches in lock step (one per cooling track): the probes of all N axes are issued together in
+// every round, so N searches cost the dependent round trips of the longest one.  Same indices as N calls of
+// bracket8<false>.
+template <int N>
+__device__ __forceinline__ void bracket8_lockstep(const double *const (&ax)[N], const int (&n)[N], double x, int (&lo)[N])
+{
+    int len[N];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { lo[k] = 0; len[k] = n[k] - 1; any = any || len[k] >= 8; }
+    while (any) {
+        any = false;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const bool on = len[k] >= 8;
+            const int step = on ? len[k] >> 3 : 0;               // an axis that is done probes its own lo (ignored)
+            const double *p = ax[k] + lo[k];
+            int c = 0;
+#pragma unroll
+            for (int j = 1; j < 8; ++j) c += (p[j * step] <= x) ? 1 : 0;
+            lo[k] += on ? c * step : 0;
+            len[k] = on ? ((c == 7) ? len[k] - 7 * step : step) : len[k];
+            any = any || len[k] >= 8;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double *p = ax[k] + lo[k];
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            const double v = j < len[k] ? p[j] : p[0];           // never reads past the axis
+            c += (j < len[k] && v <= x) ? 1 : 0;
+        }
+        lo[k] += c;
+    }
+}
+
+// WD cooling model: (log Teff, log radius) of a WD of mass wd_mass at log cooling age log_cool.
+// Every (carbonicity, mass) node is a track with ITS OWN age axis: the age is bracketed (clamped; extrapolation
+// allowed) in each of the 2 (4 with a carbonicity axis) neighbouring tracks' axes, the two quantities are interpolated
+// along each track, then across mass, then across carbonicity.  ax.wc_* may point into LDS.
+template <int NT>
+__device__ __forceinline__ void wd_cooling_tracks(const DevPack &pk, const WdAxes &ax, int ic, int im, double tm, double tc,
+                                                  double log_cool, const double *age_base, double &log_teff, double &log_rad)
+{
+    const double *axes[NT];
+    int n[NT], off[NT], ia[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {                               // k = dc * 2 + dm
+        const int t = (ic + (k >> 1)) * pk.n_wc_mass + im + (k & 1);
+        const unsigned long long w = __double_as_longlong(ax.wc_track[t]);
+        n[k] = (int)(w & 0xFFFFFFFFull); off[k] = (int)(w >> 32);
+        axes[k] = age_base + off[k];
+    }
+    double vt[NT], vr[NT];
+    if (pk.wc_uniform) {          // a rectangular table: the tracks share one age axis -- one search, one weight for all of them
+        const int i0 = bracket8<false>(age_base, n[0], log_cool);
+        const double a0 = age_base[i0], a1 = age_base[i0 + 1];
+        const double ta = fdiv(log_cool - a0, a1 - a0);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const size_t b = (size_t)off[k] + i0;
+            vt[k] = lerp(pk.wc_log_teff[b], pk.wc_log_teff[b + 1], ta);
+            vr[k] = lerp(pk.wc_log_radius[b], pk.wc_log_radius[b + 1], ta);
+        }
+    } else {
+        bracket8_lockstep<NT>(axes, n, log_cool, ia);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const double a0 = axes[k][ia[k]], a1 = axes[k][ia[k] + 1];
+            const double ta = fdiv(log_cool - a0, a1 - a0);
+            const size_t b = (size_t)off[k] + ia[k];
+            vt[k] = lerp(pk.wc_log_teff[b], pk.wc_log_teff[b + 1], ta);
+            vr[k] = lerp(pk.wc_log_radius[b], pk.wc_log_radius[b + 1], ta);
+        }
+    }
+    log_teff = lerp(vt[0], vt[1], tm);
+    log_rad = lerp(vr[0], vr[1], tm);
+    if (NT == 4) {
+        log_teff = lerp(log_teff, lerp(vt[NT - 2], vt[NT - 1], tm), tc);
+        log_rad = lerp(log_rad, lerp(vr[NT - 2], vr[NT - 1], tm), tc);
+    }
+}
+
+__device__ __forceinline__ void wd_cooling(const DevPack &pk, const WdAxes &ax, const double *__restrict__ par, double wd_mass,
+                                           double log_cool, double &log_teff, double &log_rad)
+{
+    const int im = bracket8<false>(ax.wc_mass, pk.n_wc_mass, wd_mass);
+    const double tm = fdiv(wd_mass - ax.wc_mass[im], ax.wc_mass[im + 1] - ax.wc_mass[im]);
+    if (pk.n_wc_carb > 1) {
+        const int ic = bracket8<false>(ax.wc_carb, pk.n_wc_carb, par[B9_P_CARBONICITY]);
+        const double tc = fdiv(par[B9_P_CARBONICITY] - ax.wc_carb[ic], ax.wc_carb[ic + 1] - ax.wc_carb[ic]);
+        // (two calls, not one with a selected pointer: each keeps its address space -- ds_read for the LDS copy)
+        // (a rectangular table: the LDS copy holds the one shared axis; the global one starts at point wc_off0)
+        const double *g = pk.wc_log_age + (pk.wc_uniform ? pk.wc_off0 : 0);
+        if (ax.wc_log_age_lds) wd_cooling_tracks<4>(pk, ax, ic, im, tm, tc, log_cool, ax.wc_log_age_lds, log_teff, log_rad);
+        else wd_cooling_tracks<4>(pk, ax, ic, im, tm, tc, log_cool, g, log_teff, log_rad);
+    } else {
+        const double *g = pk.wc_log_age + (pk.wc_uniform ? pk.wc_off0 : 0);
+        if (ax.wc_log_age_lds) wd_cooling_tracks<2>(pk, ax, 0, im, tm, 0.0, log_cool, ax.wc_log_age_lds, log_teff, log_rad);
+        else wd_cooling_tracks<2>(pk, ax, 0, im, tm, 0.0, log_cool, g, log_teff, log_rad);
+    }
+}
+
+// Precursor log-age of a WD progenitor of mass m: prec_log_age_corner for the NC (2, or 4 with a helium axis) corner
+// columns of AGB-tip masses IN LOCK STEP -- the probes of all columns are issued together in every round of the
+// descending 8-ary search, so NC inversions cost the dependent round trips of one -- then interpolated in Y and FeH.
+// Same operations per corner as prec_log_age_corner (same bits).
+template <int NC>
+__device__ __forceinline__ void prec_corners(const DevPack &pk, const double *const (&tips)[4], const double *log_age, double m, double (&out)[4])
+{
+    const int na = pk.n_age;
+    int lo[NC], len[NC];
+    bool heavy[NC], light[NC], any = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        heavy[c] = m > tips[c][0];
+        light[c] = m <= tips[c][na - 1];
+        lo[c] = 0; len[c] = (heavy[c] || light[c]) ? 0 : na - 1;
+        any = any || len[c] >= 8;
+    }
+    while (any) {
+        any = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool on = len[c] >= 8;
+            const int step = on ? len[c] >> 3 : 0;
+            const double *p = tips[c] + lo[c];
+            int k = 0;
+#pragma unroll
+            for (int j = 1; j < 8; ++j) k += (p[j * step] >= m) ? 1 : 0;
+            lo[c] += on ? k * step : 0;
+            len[c] = on ? ((k == 7) ? len[c] - 7 * step : step) : len[c];
+            any = any || len[c] >= 8;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double *p = tips[c] + lo[c];
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            const double v = j < len[c] ? p[j] : p[0];
+            k += (j < len[c] && v >= m) ? 1 : 0;
+        }
+        lo[c] += k;
+        const double a = tips[c][lo[c]], b = tips[c][lo[c] + 1];
+        const double t = (b != a) ? fdiv(m - a, b - a) : 0.0;
+        double v = lerp(log_age[lo[c]], log_age[lo[c] + 1], t);
+        v = light[c] ? log_age[na - 1] : v;
+        out[c] = v;
+    }
+    // heavier than a column's youngest tip: extrapolated (rare; the logarithm is only paid when some lane needs it)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (heavy[c]) out[c] = log_age[0] - 2.7 * log10(m / tips[c][0]);
 }
 
 // IFMR -> WD cooling model -> atmosphere table.  Only the stars above the AGB
@@ -180,30 +358,8 @@ __device__ __forceinline__ void wd_mags(const DevPack &pk, const WdAxes &ax, con
     const double wd_mass = ifmr(pk.ifmr_id, par, m);
     const double log_cool = log10(exp10(log_age) - exp10(prec));
 
-    const int ia = bracket(ax.wc_log_age, pk.n_wc_age, log_cool);
-    const double ta = (log_cool - ax.wc_log_age[ia]) / (ax.wc_log_age[ia + 1] - ax.wc_log_age[ia]);
-    const int im = bracket(ax.wc_mass, pk.n_wc_mass, wd_mass);
-    const double tm = (wd_mass - ax.wc_mass[im]) / (ax.wc_mass[im + 1] - ax.wc_mass[im]);
-    const int nc = pk.n_wc_carb > 1 ? 2 : 1;
-    int ic = 0; double tc = 0.0;
-    if (nc == 2) {
-        ic = bracket(ax.wc_carb, pk.n_wc_carb, par[B9_P_CARBONICITY]);
-        tc = (par[B9_P_CARBONICITY] - ax.wc_carb[ic]) / (ax.wc_carb[ic + 1] - ax.wc_carb[ic]);
-    }
     double tr[2];
-    for (int q = 0; q < 2; ++q) {
-        const double *tab = q ? pk.wc_log_radius : pk.wc_log_teff;
-        double vc[2] = {0.0, 0.0};
-        for (int dc = 0; dc < nc; ++dc) {
-            double vm[2];
-            for (int dm = 0; dm < 2; ++dm) {
-                size_t base = ((size_t)(ic + dc) * pk.n_wc_mass + (im + dm)) * pk.n_wc_age + ia;
-                vm[dm] = lerp(tab[base], tab[base + 1], ta);
-            }
-            vc[dc] = lerp(vm[0], vm[1], tm);
-        }
-        tr[q] = (nc == 2) ? lerp(vc[0], vc[1], tc) : vc[0];
-    }
+    wd_cooling(pk, ax, par, wd_mass, log_cool, tr[0], tr[1]);
     const double log_teff = tr[0];
     const double logg = LOG_G_PLUS_LOG_MSUN + log10(wd_mass) - 2.0 * tr[1];
     const int ty = (wd_type > 0 && pk.n_at_type > 1) ? 1 : 0;
@@ -291,23 +447,26 @@ __device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, c
     if (m <= is_tip) {                                           // MS / RGB (msrgb_mags)
         if (m < is_mass[0]) return c;
         int lo; double t;
+        HS2(11);
         find_bracket(is_mass, is_n, m, lo, t);
-#ifndef B9_HEAVY_FAST_DIV
-        { const double a = is_mass[lo], d = is_mass[lo + 1] - a; t = (d > 0.0) ? (m - a) / d : 0.0; }   // the oracle's exact quotient
-#endif
+        HS2(12);
         c.kind = 1; c.r0 = is_mags + (size_t)lo * NFP; c.t = t;
         return c;
     }
     if (!(m <= pk.m_wd_up)) return c;                            // NS / BH
     if (pk.n_wc_mass < 2 || pk.n_at_teff < 2) return c;          // no WD models loaded
     // WD (wd_mags): precursor age -> cooling age -> (Teff, radius) -> atmosphere rows
-    const int ny = pk.n_y > 1 ? 2 : 1;
-    const double v00 = prec_log_age_corner(pk, ax.tips[0], ax.log_age, m), v10 = prec_log_age_corner(pk, ax.tips[2], ax.log_age, m);
-    double vf0 = v00, vf1 = v10;
-    if (ny == 2) {
-        vf0 = lerp(v00, prec_log_age_corner(pk, ax.tips[1], ax.log_age, m), t_y);
-        vf1 = lerp(v10, prec_log_age_corner(pk, ax.tips[3], ax.log_age, m), t_y);
+    double pc[4];
+    double vf0, vf1;
+    if (pk.n_y > 1) {
+        prec_corners<4>(pk, ax.tips, ax.log_age, m, pc);
+        vf0 = lerp(pc[0], pc[1], t_y); vf1 = lerp(pc[2], pc[3], t_y);
+    } else {
+        const double *const two[4] = {ax.tips[0], ax.tips[2], ax.tips[0], ax.tips[2]};
+        prec_corners<2>(pk, two, ax.log_age, m, pc);
+        vf0 = pc[0]; vf1 = pc[1];
     }
+    HS2(2);
     const double prec = lerp(vf0, vf1, t_feh);
     const double log_age = par[B9_P_LOGAGE];
     if (prec >= log_age) { c.kind = 3; return c; }
@@ -317,30 +476,10 @@ __device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, c
 #else
     const double log_cool = log10(exp10(log_age) - exp10(prec));
 #endif
-    const int ia = bracket8<false>(ax.wc_log_age, pk.n_wc_age, log_cool);
-    const double ta = (log_cool - ax.wc_log_age[ia]) / (ax.wc_log_age[ia + 1] - ax.wc_log_age[ia]);
-    const int im = bracket8<false>(ax.wc_mass, pk.n_wc_mass, wd_mass);
-    const double tm = (wd_mass - ax.wc_mass[im]) / (ax.wc_mass[im + 1] - ax.wc_mass[im]);
-    const int nc = pk.n_wc_carb > 1 ? 2 : 1;
-    int ic = 0; double tc = 0.0;
-    if (nc == 2) {
-        ic = bracket8<false>(ax.wc_carb, pk.n_wc_carb, par[B9_P_CARBONICITY]);
-        tc = (par[B9_P_CARBONICITY] - ax.wc_carb[ic]) / (ax.wc_carb[ic + 1] - ax.wc_carb[ic]);
-    }
-    // the 8 (16 with a carbonicity axis) table words of both quantities are requested together
-    const size_t b00 = ((size_t)ic * pk.n_wc_mass + im) * pk.n_wc_age + ia, b01 = b00 + pk.n_wc_age;
-    const size_t c_step = (size_t)pk.n_wc_mass * pk.n_wc_age;
+    HS2(4);
     double tr[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const double *tab = q ? pk.wc_log_radius : pk.wc_log_teff;
-        double v = lerp(lerp(tab[b00], tab[b00 + 1], ta), lerp(tab[b01], tab[b01 + 1], ta), tm);
-        if (nc == 2) {
-            const double v1 = lerp(lerp(tab[b00 + c_step], tab[b00 + c_step + 1], ta), lerp(tab[b01 + c_step], tab[b01 + c_step + 1], ta), tm);
-            v = lerp(v, v1, tc);
-        }
-        tr[q] = v;
-    }
+    wd_cooling(pk, ax, par, wd_mass, log_cool, tr[0], tr[1]);
+    HS2(6);
     const double log_teff = tr[0];
 #ifdef B9_ABL_HEAVY_CHEAPMATH
     const double logg = LOG_G_PLUS_LOG_MSUN + (wd_mass - 1.0) * 0.43 - 2.0 * tr[1];
@@ -349,12 +488,13 @@ __device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, c
 #endif
     const int ty = (wd_type > 0 && pk.n_at_type > 1) ? 1 : 0;
     const int it = bracket8<false>(ax.at_log_teff, pk.n_at_teff, log_teff);
-    c.t = (log_teff - ax.at_log_teff[it]) / (ax.at_log_teff[it + 1] - ax.at_log_teff[it]);
+    c.t = fdiv(log_teff - ax.at_log_teff[it], ax.at_log_teff[it + 1] - ax.at_log_teff[it]);
     const int ig = bracket8<false>(ax.at_logg, pk.n_at_logg, logg);
-    c.tg = (logg - ax.at_logg[ig]) / (ax.at_logg[ig + 1] - ax.at_logg[ig]);
+    c.tg = fdiv(logg - ax.at_logg[ig], ax.at_logg[ig + 1] - ax.at_logg[ig]);
     c.r0 = pk.at_mags + (((size_t)ty * pk.n_at_logg + ig) * pk.n_at_teff + it) * NFP;
     c.r1 = c.r0 + (size_t)pk.n_at_teff * NFP;
     c.kind = 2;
+    HS2(7);
     return c;
 }
 
@@ -371,38 +511,44 @@ __device__ __forceinline__ double comp_mag(const Comp &c, int f)
     return c.kind == 1 ? v0 : (c.kind == 2 ? two : (c.kind == 3 ? -4.0 : B9_MAG_NOFLUX));
 }
 
+// What one lane of the heavy-star role works on: ONE component of a system in ONE population under ONE candidate
+// parameter row -- the caller has selected these for the lane (field by field: indexing local arrays of views with a
+// per-lane index would put them in scratch memory).
+template <int NFP>
+struct LaneView {
+    const double *is_mass, *is_mags;  // the (candidate, population)'s derived isochrone
+    int is_n;
+    double is_tip, t_feh, t_y;
+    const double *par;                // the candidate's parameter row
+    WdAxes ax;                        // WD axes (LDS) with the (candidate, population)'s AGB-tip columns
+};
+
 // One star through the descriptors, spread over 2 NPOPS neighbouring lanes: lane `sub` of the star's group evaluates
 // component (sub & 1) in population (sub >> 1).  The heavy role is a latency chain (a WD descriptor is ~30 dependent LDS
 // search steps, three library transcendentals and two memory round trips); laid end to end in one lane a two-population
-// binary cost four of them (22-30 us measured), side by side they cost one.  The lanes meet three times, by wave shuffles:
-// the secondary's magnitude (per filter), the other population's log-likelihood, and nothing else.  Every value is
-// formed by star_value's operations in star_value's order (same bits).  All lanes of a group must call (full EXEC);
-// the result is valid in the group's lane 0.
+// binary cost four of them (22-30 us measured), side by side they cost one.  The lanes meet twice, by wave shuffles: the
+// secondary's magnitude (per filter) and the other population's log-likelihood.  Every value is formed by
+// star_value's operations in star_value's order (same bits).  All lanes of a group must call (full EXEC); the result is
+// valid in the group's lane 0.
 template <int NFP, int NPOPS>
-__device__ __forceinline__ double star_value_lanes(const DevPack &pk, const WdAxes (&ax)[NPOPS], const IsoView<NFP> (&iso)[NPOPS],
-                                                   const double *__restrict__ par, const DevStars &st, int j /* index in the descending-mass list */,
-                                                   int sub, double log_lam, double log_1ml)
+__device__ __forceinline__ double star_value_lanes(const DevPack &pk, const LaneView<NFP> &lv, const DevStars &st,
+                                                   int j /* index in the descending-mass list */, int sub, double m1)
 {
+    HS2(0);
     const int comp = sub & 1;
-    const bool B = NPOPS == 2 && (sub >> 1) != 0;                    // this lane's population
     // everything the star needs from memory is requested here, in one round trip (heavy-order arrays: DevStars::hv_*)
-    const double m1 = st.heavy_mass[j], q = st.hv_q[j], c0 = st.hv_c0[j], la = st.hv_la[j];
+    const double q = st.hv_q[j], c0 = st.hv_c0[j], la = st.hv_la[j];
     const int wd_type = st.hv_flags[j] & 1;
     double obs[NFP], wgt[NFP];
 #pragma unroll
     for (int f = 0; f < NFP; ++f) { obs[f] = st.hv_obs[(size_t)f * st.hv_pad + j]; wgt[f] = st.hv_w[(size_t)f * st.hv_pad + j]; }
-    const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
+    HS2(1);
+    const double mod = lv.par[B9_P_MOD], av = lv.par[B9_P_ABS];
     const bool binary = q > 0.0;
-    // (field-by-field selects: indexing the local arrays with a per-lane population would put them in scratch memory)
-    const double *is_mass = B ? iso[NPOPS - 1].mass : iso[0].mass, *is_mags = B ? iso[NPOPS - 1].mags : iso[0].mags;
-    const int is_n = B ? iso[NPOPS - 1].n : iso[0].n;
-    const double is_tip = B ? iso[NPOPS - 1].tip : iso[0].tip, t_feh = B ? iso[NPOPS - 1].t_feh : iso[0].t_feh,
-                 t_y = B ? iso[NPOPS - 1].t_y : iso[0].t_y;
-    WdAxes axk = ax[0];                                               // only the four AGB-tip columns differ between populations
-#pragma unroll
-    for (int c = 0; c < 4; ++c) axk.tips[c] = B ? ax[NPOPS - 1].tips[c] : ax[0].tips[c];
-    Comp d; d.kind = 0; d.r0 = is_mags; d.r1 = is_mags; d.t = 0.0; d.tg = 0.0;
-    if (comp == 0 || binary) d = comp_desc<NFP>(pk, axk, is_mass, is_mags, is_n, is_tip, t_feh, t_y, par, comp ? q * m1 : m1, wd_type);
+    Comp d; d.kind = 0; d.r0 = lv.is_mags; d.r1 = lv.is_mags; d.t = 0.0; d.tg = 0.0;
+    if (comp == 0 || binary)
+        d = comp_desc<NFP>(pk, lv.ax, lv.is_mass, lv.is_mags, lv.is_n, lv.is_tip, lv.t_feh, lv.t_y, lv.par, comp ? q * m1 : m1, wd_type);
+    HS2(8);
     double chi2 = 0.0;
 #pragma unroll B9_HEAVY_UNROLL
     for (int f = 0; f < NFP; ++f) {
@@ -412,11 +558,13 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const WdAx
         const double dd = (p + (mod + pk.abs_m1[f] * av)) - obs[f];
         chi2 = fma(wgt[f] * dd, dd, chi2);
     }
+    HS2(9);
     const double ll = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
     double l = ll;
     if (NPOPS == 2) {
+        const double lam = lv.par[B9_P_LAMBDA];
         const double ll_b = __shfl_xor(ll, 2, 64);                    // population B's, in population A's lanes
-        l = logaddexp(log_lam + ll, log_1ml + ll_b);
+        l = logaddexp(log(lam) + ll, log1p(-lam) + ll_b);
     }
     return logaddexp(la, l);
 }

@@ -231,138 +231,191 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
     return (log_ge1(a.mant + a.mant) + (double)(a.expo - 1) * 0.693147180559945309417) + a.add;
 }
 
-// The stars the hot path skips -- primary heavier than the walker's AGB tip (SURVEY 8a row a7:
-// IFMR -> WD cooling -> WD atmosphere, or NS/BH) -- are evaluated by extra workgroups of the SAME
-// launch, through the general per-star code.  Because stars are also indexed by descending mass
-// (heavy_mass / heavy_slot), that set is a prefix whose length each heavy workgroup finds with a
-// 256-ary search (two rounds for 50k stars).  The WD axes are staged in LDS.  `parts` workgroups
-// share a walker's heavy stars; each writes one partial.
+// The stars the hot path skips -- primary heavier than the walker's AGB tip (IFMR -> WD cooling -> WD
+// atmosphere, or NS/BH) -- are evaluated by extra workgroups of the SAME launch (`parts` per walker), through the
+// general per-star code.  The role is ONE long dependent chain per star (~10 us: precursor age -> cooling age ->
+// cooling tracks -> atmosphere rows), so it is built to start that chain at once:
+//   * In the fused sampler step (NC = 2 candidate rows) everything it stages is requested for BOTH candidates at entry,
+//     in the same memory round trip as the previous step's accept/reject; only the candidate that decision selects is then
+//     evaluated (evaluating both cost more than it saved: usually only one of them has heavy stars at all).
+//   * It does NOT search for the number of heavy stars: stars are also listed by descending mass (heavy_mass and the
+//     hv_* copies of their data), a wave walks that list in chunks and stops at the first chunk in which no star of either
+//     candidate is above its AGB tip.
+//   * Everything it stages in LDS -- the WD axes and, per (candidate, population), the AGB-tip columns of the four
+//     (FeH, Y) corners -- is ONE flat list; each thread requests its elements at entry, all loads independent: one memory
+//     round trip (it used to be 6 + 4 NPOPS dependent ones).
+// A star occupies G = 2 NPOPS neighbouring lanes: (population, component) -- star_value_lanes.
 #ifndef B9_HEAVY_STAGE_E
-#define B9_HEAVY_STAGE_E 4          // staged axis elements a thread carries in registers across the count search (4 x 256 covers every pack here)
+#define B9_HEAVY_STAGE_E 18         // 256-double blocks of the staged list a thread carries an element of in registers (longer lists finish in a loop)
 #endif
-template <int NFP, int NPOPS>
-__device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *__restrict__ hdr,
-                                         const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
-                                         const double *__restrict__ params, int w, int part, int parts,
-                                         double *__restrict__ out_partial, double *__restrict__ perstar, double *smem)
+template <int NFP, int NPOPS, int NC, class SelectFn>
+__device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *const (&hdr)[NC],
+                                            const double *const (&iso_data)[NC], long long iso_stride, int mass_cap,
+                                            const double *const (&params)[NC], SelectFn select, int w, int part, int parts,
+                                            double *const (&out_partial)[NC], double *__restrict__ perstar, double *smem)
 {
-    const int tid = threadIdx.x;
-    int *s_cnt = reinterpret_cast<int *>(smem);         // 4 ints
-    double *s_red = smem + 2;                            // 4 doubles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *s_red = smem;                                // [NC][4]
     double *s_axes = smem + 8;
-    const double *par = params + (size_t)w * B9_NPARAM;
-    IsoView<NFP> iso[NPOPS];
-    double tip_min;
-    const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
-    if (!valid) { if (tid == 0) *out_partial = 0.0; return; }
-    // Everything the role stages in LDS -- the six WD axes and, per population, the AGB-tip columns of the four
-    // (FeH, Y) corners -- is ONE flat list of doubles; each thread requests its elements (<= B9_HEAVY_STAGE_E each)
-    // here, all loads independent, BEFORE the search for the number of heavy stars below, so that the whole staging
-    // costs one memory round trip that overlaps the search's (it used to be 6 + 4 NPOPS dependent trips).
-    HSTAMP(1);
-    constexpr int NSEG = 6 + 4 * NPOPS, E = B9_HEAVY_STAGE_E;
-    const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1;
+    // ---- the staged list, pass 1: everything whose address needs no isochrone header -- requested at entry, in the same
+    // memory round trip as the headers.  Segments: NC0 common axes; the whole AGB-tip table when it is small (else the
+    // corner columns follow in pass 2); per (candidate, population) the derived isochrone's mass column (a heavy
+    // primary's companion, or a star that is heavy under one candidate only, is on the MS/RGB branch: its bracket search
+    // then runs in LDS, as the hot role's does).
+    constexpr int NC0 = 7, NM0 = NC0 + 1, NSEG = NM0 + NPOPS * NC, E = B9_HEAVY_STAGE_E;
+    const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1, n_tips = pk.n_feh * pk.n_y * na;
     const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
+    const bool stage_wc_age = has_wd && (pk.wc_uniform || pk.n_wc_points <= B9_WC_AGE_LDS_MAX);       // (as heavy_lds_doubles sized the LDS)
+    const bool tips_all = n_tips <= B9_TIPS_LDS_MAX;
     const double *seg_src[NSEG];
-    int seg_off[NSEG + 1];
+    int seg_off[NSEG + 1], seg_len[NSEG];
     {
-        const double *src6[6] = {pk.log_age, pk.wc_log_age, pk.wc_mass, pk.wc_carb, pk.at_log_teff, pk.at_logg};
-        const int len6[6] = {na, has_wd ? pk.n_wc_age : 0, has_wd ? pk.n_wc_mass : 0, has_wd ? pk.n_wc_carb : 0,
-                             has_wd ? pk.n_at_teff : 0, has_wd ? pk.n_at_logg : 0};
+        // (cooling-age axes: all tracks', or the one shared axis of a rectangular table)
+        const double *src0[NM0] = {pk.log_age, pk.wc_log_age + (pk.wc_uniform ? pk.wc_off0 : 0), pk.wc_mass, pk.wc_carb, pk.at_log_teff,
+                                   pk.at_logg, pk.wc_track, pk.tips};
+        const int len0[NM0] = {na, stage_wc_age ? (pk.wc_uniform ? pk.wc_n0 : pk.n_wc_points) : 0, has_wd ? pk.n_wc_mass : 0, has_wd ? pk.n_wc_carb : 0,
+                               has_wd ? pk.n_at_teff : 0, has_wd ? pk.n_at_logg : 0, has_wd ? pk.n_wc_carb * pk.n_wc_mass : 0,
+                               tips_all ? n_tips : 4 * NPOPS * NC * na};
+        // every segment starts at a multiple of 256 doubles of the LDS image: block k of the list (elements k * 256 + tid)
+        // then lies in ONE segment, found with scalar compares -- a per-element search through the segment table cost each
+        // thread ~60 vector instructions per element, 1.5 us of this role's chain
         seg_off[0] = 0;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { seg_src[a] = src6[a]; seg_off[a + 1] = seg_off[a] + len6[a]; }
+        for (int a = 0; a < NM0; ++a) { seg_src[a] = src0[a]; seg_len[a] = len0[a]; seg_off[a + 1] = seg_off[a] + ((len0[a] + 255) & ~255); }
 #pragma unroll
-        for (int kp = 0; kp < NPOPS; ++kp)               // each population brackets (FeH, Y) on its own
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int df = c >> 1, dy = c & 1, k = 6 + kp * 4 + c;
-                seg_src[k] = pk.tips + (size_t)((iso[kp].i_feh + df) * pk.n_y + (iso[kp].i_y + (dy < ny ? dy : 0))) * na;
-                seg_off[k + 1] = seg_off[k] + na;
+            for (int kp = 0; kp < NPOPS; ++kp) {         // (a candidate's buffer exists even when its contents do not yet)
+                const int k = NM0 + c * NPOPS + kp;
+                seg_src[k] = iso_data[c] + (size_t)(w * NPOPS + kp) * iso_stride;
+                seg_len[k] = mass_cap;
+                seg_off[k + 1] = seg_off[k] + ((mass_cap + 255) & ~255);
             }
     }
-    const int n_stage = seg_off[NSEG];
+    const int n_blocks = seg_off[NSEG] >> 8, tip_lo = seg_off[NC0];
+    // element `tid` of block `blk`: its source address and whether it exists (wave-uniform segment lookup)
+    auto stage_elem = [&](int blk, const double *&src) {
+        int g_off = 0, g_len = seg_len[0];
+        const double *g_src = seg_src[0];
+#pragma unroll
+        for (int g = 1; g < NSEG; ++g) {
+            const bool here = blk * 256 >= seg_off[g];
+            g_off = here ? seg_off[g] : g_off; g_len = here ? seg_len[g] : g_len; g_src = here ? seg_src[g] : g_src;
+        }
+        const int j = blk * 256 + tid - g_off;
+        src = g_src + j;
+        // (pass 1 skips the AGB-tip columns of large grids: their addresses need the headers -- pass 2)
+        return blk < n_blocks && j < g_len && (tips_all || g_off != tip_lo);
+    };
     double sv[E];
 #pragma unroll
-    for (int k = 0; k < E; ++k) {
-        const int e = tid + k * 256;
-        const double *src = seg_src[0] + e;
+    for (int k = 0; k < E; ++k) { const double *src; sv[k] = stage_elem(k, src) ? *src : 0.0; }
+    // (both candidates' headers are requested BEFORE the selection is known -- one round trip fewer on the chain; a
+    //  candidate that does not exist yet, in the first launch of a block, holds anything: its fields are only used once
+    //  selected, and it never is)
+    IsoView<NFP> iso[NC][NPOPS];
+    bool valid[NC];
+    double tip_min[NC];
 #pragma unroll
-        for (int g = 1; g < NSEG; ++g) src = e >= seg_off[g] ? seg_src[g] + (e - seg_off[g]) : src;
-        sv[k] = e < n_stage ? *src : 0.0;
+    for (int c = 0; c < NC; ++c) valid[c] = load_iso_views<NFP, NPOPS>(hdr[c], iso_data[c], iso_stride, mass_cap, w, iso[c], tip_min[c]);
+    const int sel = NC == 2 ? select() : 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) if (c != sel) { valid[c] = false; tip_min[c] = __builtin_inf(); }
+    if (!(sel ? valid[NC - 1] : valid[0])) {
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) *out_partial[c] = 0.0;
+        }
+        return;
     }
-    int lo = 0, hi = st.n;                               // count = first k with heavy_mass[k] <= tip_min
-    while (lo < hi) {
-        const int span = hi - lo, step = (span + 255) / 256;
-        const int p = lo + tid * step;
-        const bool above = (p < hi) && (st.heavy_mass[p] > tip_min);
-        const int c = block_count(above, s_cnt);
-        if (c == 0) { hi = lo; }
-        else { const int nlo = lo + (c - 1) * step + 1, nhi = lo + c * step; lo = nlo; hi = nhi < hi ? nhi : hi; }
+    const int safe = sel;
+    HSTAMP(1);
+#pragma unroll
+    for (int k = 0; k < E; ++k) { const double *src; if (stage_elem(k, src)) s_axes[k * 256 + tid] = sv[k]; }
+    for (int blk = E; blk < n_blocks; ++blk) { const double *src; if (stage_elem(blk, src)) s_axes[blk * 256 + tid] = *src; }       // very long lists only
+    if (!tips_all) {
+        // pass 2 (large grids only): the AGB-tip columns of each (candidate, population)'s four (FeH, Y) corners, whose
+        // addresses the headers give
+        for (int e = tid; e < 4 * NPOPS * NC * na; e += 256) {
+            const int col = e / na, j = e - col * na, q = col & 3, ck = col >> 2, c = ck / NPOPS, kp = ck - c * NPOPS;
+            const int df = q >> 1, dy = q & 1;
+            int v_feh = 0, v_y = 0;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+                for (int kk = 0; kk < NPOPS; ++kk) {
+                    const bool me = (valid[c] ? c : safe) == cc && kp == kk;
+                    v_feh = me ? iso[cc][kk].i_feh : v_feh; v_y = me ? iso[cc][kk].i_y : v_y;
+                }
+            s_axes[tip_lo + e] = pk.tips[(size_t)((v_feh + df) * pk.n_y + (v_y + (dy < ny ? dy : 0))) * na + j];
+        }
     }
-    const int count = lo;
-    HSTAMP(2);
-#ifdef B9_GANTT
-    if (threadIdx.x == 0 && blockIdx.x < 64) g_gantt_heavy[blockIdx.x * 8 + 7] = (unsigned long long)count;
-#endif
+    __syncthreads();
+    HSTAMP(3);
+    // this lane's (candidate, population, component)
+    // A star occupies G = 2 NPOPS neighbouring lanes (population, component) of the evaluated candidate's chain.
+    constexpr int G = 2 * NPOPS, PER = 64 / G, WPC = 4;
+    const int sub2 = lane % G, pop = sub2 >> 1, cand = sel, wslot = wave;
+    LaneView<NFP> lv;
+    {
+        const int cs = (cand ? valid[NC - 1] : valid[0]) ? cand : safe;          // the candidate whose views this lane reads
+        const bool B = NPOPS == 2 && pop;
+        const bool C = cs != 0;
+        // (field-by-field selects with constant indices: a run-time index would put the views in scratch memory)
+#define B9_PICK(field) (C ? (B ? iso[NC - 1][NPOPS - 1].field : iso[NC - 1][0].field) : (B ? iso[0][NPOPS - 1].field : iso[0][0].field))
+        lv.is_mags = B9_PICK(mags); lv.is_n = B9_PICK(n); lv.is_tip = B9_PICK(tip);
+        lv.t_feh = B9_PICK(t_feh); lv.t_y = B9_PICK(t_y);
+        const int v_feh = B9_PICK(i_feh), v_y = B9_PICK(i_y);
+#undef B9_PICK
+        const int ck = (C ? NC - 1 : 0) * NPOPS + (B ? NPOPS - 1 : 0);
+        lv.is_mass = s_axes + seg_off[NM0] + ck * ((mass_cap + 255) & ~255);     // the LDS copy of the mass column
+        lv.par = (C ? params[NC - 1] : params[0]) + (size_t)w * B9_NPARAM;
+        lv.ax.log_age = s_axes + seg_off[0];
+        lv.ax.wc_log_age_lds = stage_wc_age ? s_axes + seg_off[1] : nullptr;
+        lv.ax.wc_mass = s_axes + seg_off[2]; lv.ax.wc_carb = s_axes + seg_off[3];
+        lv.ax.at_log_teff = s_axes + seg_off[4]; lv.ax.at_logg = s_axes + seg_off[5]; lv.ax.wc_track = s_axes + seg_off[6];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int df = q >> 1, dy = q & 1;
+            const int col = tips_all ? ((v_feh + df) * pk.n_y + (v_y + (dy < ny ? dy : 0))) : ck * 4 + q;
+            lv.ax.tips[q] = s_axes + tip_lo + col * na;
+        }
+    }
+    const bool my_valid = cand ? valid[NC - 1] : valid[0];
+    const double my_tip = cand ? tip_min[NC - 1] : tip_min[0];
     double acc = 0.0;
-    if (count > 0) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) { const int e = tid + k * 256; if (e < n_stage) s_axes[e] = sv[k]; }
-        for (int e = tid + E * 256; e < n_stage; e += 256) {       // very long axes only
-            const double *src = seg_src[0] + e;
-#pragma unroll
-            for (int g = 1; g < NSEG; ++g) src = e >= seg_off[g] ? seg_src[g] + (e - seg_off[g]) : src;
-            s_axes[e] = *src;
+    // chunks of PER stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over a
+    // candidate's waves second (a short list spreads over as many CUs as there are parts); a wave stops at its first chunk
+    // without a heavy star (masses descend).  Wave-uniform trip count: the shuffles see full EXEC.  The next chunk's masses
+    // are requested before this chunk is evaluated.
+    int c = part + parts * wslot;
+    int j = c * PER + lane / G, jj = j < st.n ? j : st.n - 1;
+    double m1 = st.heavy_mass[jj];
+    while (c * PER < st.n) {
+        const bool live = j < st.n && my_valid && m1 > my_tip;
+        if (__ballot(live) == 0ull) break;
+        const int c_n = c + parts * WPC, j_n = c_n * PER + lane / G, jj_n = j_n < st.n ? j_n : st.n - 1;
+        const double m1_n = st.heavy_mass[jj_n];
+        const double v = star_value_lanes<NFP, NPOPS>(pk, lv, st, jj, sub2, m1);
+        if (live && sub2 == 0) {
+            if (perstar) perstar[(size_t)w * st.n + st.hv_perm[jj]] = v;
+            acc += v;
         }
-        __syncthreads();
-        HSTAMP(3);
-        WdAxes ax[NPOPS];
-#pragma unroll
-        for (int kp = 0; kp < NPOPS; ++kp) {
-            ax[kp].log_age = s_axes + seg_off[0]; ax[kp].wc_log_age = s_axes + seg_off[1]; ax[kp].wc_mass = s_axes + seg_off[2];
-            ax[kp].wc_carb = s_axes + seg_off[3]; ax[kp].at_log_teff = s_axes + seg_off[4]; ax[kp].at_logg = s_axes + seg_off[5];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ax[kp].tips[c] = s_axes + seg_off[6 + kp * 4 + c];
-        }
-        const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
-        const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
-        // A star occupies G = 2 NPOPS neighbouring lanes (star_value_lanes).  Chunks of 64 / G stars of the descending-mass
-        // list are dealt round-robin over the walker's workgroups first and over a workgroup's four waves second: a
-        // short list spreads over as many CUs as there are parts.
-        const int lane = tid & 63, wave = tid >> 6;
-#ifdef B9_HEAVY_ARRAYS      // (one lane per star, per-filter arrays: kept for comparison builds)
-        for (int c = part + parts * wave; c * 64 < count; c += parts * 4) {
-            const int j = c * 64 + lane;
-            if (j < count) {
-                const int i = st.heavy_slot[j];
-                const double v = star_value<NFP, NPOPS>(pk, ax, iso, par, st, i, log_lam, log_1ml);
-                if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = v;
-                acc += v;
-            }
-        }
-#else
-        constexpr int G = 2 * NPOPS, PER = 64 / G;
-        const int sub = lane % G;
-        for (int c = part + parts * wave; c * PER < count; c += parts * 4) {          // wave-uniform trip count: the shuffles see full EXEC
-            const int j = c * PER + lane / G;
-            const bool live = j < count;
-            const int jj = live ? j : count - 1;
-            const double v = star_value_lanes<NFP, NPOPS>(pk, ax, iso, par, st, jj, sub, log_lam, log_1ml);
-            if (live && sub == 0) {
-                if (perstar) perstar[(size_t)w * st.n + st.hv_perm[jj]] = v;
-                acc += v;
-            }
-        }
-#endif
+        c = c_n; j = j_n; jj = jj_n; m1 = m1_n;
     }
     HSTAMP(4);
-    const double sum = wave_sum(acc);
+    // the evaluated candidate's partial: fixed-order sum over the waves (the other candidate's slot gets 0)
+    {
+        const double sum = wave_sum(acc);
+        if (lane == 0) s_red[wave] = sum;
+    }
     __syncthreads();
     HSTAMP(5);
-    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) *out_partial = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (tid == 0) {
+        const double tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) *out_partial[c] = c == sel ? tot : 0.0;
+    }
 }
 
 template <int NFP, int NPOPS, int WB>
@@ -383,8 +436,12 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevP
         if (hb >= n_walkers * heavy_parts) return;            // padding to a multiple of 8
         const int w = hb / heavy_parts, part = hb - w * heavy_parts;
 #ifndef B9_ABL_NO_HEAVY
-        heavy_stars<NFP, NPOPS>(pk, st, hdr, iso_data, iso_stride, mass_cap, params, w, part, heavy_parts,
-                                partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part, perstar, smem);
+        {
+            const IsoHdr *const h1[1] = {hdr};
+            const double *const i1[1] = {iso_data}, *const p1[1] = {params};
+            double *const o1[1] = {partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part};
+            heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, iso_stride, mass_cap, p1, [] { return 0; }, w, part, heavy_parts, o1, perstar, smem);
+        }
 #else
         if (threadIdx.x == 0) partial[(size_t)w * partial_stride + (size_t)n_groups * 4 + part] = 0.0;   // ablation build
 #endif

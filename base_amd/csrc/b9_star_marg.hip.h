@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, B9_MARG_MIN_WAVES) void k_star_marg(DevPack pk
             const int ny = pk.n_y > 1 ? 2 : 1;
             for (int df = 0; df < 2; ++df) for (int dy = 0; dy < 2; ++dy)
                 ax.tips[df * 2 + dy] = pk.tips + (size_t)((is.i_feh + df) * pk.n_y + (is.i_y + (dy < ny ? dy : 0))) * pk.n_age;
-            ax.wc_log_age = pk.wc_log_age; ax.wc_mass = pk.wc_mass; ax.wc_carb = pk.wc_carb;
+            ax.wc_log_age_lds = nullptr; ax.wc_track = pk.wc_track; ax.wc_mass = pk.wc_mass; ax.wc_carb = pk.wc_carb;
             ax.at_log_teff = pk.at_log_teff; ax.at_logg = pk.at_logg;
             const int steps = 8 * K;
             const double dM = (pk.m_wd_up - is.tip) / steps;

@@ -176,8 +176,9 @@ b9_pack ModelPack::view() const
     p.iso_first_eep = iso_first_eep.data(); p.iso_n_eep = iso_n_eep.data(); p.iso_offset = iso_offset.data();
     p.n_points = (int64_t)mass.size();
     p.mass = mass.data(); p.mags = mags.data(); p.abs_coeff = abs_coeff.data();
-    p.n_wc_carb = (int32_t)wc_carb.size(); p.n_wc_mass = (int32_t)wc_mass.size(); p.n_wc_age = (int32_t)wc_log_age.size();
+    p.n_wc_carb = (int32_t)wc_carb.size(); p.n_wc_mass = (int32_t)wc_mass.size(); p.n_wc_points = (int64_t)wc_log_age.size();
     p.wc_carb = wc_carb.data(); p.wc_mass = wc_mass.data(); p.wc_log_age = wc_log_age.data();
+    p.wc_n_age = wc_n_age.data(); p.wc_offset = wc_offset.data();
     p.wc_log_teff = wc_log_teff.data(); p.wc_log_radius = wc_log_radius.data();
     p.n_at_type = n_at_type; p.n_at_logg = (int32_t)at_logg.size(); p.n_at_teff = (int32_t)at_log_teff.size();
     p.at_logg = at_logg.data(); p.at_log_teff = at_log_teff.data(); p.at_mags = at_mags.data();
@@ -320,17 +321,25 @@ ModelPack load_model_pack(const std::string &dir, const std::string &ms_model, c
             if (tracks.empty()) fail(path + ": no cooling tracks");
             for (auto &t : tracks) { insert_axis(pk.wc_carb, t.carb); insert_axis(pk.wc_mass, t.mass); }
             std::sort(pk.wc_carb.begin(), pk.wc_carb.end()); std::sort(pk.wc_mass.begin(), pk.wc_mass.end());
-            pk.wc_log_age = tracks.front().age;
-            const size_t nA = pk.wc_log_age.size();
-            pk.wc_log_teff.assign(pk.wc_carb.size() * pk.wc_mass.size() * nA, NAN);
-            pk.wc_log_radius = pk.wc_log_teff;
+            // every (carbonicity, mass) node needs exactly one track; each keeps ITS OWN age axis (tracks are ragged)
+            const size_t nC = pk.wc_carb.size(), nM = pk.wc_mass.size();
+            std::vector<const Track *> at(nC * nM, nullptr);
             for (auto &t : tracks) {
-                if (t.age != pk.wc_log_age) fail(path + ": every cooling track must use the same age axis (rectangular table)");
-                size_t base = ((size_t)axis_index(pk.wc_carb, t.carb) * pk.wc_mass.size() + axis_index(pk.wc_mass, t.mass)) * nA;
-                std::copy(t.teff.begin(), t.teff.end(), pk.wc_log_teff.begin() + base);
-                std::copy(t.rad.begin(), t.rad.end(), pk.wc_log_radius.begin() + base);
+                const size_t k = (size_t)axis_index(pk.wc_carb, t.carb) * nM + axis_index(pk.wc_mass, t.mass);
+                if (at[k]) fail(path + ": duplicate cooling track");
+                if (t.age.size() < 2) fail(path + ": a cooling track needs at least two points");
+                for (size_t i = 1; i < t.age.size(); ++i)
+                    if (!(t.age[i] > t.age[i - 1])) fail(path + ": the cooling ages of a track must ascend");
+                at[k] = &t;
             }
-            for (double v : pk.wc_log_teff) if (std::isnan(v)) fail(path + ": cooling table has holes");
+            for (size_t k = 0; k < at.size(); ++k) {
+                if (!at[k]) fail(path + ": the (carbonicity, mass) grid of cooling tracks has holes");
+                pk.wc_n_age.push_back((int32_t)at[k]->age.size());
+                pk.wc_offset.push_back((int64_t)pk.wc_log_age.size());
+                pk.wc_log_age.insert(pk.wc_log_age.end(), at[k]->age.begin(), at[k]->age.end());
+                pk.wc_log_teff.insert(pk.wc_log_teff.end(), at[k]->teff.begin(), at[k]->teff.end());
+                pk.wc_log_radius.insert(pk.wc_log_radius.end(), at[k]->rad.begin(), at[k]->rad.end());
+            }
         }
         // ---- WD atmospheres ------------------------------------------------------------------------
         for (int type = 0; type < 2; ++type) {

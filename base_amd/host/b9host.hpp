@@ -40,7 +40,10 @@ struct ModelPack {
     std::vector<int32_t> iso_first_eep, iso_n_eep;
     std::vector<int64_t> iso_offset;
     std::vector<double> mass, mags, abs_coeff;
-    std::vector<double> wc_carb, wc_mass, wc_log_age, wc_log_teff, wc_log_radius;
+    // WD cooling tracks, one per (carbonicity, mass) node in that order, each with its own age axis (ragged)
+    std::vector<double> wc_carb, wc_mass, wc_log_age, wc_log_teff, wc_log_radius;   // the last three: all tracks, concatenated
+    std::vector<int32_t> wc_n_age;
+    std::vector<int64_t> wc_offset;
     std::vector<double> at_logg, at_log_teff, at_mags;
     int n_at_type = 0;
     int ifmr_id = B9_IFMR_WILLIAMS;

@@ -53,7 +53,7 @@ def _iso_points(log_age, feh, y, eep_ids, n_eep_ref, n_filt):
 
 def make_pack(name: str = "parsec", n_filt: int = 8, n_y: int = 1, ragged: bool = True,
               wd: bool = True, ifmr_id: int = abi.IFMR_WILLIAMS, n_feh: Optional[int] = None,
-              n_age: Optional[int] = None, n_eep: Optional[int] = None) -> Dict:
+              n_age: Optional[int] = None, n_eep: Optional[int] = None, wd_ragged: bool = False) -> Dict:
     """Build a synthetic pack as a dict of numpy arrays (keys = b9_pack fields)."""
     sh = dict(PACK_SHAPES[name])
     if n_feh: sh["n_feh"] = n_feh
@@ -87,18 +87,52 @@ def make_pack(name: str = "parsec", n_filt: int = 8, n_y: int = 1, ragged: bool 
              filters=(FILTERS_8[:n_filt] if n_filt <= 8 else [f"F{i}" for i in range(n_filt)]),
              ifmr_id=ifmr_id, m_wd_up=8.0)
     if wd:
-        d.update(make_wd_tables(n_filt))
+        d.update(make_wd_tables(n_filt, ragged=wd_ragged))
     return d
 
 
-def make_wd_tables(n_filt: int, n_carb: int = 3) -> Dict:
-    """Synthetic WD cooling (Montgomery-like, carbonicity axis) + Bergeron-like atmospheres."""
+def wd_cooling_tracks(pack: Dict):
+    """The WD cooling model as a list of tracks in (carbonicity, mass) order: (log_age[n], log_teff[n], log_radius[n]) each.
+    Accepts the ragged form (wc_n_age / wc_offset) and the rectangular one (one shared age axis)."""
+    n_tracks = max(1, len(pack["wc_carb"])) * len(pack["wc_mass"])
+    te, ra = np.asarray(pack["wc_log_teff"]).ravel(), np.asarray(pack["wc_log_radius"]).ravel()
+    if "wc_n_age" in pack:
+        age = np.asarray(pack["wc_log_age"])
+        return [(age[o:o + n], te[o:o + n], ra[o:o + n]) for n, o in zip(np.asarray(pack["wc_n_age"]), np.asarray(pack["wc_offset"]))]
+    n = len(pack["wc_log_age"])
+    return [(np.asarray(pack["wc_log_age"]), te[t * n:(t + 1) * n], ra[t * n:(t + 1) * n]) for t in range(n_tracks)]
+
+
+def make_wd_tables(n_filt: int, n_carb: int = 3, ragged: bool = False) -> Dict:
+    """Synthetic WD cooling (Montgomery-like, carbonicity axis) + Bergeron-like atmospheres.  ragged: every
+    (carbonicity, mass) track gets its own cooling-age axis -- different length, range and spacing -- as real cooling
+    tracks have (b9_pack: wc_n_age / wc_offset)."""
     carb = np.linspace(0.2, 0.8, n_carb) if n_carb > 1 else np.array([0.38])
     wmass = np.linspace(0.4, 1.2, 9)
-    lage = np.linspace(6.0, 10.3, 50)
-    cc, mm, aa = np.meshgrid(carb, wmass, lage, indexing="ij")
-    log_teff = 5.05 - 0.27 * (aa - 6.0) - 0.012 * (aa - 6.0) ** 2 + 0.12 * (mm - 0.6) + 0.05 * (cc - 0.38)
-    log_rad = np.log10(8.8e8) - np.log10(mm / 0.6) / 3.0 + 0.02 * (log_teff - 4.0)
+
+    def track(c, m, lage):
+        log_teff = 5.05 - 0.27 * (lage - 6.0) - 0.012 * (lage - 6.0) ** 2 + 0.12 * (m - 0.6) + 0.05 * (c - 0.38)
+        log_rad = np.log10(8.8e8) - np.log10(m / 0.6) / 3.0 + 0.02 * (log_teff - 4.0)
+        return log_teff, log_rad
+
+    if ragged:
+        ages, tes, ras, n_age, offset = [], [], [], [], []
+        off = 0
+        for ic, c in enumerate(carb):
+            for im, m in enumerate(wmass):
+                n = 50 - 3 * ((2 * ic + im) % 5) + (7 if im == 4 else 0)
+                lo, hi = 6.0 + 0.07 * ((ic + 2 * im) % 4), 10.3 - 0.05 * ((3 * ic + im) % 3)
+                lage = lo + (hi - lo) * np.linspace(0.0, 1.0, n) ** (1.0 + 0.15 * (im % 3))
+                te, ra = track(c, m, lage)
+                ages.append(lage); tes.append(te); ras.append(ra); n_age.append(n); offset.append(off)
+                off += n
+        cool = dict(wc_carb=carb, wc_mass=wmass, wc_n_age=np.array(n_age, np.int32), wc_offset=np.array(offset, np.int64),
+                    wc_log_age=np.concatenate(ages), wc_log_teff=np.concatenate(tes), wc_log_radius=np.concatenate(ras))
+    else:
+        lage = np.linspace(6.0, 10.3, 50)
+        cc, mm, aa = np.meshgrid(carb, wmass, lage, indexing="ij")
+        log_teff, log_rad = track(cc, mm, aa)
+        cool = dict(wc_carb=carb, wc_mass=wmass, wc_log_age=lage, wc_log_teff=log_teff.ravel(), wc_log_radius=log_rad.ravel())
     logg = np.linspace(7.0, 9.5, 6)
     lteff = np.linspace(3.4, 5.1, 60)
     lam = (np.arange(n_filt) - 2.0) / 3.0
@@ -108,9 +142,7 @@ def make_wd_tables(n_filt: int, n_carb: int = 3) -> Dict:
         mbol = 12.6 - 10.0 * (tt - 4.0) + (gg - 8.0) * (2.5 / 1.5) + 0.15 * t
         col = -(tt - 4.0) * (1.4 - 0.2 * t)
         at[t] = mbol[..., None] + col[..., None] * lam[None, None, :] + 0.05 * t * lam[None, None, :] ** 2
-    return dict(wc_carb=carb, wc_mass=wmass, wc_log_age=lage, wc_log_teff=log_teff.ravel(),
-                wc_log_radius=log_rad.ravel(), at_logg=logg, at_log_teff=lteff, at_mags=at.ravel(),
-                n_at_type=2)
+    return dict(cool, at_logg=logg, at_log_teff=lteff, at_mags=at.ravel(), n_at_type=2)
 
 
 # ------------------------------------------------------------------------------------------
@@ -208,26 +240,34 @@ def _wd_mags(pack, par, m, wd_type):
     wdm = _ifmr(pack, par, m)
     with np.errstate(invalid="ignore", divide="ignore"):
         cool = np.log10(np.maximum(10.0 ** log_age - 10.0 ** prec, 1e-300))
-    nC, nM, nT = len(pack["wc_carb"]), len(pack["wc_mass"]), len(pack["wc_log_age"])
-    ia, ta = _lin(pack["wc_log_age"], cool)
+    nC, nM = len(pack["wc_carb"]), len(pack["wc_mass"])
+    tracks = wd_cooling_tracks(pack)
     im, tm = _lin(pack["wc_mass"], wdm)
     if nC > 1:
         ic, tc = _lin(pack["wc_carb"], np.full_like(m, par[abi.P_CARBONICITY]))
     else:
-        ic, tc = np.zeros_like(ia), np.zeros_like(ta)
+        ic, tc = np.zeros_like(im), np.zeros_like(tm)
 
-    def tri(tab):
-        tab = tab.reshape(nC, nM, nT)
+    def along(q, t_idx):
+        """Quantity q (1 Teff, 2 radius) of every star along its track t_idx[i], at its cooling age (own axis per track)."""
+        out = np.empty(len(m))
+        for t in np.unique(t_idx):
+            sel = t_idx == t
+            age, tab = tracks[t][0], tracks[t][q]
+            ia, ta = _lin(age, cool[sel])
+            out[sel] = tab[ia] + ta * (tab[ia + 1] - tab[ia])
+        return out
+
+    def tri(q):
         def at_c(icc):
-            a0 = tab[icc, im, ia] + ta * (tab[icc, im, ia + 1] - tab[icc, im, ia])
-            a1 = tab[icc, im + 1, ia] + ta * (tab[icc, im + 1, ia + 1] - tab[icc, im + 1, ia])
+            a0, a1 = along(q, icc * nM + im), along(q, icc * nM + im + 1)
             return a0 + tm * (a1 - a0)
         if nC > 1:
             c0, c1 = at_c(ic), at_c(ic + 1)
             return c0 + tc * (c1 - c0)
         return at_c(ic)
 
-    lteff, lrad = tri(pack["wc_log_teff"]), tri(pack["wc_log_radius"])
+    lteff, lrad = tri(1), tri(2)
     logg = 26.12302173752 + np.log10(wdm) - 2.0 * lrad
     nG, nTe = len(pack["at_logg"]), len(pack["at_log_teff"])
     at = pack["at_mags"].reshape(-1, nG, nTe, nf)
@@ -401,16 +441,17 @@ def write_models_dir(pack: Dict, root: str, ms_name: Optional[str] = None, wd_na
         for name, c in zip(filters, pack["abs_coeff"]):
             f.write(f"{name} {_g(c)}\n")
     if len(pack.get("wc_mass", [])) >= 2:
-        nC, nM, nT = len(pack["wc_carb"]), len(pack["wc_mass"]), len(pack["wc_log_age"])
-        te, ra = pack["wc_log_teff"].reshape(nC, nM, nT), pack["wc_log_radius"].reshape(nC, nM, nT)
+        nM = len(pack["wc_mass"])
+        tracks = wd_cooling_tracks(pack)
         with open(os.path.join(root, "wd", f"cooling_{wd_name}.dat"), "w") as f:
             f.write("# logCoolAge logTeff logRadius\n")
             for ic, c in enumerate(pack["wc_carb"]):
                 f.write(f"%c carbonicity={_g(c)}\n")
                 for im, m in enumerate(pack["wc_mass"]):
                     f.write(f"%m mass={_g(m)}\n")
-                    for it in range(nT):
-                        f.write(f"{_g(pack['wc_log_age'][it])} {_g(te[ic, im, it])} {_g(ra[ic, im, it])}\n")
+                    age, te, ra = tracks[ic * nM + im]
+                    for it in range(len(age)):
+                        f.write(f"{_g(age[it])} {_g(te[it])} {_g(ra[it])}\n")
         nG, nTe = len(pack["at_logg"]), len(pack["at_log_teff"])
         at = pack["at_mags"].reshape(-1, nG, nTe, nf)
         for t in range(at.shape[0]):

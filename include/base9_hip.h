@@ -93,13 +93,21 @@ typedef struct b9_pack {
     const double *mass;           /* [n_points]                                          */
     const double *mags;           /* [n_points*n_filt]                                   */
     const double *abs_coeff;      /* [n_filt]  A_f / A_V                                  */
-    /* WD cooling model: rectangular [n_wc_carb][n_wc_mass][n_wc_age] (n_wc_mass == 0: no WD models) */
-    int32_t n_wc_carb, n_wc_mass, n_wc_age;
+    /* WD cooling model (ABI 2): one cooling track per (carbonicity, WD mass) node, EACH WITH ITS OWN cooling-age axis --
+     * real cooling tracks are ragged: every mass was evolved over its own sequence of ages.  Track (ic, im) has index
+     * t = ic * n_wc_mass + im and holds wc_n_age[t] >= 2 points (log cooling age strictly ascending) starting at point
+     * offset wc_offset[t] of wc_log_age / wc_log_teff / wc_log_radius.  A lookup brackets the cooling age in each of
+     * the (2 carbonicities x) 2 masses' own axes, interpolates along each track, then across mass, then across
+     * carbonicity.  n_wc_mass == 0: no WD models.  n_wc_carb <= 1: carbonicity is not an axis. */
+    int32_t n_wc_carb, n_wc_mass;
     const double *wc_carb;        /* [n_wc_carb]                                         */
     const double *wc_mass;        /* [n_wc_mass] WD mass, Msun                            */
-    const double *wc_log_age;     /* [n_wc_age]  log10 cooling age / yr                   */
-    const double *wc_log_teff;    /* [n_wc_carb*n_wc_mass*n_wc_age]                      */
-    const double *wc_log_radius;  /* same shape, log10 R / cm                             */
+    const int32_t *wc_n_age;      /* [max(1,n_wc_carb)*n_wc_mass] points of each track      */
+    const int64_t *wc_offset;     /* [max(1,n_wc_carb)*n_wc_mass] first point of each track */
+    int64_t n_wc_points;          /* total cooling-track points                           */
+    const double *wc_log_age;     /* [n_wc_points] log10 cooling age / yr                 */
+    const double *wc_log_teff;    /* [n_wc_points]                                       */
+    const double *wc_log_radius;  /* [n_wc_points] log10 R / cm                           */
     /* WD atmospheres: [n_at_type][n_at_logg][n_at_teff][n_filt], type 0 = DA, 1 = DB      */
     int32_t n_at_type, n_at_logg, n_at_teff;
     const double *at_logg;        /* [n_at_logg]                                         */

@@ -211,9 +211,10 @@ static void wd_mags(const b9_pack *p, const b9o_iso *iso, const double *par, dou
     double wd_mass = ifmr(p, par, m);
     double log_cool = log10(pow(10.0, log_age) - pow(10.0, prec));
 
-    /* cooling model: age, then mass, then carbonicity; bracket clamped, extrapolation allowed */
-    int ia = bracket(p->wc_log_age, p->n_wc_age, log_cool);
-    double ta = (log_cool - p->wc_log_age[ia]) / (p->wc_log_age[ia + 1] - p->wc_log_age[ia]);
+    /* cooling model: every (carbonicity, mass) node is a track with ITS OWN cooling-age axis
+     * (include/base9_hip.h, b9_pack: wc_n_age / wc_offset).  The age is bracketed (clamped; extrapolation allowed) in
+     * each neighbouring track's axis and both quantities are interpolated along the track; then across mass, then
+     * across carbonicity. */
     int im = bracket(p->wc_mass, p->n_wc_mass, wd_mass);
     double tm = (wd_mass - p->wc_mass[im]) / (p->wc_mass[im + 1] - p->wc_mass[im]);
     int nc = (p->n_wc_carb > 1) ? 2 : 1, ic = 0; double tc = 0.0;
@@ -228,7 +229,11 @@ static void wd_mags(const b9_pack *p, const b9o_iso *iso, const double *par, dou
         for (int dc = 0; dc < nc; ++dc) {
             double vm[2];
             for (int dm = 0; dm < 2; ++dm) {
-                size_t base = ((size_t)(ic + dc) * p->n_wc_mass + (im + dm)) * p->n_wc_age + ia;
+                const int t = (ic + dc) * p->n_wc_mass + (im + dm);
+                const double *age = p->wc_log_age + p->wc_offset[t];
+                const int ia = bracket(age, p->wc_n_age[t], log_cool);
+                const double ta = (log_cool - age[ia]) / (age[ia + 1] - age[ia]);
+                const size_t base = (size_t)p->wc_offset[t] + ia;
                 vm[dm] = lerp(tab[base], tab[base + 1], ta);
             }
             vc[dc] = lerp(vm[0], vm[1], tm);

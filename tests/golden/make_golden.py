@@ -27,14 +27,18 @@ CASES = {
     "c1_dsed_8f_300": ("dsed", 8, 300, 0.0, 1, 1, dict(n_feh=4, n_age=8, n_eep=60)),
     "c3_parsec_8f_wd_300": ("parsec", 8, 300, 0.1, 1, 1, dict(n_feh=4, n_age=8, n_eep=60)),
     "c4_parsec_8f_2pop_300": ("parsec", 8, 300, 0.05, 3, 2, dict(n_feh=3, n_age=6, n_eep=50)),
+    # ragged WD cooling tracks (b9_pack ABI 2: wc_n_age / wc_offset), a WD-rich cluster
+    "c5_parsec_8f_wdragged_300": ("parsec", 8, 300, 0.3, 1, 1, dict(n_feh=4, n_age=8, n_eep=60, wd_ragged=True)),
 }
 PACK_KEYS = ["feh", "y", "log_age", "iso_first_eep", "iso_n_eep", "iso_offset", "mass", "mags", "abs_coeff",
              "wc_carb", "wc_mass", "wc_log_age", "wc_log_teff", "wc_log_radius", "at_logg", "at_log_teff", "at_mags"]
 STAR_KEYS = ["obs", "sigma", "mass1", "mass_ratio", "clust_prior", "stage", "wd_type", "filter_prior_min", "filter_prior_max"]
 
 
-def main():
+def main(only=None):
     for name, (pk, nf, ns, wd, ny, npops, kw) in CASES.items():
+        if only and name not in only:
+            continue
         pack_d = synth.make_pack(pk, n_filt=nf, n_y=ny, **kw)
         truth = synth.default_params(pack_d)
         cl = synth.make_cluster(pack_d, ns, seed=9001, truth=truth, wd_frac=wd, n_pops=npops)
@@ -57,6 +61,7 @@ def main():
         start = params[:3].copy()
         chain = mcmc.HostBlockRunner(orc.logpost).run(start, orc.logpost(start), np.array([0, 1, 2]), free, chol, 2024, 40, 20)
         out = {f"pack_{k}": np.asarray(pack_d[k]) for k in PACK_KEYS}
+        out.update({f"pack_{k}": np.asarray(pack_d[k]) for k in ("wc_n_age", "wc_offset") if k in pack_d})
         out.update(marg_logpost=mlp, marg_perstar=mps, sm_mass=sm[0], sm_ratio=sm[1], sm_member=sm[2], sm_pop=sm[3], sm_margin=sm[4],
                    chain_free=free, chain_chol=chol, chain_params=chain[0], chain_logpost=chain[1], chain_samples=chain[2],
                    chain_lps=chain[3], chain_accepted=chain[4])
@@ -71,4 +76,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]))        # no arguments: every case; else only the named ones

@@ -102,6 +102,53 @@ def test_logpost_matches_oracle(hip, monkeypatch, name, n_filt, n_stars, wd_frac
     np.testing.assert_array_equal(lp_g, lp_g2)
 
 
+def _long_tracks(pack_d, factor):
+    """The same cooling tracks resampled `factor` times denser (own axis per track): past the LDS staging limit the
+    kernels search the age axes in L2 instead."""
+    tracks = synth.wd_cooling_tracks(pack_d)
+    ages, tes, ras, n_age, offset, off = [], [], [], [], [], 0
+    for a, te, ra in tracks:
+        fine = np.interp(np.linspace(0, len(a) - 1, (len(a) - 1) * factor + 1), np.arange(len(a)), a)
+        ages.append(fine); tes.append(np.interp(fine, a, te)); ras.append(np.interp(fine, a, ra))
+        n_age.append(len(fine)); offset.append(off); off += len(fine)
+    return dict(pack_d, wc_n_age=np.array(n_age, np.int32), wc_offset=np.array(offset, np.int64), wc_log_age=np.concatenate(ages),
+                wc_log_teff=np.concatenate(tes), wc_log_radius=np.concatenate(ras))
+
+
+@pytest.mark.parametrize("n_y,n_pops,dense", [(1, 1, 1), (3, 2, 1), (1, 1, 8)])
+def test_ragged_wd_cooling_tracks(hip, n_y, n_pops, dense):
+    """b9_pack ABI 2: every (carbonicity, mass) cooling track has its own age axis.  Given-mass mode (the heavy-star role:
+    axes in LDS, or in L2 when they are too long for it), the marginalised mode's WD-stage integral, and the per-star
+    mass draws, against the oracle."""
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=900, wd_frac=0.3, n_y=n_y, n_pops=n_pops,
+                                                             small=False, wd_ragged=True)
+    if dense > 1:
+        pack_d = _long_tracks(pack_d, dense)
+        pack = abi.make_pack(pack_d)
+        assert pack.struct.n_wc_points > 6144
+    assert len(set(np.asarray(pack_d["wc_n_age"]).tolist())) > 2
+    eng = hip.Engine(pack, stars, priors, options)
+    orc = oracle.Oracle(pack, stars, priors, options)
+    params = synth.walker_params(cl["truth"], 5, n_pops=n_pops)
+    params[2, abi.P_LOGAGE] = pack_d["log_age"][0] + 0.02         # young: cooling ages below some tracks' first point
+    params[3, abi.P_CARBONICITY] = 0.23
+    params[4, abi.P_LOGAGE] = pack_d["log_age"][-1] - 1e-3        # old: most stars above the tip, long cooling ages
+    lp_g, ps_g = eng.logpost(params, perstar=True)
+    lp_o, ps_o = orc.logpost(params, perstar=True)
+    _close(ps_g, ps_o)
+    _close(lp_g, lp_o)
+    # marginalised mode: WD-stage stars integrate over the WD branch
+    opt_m = abi.make_options(abi.MODE_MARGINALISED, n_pops, 2, 2)
+    sub = {k: (np.asarray(v)[:120] if k in ("obs", "sigma", "mass1", "mass_ratio", "clust_prior", "stage", "wd_type") else v) for k, v in cl.items()}
+    stars_m = abi.make_stars(sub)
+    eng_m = hip.Engine(pack, stars_m, priors, opt_m)
+    got = eng_m.logpost(params[:3], perstar=True)
+    want = oracle.Oracle(pack, stars_m, priors, opt_m).logpost(params[:3], perstar=True)
+    assert (np.asarray(sub["stage"]) == abi.STAGE_WD).sum() > 10
+    _close(got[1], want[1])
+    _close(got[0], want[0])
+
+
 def test_all_ifmr_ids_and_db_atmospheres(hip):
     for ifmr in range(6):
         pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=500, wd_frac=0.3, ifmr_id=ifmr)

@@ -34,9 +34,9 @@ def _arr(ptr, n, dtype=np.float64):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).copy() if n else np.zeros(0, dtype)
 
 
-@pytest.mark.parametrize("name,n_filt,n_y", [("parsec", 8, 1), ("dsed", 5, 3)])
-def test_model_pack_round_trip(hostlib, tmp_path, name, n_filt, n_y):
-    pack_d = synth.make_pack(name, n_filt=n_filt, n_y=n_y, n_feh=3, n_age=4, n_eep=30)
+@pytest.mark.parametrize("name,n_filt,n_y,wd_ragged", [("parsec", 8, 1, False), ("dsed", 5, 3, True)])
+def test_model_pack_round_trip(hostlib, tmp_path, name, n_filt, n_y, wd_ragged):
+    pack_d = synth.make_pack(name, n_filt=n_filt, n_y=n_y, n_feh=3, n_age=4, n_eep=30, wd_ragged=wd_ragged)
     root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
     # ask for the filters in a different order than the files hold them
     want = list(reversed(pack_d["filters"]))
@@ -54,7 +54,19 @@ def test_model_pack_round_trip(hostlib, tmp_path, name, n_filt, n_y):
         np.testing.assert_array_equal(_arr(view.mass, view.n_points), pack_d["mass"])
         np.testing.assert_array_equal(_arr(view.mags, view.n_points * n_filt).reshape(-1, n_filt), pack_d["mags"][:, ::-1])
         np.testing.assert_array_equal(_arr(view.abs_coeff, n_filt), pack_d["abs_coeff"][::-1])
-        np.testing.assert_array_equal(_arr(view.wc_log_teff, view.n_wc_carb * view.n_wc_mass * view.n_wc_age), pack_d["wc_log_teff"])
+        # cooling tracks: one per (carbonicity, mass) node, each with its own age axis (rectangular packs repeat theirs)
+        tracks = synth.wd_cooling_tracks(pack_d)
+        n_tracks = view.n_wc_carb * view.n_wc_mass
+        assert n_tracks == len(tracks) and view.n_wc_points == sum(len(t[0]) for t in tracks)
+        n_age, off = _arr(view.wc_n_age, n_tracks, np.int32), _arr(view.wc_offset, n_tracks, np.int64)
+        age, te, ra = (_arr(p, view.n_wc_points) for p in (view.wc_log_age, view.wc_log_teff, view.wc_log_radius))
+        for t, (a, b, c) in enumerate(tracks):
+            assert n_age[t] == len(a)
+            np.testing.assert_array_equal(age[off[t]:off[t] + n_age[t]], a)
+            np.testing.assert_array_equal(te[off[t]:off[t] + n_age[t]], b)
+            np.testing.assert_array_equal(ra[off[t]:off[t] + n_age[t]], c)
+        if wd_ragged:
+            assert len(set(n_age.tolist())) > 1
         at = pack_d["at_mags"].reshape(2, view.n_at_logg, view.n_at_teff, n_filt)[..., ::-1]
         np.testing.assert_array_equal(_arr(view.at_mags, at.size), at.ravel())
         assert view.n_at_type == 2

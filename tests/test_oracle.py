@@ -97,6 +97,38 @@ def test_ifmr_variants_and_wd_types():
         np.testing.assert_allclose(ps[0], ref_ps, rtol=1e-10, atol=1e-9)
 
 
+@pytest.mark.parametrize("n_y,n_pops", [(1, 1), (3, 2)])
+def test_ragged_wd_cooling_tracks_match_numpy(n_y, n_pops):
+    """Cooling tracks with their own age axes (different lengths, ranges, spacings): oracle vs the numpy statement, on a
+    cluster rich in WDs of every cooling age -- including ages outside a track's range (clamped bracket, extrapolation)."""
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=500, wd_frac=0.3, n_y=n_y, n_pops=n_pops, wd_ragged=True)
+    assert len(set(pack_d["wc_n_age"].tolist())) > 2
+    orc = _oracle(pack, stars, priors, options)
+    params = synth.walker_params(cl["truth"], 4, n_pops=n_pops)
+    params[2, abi.P_LOGAGE] = pack_d["log_age"][0] + 0.02         # a young cluster: short cooling ages
+    params[3, abi.P_CARBONICITY] = 0.23                            # near the edge of the carbonicity axis
+    lp, ps = orc.logpost(params, perstar=True)
+    assert (cl["stage"] == abi.STAGE_WD).sum() > 80
+    for w in range(len(params)):
+        ref, ref_ps = numpy_ref.logpost(pack_d, cl, priors, params[w], n_pops)
+        np.testing.assert_allclose(ps[w], ref_ps, rtol=1e-10, atol=1e-9)
+        assert abs(lp[w] - ref) <= 1e-9 * max(1.0, abs(ref))
+
+
+def test_rectangular_cooling_table_is_a_special_case_of_ragged_tracks():
+    """A rectangular table (one shared age axis) given in the ragged form -- every track carrying its own copy of
+    the axis -- gives the same bits as the rectangular form abi.make_pack expands."""
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=300, wd_frac=0.3)
+    n_tracks, n_age = len(pack_d["wc_carb"]) * len(pack_d["wc_mass"]), len(pack_d["wc_log_age"])
+    rag = dict(pack_d, wc_n_age=np.full(n_tracks, n_age, np.int32), wc_offset=np.arange(n_tracks, dtype=np.int64) * n_age,
+               wc_log_age=np.tile(pack_d["wc_log_age"], n_tracks))
+    params = synth.walker_params(cl["truth"], 3)
+    a = _oracle(pack, stars, priors, options).logpost(params, perstar=True)
+    b = _oracle(abi.make_pack(rag), stars, priors, options).logpost(params, perstar=True)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
 def test_two_pop_lambda_limits_equal_single_pop():
     pack_d, cl, pack, stars, priors, _ = build_problem("parsec", 8, n_stars=300, n_y=3, n_pops=2)
     one = _oracle(pack, stars, priors, abi.make_options(n_pops=1))

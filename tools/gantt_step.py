@@ -69,6 +69,14 @@ if eng.lib.b9_debug_read_gantt_heavy(hb.ctypes.data) == 0:
     h = h[h[:, 5] > 0]
     print("heavy role phases of the last launch, us (workgroup: decide | count search | stage+sync | stars | reduce ; heavy stars of the walker):")
     for k, r in enumerate(h[:12]):
-        print(f"   wg {k:2d}: {(r[1]-r[0])/100:5.2f} | {(r[2]-r[1])/100:5.2f} | {(r[3]-r[2])/100 if r[3] else 0:5.2f} | {(r[4]-max(r[3], r[2]))/100:5.2f} | {(r[5]-r[4])/100:5.2f} ; {r[7]}")
+        print(f"   wg {k:2d}: loads {(r[1]-r[0])/100:5.2f} | stage+sync {(r[3]-r[1])/100:5.2f} | stars {(r[4]-r[3])/100:5.2f} | reduce {(r[5]-r[4])/100:5.2f}")
+h2 = np.zeros((64, 16), dtype=np.uint64)
+eng.lib.b9_debug_read_gantt_heavy2.argtypes = [C.c_void_p]
+if eng.lib.b9_debug_read_gantt_heavy2(h2.ctypes.data) == 0:
+    h = h2.astype(np.int64)
+    h = h[h[:, 9] > 0]
+    print("inside one heavy star (one lane), us since entry: data 1 | prec 2 | exp/log 4 | cooling 6 | desc 7 | loop start 8 | loop end 9 | MS search 11-12")
+    for k, r in enumerate(h[:4]):
+        print("   wg %2d: " % k + " ".join("%d:%5.2f" % (j, (r[j] - r[0]) / 100) if r[j] else "%d:  -  " % j for j in (1, 2, 4, 6, 7, 8, 9, 11, 12)))
 periods = np.diff([s[:, 0].min() for s in steps]) / 100.0
 print("launch period (first start -> next first start):", np.round(periods, 2))
