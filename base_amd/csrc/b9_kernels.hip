@@ -103,7 +103,7 @@ hipError_t b9k_derive_iso_rows(const DevPack &pk, const double *host_rows, doubl
 // B9_WC_AGE_LDS_MAX doubles; longer ones are searched in L2) + per (candidate, population) the four AGB-tip columns
 static size_t heavy_lds_doubles(const DevPack &pk, int n_pops, int n_cand, int mass_cap)
 {
-    auto blk = [](size_t n) { return (n + 255) & ~(size_t)255; };         // every segment starts at a multiple of 256 doubles
+    auto blk = [](size_t n) { return n; };
     const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
     const size_t wc_age = !has_wd ? 0 : (pk.wc_uniform ? (size_t)pk.wc_n0 : (pk.n_wc_points <= B9_WC_AGE_LDS_MAX ? (size_t)pk.n_wc_points : 0));
     const size_t n_tips = (size_t)pk.n_feh * pk.n_y * pk.n_age;

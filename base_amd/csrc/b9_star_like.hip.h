@@ -246,7 +246,7 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
 //     round trip (it used to be 6 + 4 NPOPS dependent ones).
 // A star occupies G = 2 NPOPS neighbouring lanes: (population, component) -- star_value_lanes.
 #ifndef B9_HEAVY_STAGE_E
-#define B9_HEAVY_STAGE_E 18         // 256-double blocks of the staged list a thread carries an element of in registers (longer lists finish in a loop)
+#define B9_HEAVY_STAGE_E 8          // staged elements a thread carries in registers (8 x 256 doubles; longer lists finish in a loop)
 #endif
 template <int NFP, int NPOPS, int NC, class SelectFn>
 __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *const (&hdr)[NC],
@@ -268,7 +268,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     const bool stage_wc_age = has_wd && (pk.wc_uniform || pk.n_wc_points <= B9_WC_AGE_LDS_MAX);       // (as heavy_lds_doubles sized the LDS)
     const bool tips_all = n_tips <= B9_TIPS_LDS_MAX;
     const double *seg_src[NSEG];
-    int seg_off[NSEG + 1], seg_len[NSEG];
+    int seg_off[NSEG + 1];
     {
         // (cooling-age axes: all tracks', or the one shared axis of a rectangular table)
         const double *src0[NM0] = {pk.log_age, pk.wc_log_age + (pk.wc_uniform ? pk.wc_off0 : 0), pk.wc_mass, pk.wc_carb, pk.at_log_teff,
@@ -276,40 +276,30 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         const int len0[NM0] = {na, stage_wc_age ? (pk.wc_uniform ? pk.wc_n0 : pk.n_wc_points) : 0, has_wd ? pk.n_wc_mass : 0, has_wd ? pk.n_wc_carb : 0,
                                has_wd ? pk.n_at_teff : 0, has_wd ? pk.n_at_logg : 0, has_wd ? pk.n_wc_carb * pk.n_wc_mass : 0,
                                tips_all ? n_tips : 4 * NPOPS * NC * na};
-        // every segment starts at a multiple of 256 doubles of the LDS image: block k of the list (elements k * 256 + tid)
-        // then lies in ONE segment, found with scalar compares -- a per-element search through the segment table cost each
-        // thread ~60 vector instructions per element, 1.5 us of this role's chain
         seg_off[0] = 0;
 #pragma unroll
-        for (int a = 0; a < NM0; ++a) { seg_src[a] = src0[a]; seg_len[a] = len0[a]; seg_off[a + 1] = seg_off[a] + ((len0[a] + 255) & ~255); }
+        for (int a = 0; a < NM0; ++a) { seg_src[a] = src0[a]; seg_off[a + 1] = seg_off[a] + len0[a]; }
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int kp = 0; kp < NPOPS; ++kp) {         // (a candidate's buffer exists even when its contents do not yet)
                 const int k = NM0 + c * NPOPS + kp;
                 seg_src[k] = iso_data[c] + (size_t)(w * NPOPS + kp) * iso_stride;
-                seg_len[k] = mass_cap;
-                seg_off[k + 1] = seg_off[k] + ((mass_cap + 255) & ~255);
+                seg_off[k + 1] = seg_off[k] + mass_cap;
             }
     }
-    const int n_blocks = seg_off[NSEG] >> 8, tip_lo = seg_off[NC0];
-    // element `tid` of block `blk`: its source address and whether it exists (wave-uniform segment lookup)
-    auto stage_elem = [&](int blk, const double *&src) {
-        int g_off = 0, g_len = seg_len[0];
-        const double *g_src = seg_src[0];
+    const int n_stage = seg_off[NSEG], tip_lo = seg_off[NC0], tip_hi = seg_off[NM0];
+    auto stage_src = [&](int e) {
+        const double *src = seg_src[0] + e;
 #pragma unroll
-        for (int g = 1; g < NSEG; ++g) {
-            const bool here = blk * 256 >= seg_off[g];
-            g_off = here ? seg_off[g] : g_off; g_len = here ? seg_len[g] : g_len; g_src = here ? seg_src[g] : g_src;
-        }
-        const int j = blk * 256 + tid - g_off;
-        src = g_src + j;
-        // (pass 1 skips the AGB-tip columns of large grids: their addresses need the headers -- pass 2)
-        return blk < n_blocks && j < g_len && (tips_all || g_off != tip_lo);
+        for (int g = 1; g < NSEG; ++g) src = e >= seg_off[g] ? seg_src[g] + (e - seg_off[g]) : src;
+        return src;
     };
+    // (pass 1 skips the AGB-tip columns of large grids: their addresses need the headers -- pass 2)
+    auto in_pass1 = [&](int e) { return e < n_stage && (tips_all || e < tip_lo || e >= tip_hi); };
     double sv[E];
 #pragma unroll
-    for (int k = 0; k < E; ++k) { const double *src; sv[k] = stage_elem(k, src) ? *src : 0.0; }
+    for (int k = 0; k < E; ++k) { const int e = tid + k * 256; sv[k] = in_pass1(e) ? *stage_src(e) : 0.0; }
     // (both candidates' headers are requested BEFORE the selection is known -- one round trip fewer on the chain; a
     //  candidate that does not exist yet, in the first launch of a block, holds anything: its fields are only used once
     //  selected, and it never is)
@@ -331,8 +321,8 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     const int safe = sel;
     HSTAMP(1);
 #pragma unroll
-    for (int k = 0; k < E; ++k) { const double *src; if (stage_elem(k, src)) s_axes[k * 256 + tid] = sv[k]; }
-    for (int blk = E; blk < n_blocks; ++blk) { const double *src; if (stage_elem(blk, src)) s_axes[blk * 256 + tid] = *src; }       // very long lists only
+    for (int k = 0; k < E; ++k) { const int e = tid + k * 256; if (in_pass1(e)) s_axes[e] = sv[k]; }
+    for (int e = tid + E * 256; e < n_stage; e += 256) if (in_pass1(e)) s_axes[e] = *stage_src(e);       // very long lists only
     if (!tips_all) {
         // pass 2 (large grids only): the AGB-tip columns of each (candidate, population)'s four (FeH, Y) corners, whose
         // addresses the headers give
@@ -368,7 +358,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         const int v_feh = B9_PICK(i_feh), v_y = B9_PICK(i_y);
 #undef B9_PICK
         const int ck = (C ? NC - 1 : 0) * NPOPS + (B ? NPOPS - 1 : 0);
-        lv.is_mass = s_axes + seg_off[NM0] + ck * ((mass_cap + 255) & ~255);     // the LDS copy of the mass column
+        lv.is_mass = s_axes + seg_off[NM0] + ck * mass_cap;                      // the LDS copy of the mass column
         lv.par = (C ? params[NC - 1] : params[0]) + (size_t)w * B9_NPARAM;
         lv.ax.log_age = s_axes + seg_off[0];
         lv.ax.wc_log_age_lds = stage_wc_age ? s_axes + seg_off[1] : nullptr;

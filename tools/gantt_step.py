@@ -67,7 +67,7 @@ eng.lib.b9_debug_read_gantt_heavy.argtypes = [C.c_void_p]
 if eng.lib.b9_debug_read_gantt_heavy(hb.ctypes.data) == 0:
     h = hb.astype(np.int64)
     h = h[h[:, 5] > 0]
-    print("heavy role phases of the last launch, us (workgroup: decide | count search | stage+sync | stars | reduce ; heavy stars of the walker):")
+    print("heavy role phases of the last launch, us (workgroup: entry loads + decision | LDS stage + barrier | stars | reduce):")
     for k, r in enumerate(h[:12]):
         print(f"   wg {k:2d}: loads {(r[1]-r[0])/100:5.2f} | stage+sync {(r[3]-r[1])/100:5.2f} | stars {(r[4]-r[3])/100:5.2f} | reduce {(r[5]-r[4])/100:5.2f}")
 h2 = np.zeros((64, 16), dtype=np.uint64)
