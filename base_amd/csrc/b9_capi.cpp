@@ -362,6 +362,10 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
     sp.plan.tiles_per_block = tpb;
     sp.plan.n_groups = (n_tiles + tpb - 1) / tpb;
+    if (const char *e = getenv("B9_N_GROUPS")) {         // experiments: tile groups per walker (strided plans only)
+        sp.plan.n_groups = std::max(1, std::min(atoi(e), n_tiles));
+        sp.plan.tiles_per_block = tpb = (n_tiles + sp.plan.n_groups - 1) / sp.plan.n_groups;
+    }
     int parts = ctx->derive_parts;
     if (parts <= 0) {
         const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_groups * n_walkers - (long long)n_walkers * ctx->heavy_parts;

@@ -526,45 +526,61 @@ struct LaneView {
 // One star through the descriptors, spread over 2 NPOPS neighbouring lanes: lane `sub` of the star's group evaluates
 // component (sub & 1) in population (sub >> 1).  The heavy role is a latency chain (a WD descriptor is ~30 dependent LDS
 // search steps, three library transcendentals and two memory round trips); laid end to end in one lane a two-population
-// binary cost four of them (22-30 us measured), side by side they cost one.  The lanes meet twice, by wave shuffles: the
-// secondary's magnitude (per filter) and the other population's log-likelihood.  Every value is formed by
-// star_value's operations in star_value's order (same bits).  All lanes of a group must call (full EXEC); the result is
-// valid in the group's lane 0.
+// binary cost four of them (22-30 us measured), side by side they cost one.  The lanes meet by wave shuffles: the pair
+// of a population swaps component descriptors and then splits the FILTERS (each lane forms both components' magnitudes in
+// half of them), and the populations swap log-likelihoods.  Every magnitude is formed by star_value's operations; the
+// chi^2 is the sum of two half-sums instead of one chain over the filters (a 1e-16 relative difference).  All lanes of a
+// group must call (full EXEC); the result is valid in every lane of the group.
 template <int NFP, int NPOPS>
 __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const LaneView<NFP> &lv, const DevStars &st,
                                                    int j /* index in the descending-mass list */, int sub, double m1)
 {
-    HS2(0);
     const int comp = sub & 1;
+    constexpr int HF = NFP / 2;                                       // filters per lane of a (population) pair
     // everything the star needs from memory is requested here, in one round trip (heavy-order arrays: DevStars::hv_*)
     const double q = st.hv_q[j], c0 = st.hv_c0[j], la = st.hv_la[j];
     const int wd_type = st.hv_flags[j] & 1;
-    double obs[NFP], wgt[NFP];
+    double obs[HF], wgt[HF];
 #pragma unroll
-    for (int f = 0; f < NFP; ++f) { obs[f] = st.hv_obs[(size_t)f * st.hv_pad + j]; wgt[f] = st.hv_w[(size_t)f * st.hv_pad + j]; }
-    HS2(1);
+    for (int k = 0; k < HF; ++k) {
+        const int f = comp * HF + k;
+        obs[k] = st.hv_obs[(size_t)f * st.hv_pad + j]; wgt[k] = st.hv_w[(size_t)f * st.hv_pad + j];
+    }
     const double mod = lv.par[B9_P_MOD], av = lv.par[B9_P_ABS];
     const bool binary = q > 0.0;
+    // 1. each lane of the pair reduces ITS component to a descriptor (the long chain; the two run side by side)
     Comp d; d.kind = 0; d.r0 = lv.is_mags; d.r1 = lv.is_mags; d.t = 0.0; d.tg = 0.0;
     if (comp == 0 || binary)
         d = comp_desc<NFP>(pk, lv.ax, lv.is_mass, lv.is_mags, lv.is_n, lv.is_tip, lv.t_feh, lv.t_y, lv.par, comp ? q * m1 : m1, wd_type);
-    HS2(8);
+    // 2. the lanes swap descriptors: both now hold the primary's (c1) and the secondary's (c2) ...
+    Comp o;
+    o.kind = __shfl_xor(d.kind, 1, 64);
+    o.r0 = reinterpret_cast<const double *>(__shfl_xor((unsigned long long)reinterpret_cast<size_t>(d.r0), 1, 64));
+    o.r1 = reinterpret_cast<const double *>(__shfl_xor((unsigned long long)reinterpret_cast<size_t>(d.r1), 1, 64));
+    o.t = __shfl_xor(d.t, 1, 64); o.tg = __shfl_xor(d.tg, 1, 64);
+    Comp c1, c2;
+    c1.kind = comp ? o.kind : d.kind; c1.r0 = comp ? o.r0 : d.r0; c1.r1 = comp ? o.r1 : d.r1; c1.t = comp ? o.t : d.t; c1.tg = comp ? o.tg : d.tg;
+    c2.kind = comp ? d.kind : o.kind; c2.r0 = comp ? d.r0 : o.r0; c2.r1 = comp ? d.r1 : o.r1; c2.t = comp ? d.t : o.t; c2.tg = comp ? d.tg : o.tg;
+    // 3. ... and each takes HALF of the filters (the secondary's lane is not idle through the flux combines; a single
+    //    star's second lane, idle until now, takes half of the primary's filters)
     double chi2 = 0.0;
-#pragma unroll B9_HEAVY_UNROLL
-    for (int f = 0; f < NFP; ++f) {
-        double p = comp_mag<NFP>(d, f);
-        const double p2 = __shfl_xor(p, 1, 64);                       // the secondary's magnitude, in the primary's lane
+#pragma unroll
+    for (int k = 0; k < HF; ++k) {
+        const int f = comp * HF + k;
+        double p = comp_mag<NFP>(c1, f);
+        const double p2 = comp_mag<NFP>(c2, f);
         if (binary) p -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (p2 - p));
-        const double dd = (p + (mod + pk.abs_m1[f] * av)) - obs[f];
-        chi2 = fma(wgt[f] * dd, dd, chi2);
+        const double dd = (p + (mod + pk.abs_m1[f] * av)) - obs[k];
+        chi2 = fma(wgt[k] * dd, dd, chi2);
     }
-    HS2(9);
+    chi2 += __shfl_xor(chi2, 1, 64);                                  // (the sum of the two halves: the same bits in both lanes)
     const double ll = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
     double l = ll;
     if (NPOPS == 2) {
         const double lam = lv.par[B9_P_LAMBDA];
-        const double ll_b = __shfl_xor(ll, 2, 64);                    // population B's, in population A's lanes
-        l = logaddexp(log(lam) + ll, log1p(-lam) + ll_b);
+        const double ll_o = __shfl_xor(ll, 2, 64);                    // the other population's (every lane takes part in the shuffle)
+        const double ll_a = (sub >> 1) ? ll_o : ll, ll_b = (sub >> 1) ? ll : ll_o;
+        l = logaddexp(log(lam) + ll_a, log1p(-lam) + ll_b);
     }
     return logaddexp(la, l);
 }

@@ -1,4 +1,8 @@
-"""Walker-parallel adaptive Metropolis over the HIP log-posterior (BASELINE.json north_star:
+"""Python twin of the walker-parallel driver (the product driver is the C++ one, base_amd/host/b9sampler.cpp, bound by
+base_amd/hostlib.py; this module holds the numpy statement of the device's Metropolis step -- HostBlockRunner, draws --
+that the tests compare the GPU against, and a torch.distributed flavour of the same sampler used by the gloo tests).
+
+Walker-parallel adaptive Metropolis over the HIP log-posterior (BASELINE.json north_star:
 "partition independent walkers/chains across the GPUs of one node with an RCCL all-gather of
 log-posteriors over xGMI for the adaptive proposal step").
 
@@ -284,12 +288,23 @@ class WalkerSampler:
                     self._shaped = True
                 self.chol = new                                      # `scale` keeps multiplying it
 
-    def run(self, n_steps: int, record: Optional[List] = None) -> None:
-        """n_steps in blocks, PIPELINED: while block b executes (the runner's C call releases the GIL; a worker
+    def run(self, n_steps: int, record: Optional[List] = None, adapt: Optional[bool] = None) -> None:
+        """adapt = False freezes the proposal for this call (the main run after a burn-in, as the C++ driver and the
+        reference's staged burn-in do [RECALL]); None keeps the constructor's setting.  A run() drains the pipeline when
+        it returns, so run(a); run(b) adapts at a different point than run(a + b) and gives (equally valid) different
+        chains.
+
+        n_steps in blocks, PIPELINED: while block b executes (the runner's C call releases the GIL; a worker
         thread makes it), this thread turns block b-1's samples into rows, exchanges them (the all-gather then
         runs beside block b's kernels) and adapts the proposal.  Data dependencies are those of run_block --
         the proposal of block b+1 is adapted from the rows of blocks <= b-1 -- so the chains are the same bits."""
         self.flush()
+        if adapt is not None:
+            keep, self.adapt = self.adapt, adapt
+            try:
+                return self.run(n_steps, record)
+            finally:
+                self.adapt = keep
         if getattr(self.runner, "can_pipeline", lambda: False)() and n_steps > 0:
             return self._run_device_pipeline(n_steps, record)
         done, finished = 0, None            # finished: (samples, params_end, logpost_end, n) of the block that ran last

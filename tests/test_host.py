@@ -282,3 +282,40 @@ def test_corrupted_input_files_are_rejected_or_read_never_crash(hostlib, tmp_pat
         if rc == 0: hostlib.b9h_free_pack(h)
         else: rejected += 1; assert hostlib.b9h_last_error()
     assert rejected > 40
+
+
+@pytest.mark.gpu
+def test_mcmc_cli_marginalised_mode(hostlib, tmp_path):
+    """--marginalise: every star integrated over primary mass and mass ratio (b9_options.mode), so the catalogue's mass
+    columns are hints only -- a .phot whose mass1 column is 0 runs, and the recorded log-posterior is the oracle's
+    marginalised one.  (In given-mass mode the same file is refused with a message.)"""
+    pack_d = synth.make_pack("dsed", 8, n_feh=4, n_age=8, n_eep=60)
+    truth = synth.default_params(pack_d)
+    cl = synth.make_cluster(pack_d, 120, seed=3, truth=truth)
+    cl0 = dict(cl); cl0["mass1"] = np.zeros_like(cl["mass1"]); cl0["mass_ratio"] = np.zeros_like(cl["mass_ratio"])
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    phot = synth.write_phot(cl0, pack_d["filters"], str(tmp_path / "c.phot"))
+    y = synth.write_yaml(str(tmp_path / "base9.yaml"), phot, root, str(tmp_path / "run"), truth, ms_model="dsed", burn=20, run=10, walkers=2)
+    r = _cli("singlePopMcmc", "--config", y)
+    assert r.returncode != 0 and "mass1 > 0" in r.stderr
+    r = _cli("singlePopMcmc", "--config", y, "--marginalise", "--margIsoIncrem", "2", "--nMassRatios", "2", "--block", "10")
+    assert r.returncode == 0, r.stderr
+    assert "marginalised mode" in r.stderr
+    head = open(str(tmp_path / "run.res")).readline().split()
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
+    assert res.shape == (30 * 2, len(head))
+    cl2 = dict(cl0)
+    lo, hi = np.where(np.asarray(cl["sigma"]) > 0, cl["obs"], np.inf).min(axis=0), np.where(np.asarray(cl["sigma"]) > 0, cl["obs"], -np.inf).max(axis=0)
+    cl2["filter_prior_min"], cl2["filter_prior_max"] = lo, hi
+    pri = synth.default_priors(pack_d, truth, 1)
+    for k in (abi.P_Y, abi.P_Y2):
+        pri.var[k] = 0.0
+    row = truth.copy()
+    for name, i in {n: i for i, n in enumerate(head)}.items():
+        if name in abi.PARAM_NAMES:
+            row[abi.PARAM_NAMES.index(name)] = res[-1, i]
+    opt = abi.make_options(abi.MODE_MARGINALISED, 1, 2, 2)
+    want = oracle.Oracle(abi.make_pack(pack_d), abi.make_stars(cl2), pri, opt).logpost(row[None, :])[0]
+    # the .res holds 6 decimals of each parameter: compare at the rounded position, allowing for the posterior's slope
+    # over half a unit of the last place (|dlogPost/dlogAge| ~ 1e3-1e4 here)
+    assert abs(res[-1, -2] - want) <= 1e-2, (res[-1, -2], want)
