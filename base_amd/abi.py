@@ -17,7 +17,7 @@ B9_NPARAM = 12
 PARAM_NAMES = ["logAge", "Y", "FeH", "modulus", "absorption", "carbonicity",
                "IFMRconst", "IFMRlin", "IFMRquad", "Y2", "lambda", "reserved"]
 
-BLOCK_CONTINUE, BLOCK_ASYNC = 1, 2
+BLOCK_CONTINUE, BLOCK_ASYNC, BLOCK_ROWS_EVENT = 1, 2, 4
 STAGE_MSRG, STAGE_WD, STAGE_NSBH, STAGE_BD, STAGE_DNE = 1, 3, 4, 5, 9
 IFMR_WEIDEMANN, IFMR_WILLIAMS, IFMR_SALARIS_LIN, IFMR_SALARIS_PW, IFMR_LINEAR, IFMR_QUADRATIC = range(6)
 MODE_GIVEN_MASS, MODE_MARGINALISED = 0, 1

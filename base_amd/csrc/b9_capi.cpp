@@ -60,7 +60,7 @@ struct b9_ctx {
     size_t perstar_cap = 0;
     void *d_mcmc = nullptr;          // device state of b9_mcmc_run_block (two-launch step)
     struct McmcSlot {                // fused step: one enqueued block (device block, pinned mirror, completion event)
-        void *d = nullptr, *h = nullptr;
+        void *d = nullptr, *h = nullptr, *h_dev = nullptr;   // h_dev: the pinned mirror as the device sees it (mapped)
         size_t cap = 0, hcap = 0;
         hipEvent_t done = nullptr;
         bool in_flight = false;
@@ -770,8 +770,8 @@ static int collect_block(b9_ctx *ctx, b9_ctx::McmcSlot &sl, b9_mcmc_block *blk)
     if (sl.n_samp && sl.host_samples && blk->samples) std::memcpy(blk->samples, stage + sl.o_samp, sl.n_samp * 8);
     if (sl.n_rows && blk->rows) std::memcpy(blk->rows, stage + sl.o_rows, sl.n_rows * 8);
     if (sl.n_lps && blk->lps) std::memcpy(blk->lps, stage + sl.o_lps, sl.n_lps * 8);
-    unsigned long long n_acc;
-    std::memcpy(&n_acc, stage + sl.o_nacc, 8);
+    double n_acc = 0.0;                              // per-walker counts carried in the state rows
+    for (int w = 0; w < sl.W; ++w) n_acc += fin[(size_t)w * B9_STATE_STRIDE + B9_ST_NACC];
     blk->n_accept = (int64_t)n_acc;
     return B9_OK;
 }
@@ -814,7 +814,8 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     if (n_total * 8 > sl.hcap) {
         if (sl.h) (void)hipHostFree(sl.h);
         sl.h = nullptr; sl.hcap = 0;
-        HIPCHK(ctx, hipHostMalloc(&sl.h, n_total * 8, hipHostMallocDefault));    // pinned staging mirror
+        HIPCHK(ctx, hipHostMalloc(&sl.h, n_total * 8, hipHostMallocMapped));     // pinned staging mirror, mapped into the device
+        HIPCHK(ctx, hipHostGetDevicePointer(&sl.h_dev, sl.h, 0));
         sl.hcap = n_total * 8;
     }
     if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -848,12 +849,14 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
                 st0[(size_t)w * B9_STATE_STRIDE + B9_ST_LP] = blk->logpost[w];
                 st0[(size_t)w * B9_STATE_STRIDE + B9_ST_LPRIOR] = -INFINITY;
             }
-        HIPCHK(ctx, hipMemcpyAsync(dev, stage, up_words * 8, hipMemcpyHostToDevice, s));
-        if (cont) {      // the previous block's final state, device to device (stream-ordered behind its last launch)
+        // one launch: the upload, read by the device from the mapped mirror, and -- continuing -- the previous block's final
+        // state (stream-ordered behind its last launch) in place of the starting state
+        const double *prev_final = nullptr;
+        if (cont) {
             const b9_ctx::McmcSlot &pv = ctx->slot[ctx->last_slot];
-            const double *prev_final = static_cast<const double *>(pv.d) + (pv.final_parity ? pv.o_st1 : pv.o_st0);
-            HIPCHK(ctx, b9k_mcmc_continue(prev_final, d_cur0, d_lp0, d_state, W, s));
+            prev_final = static_cast<const double *>(pv.d) + (pv.final_parity ? pv.o_st1 : pv.o_st0);
         }
+        HIPCHK(ctx, b9k_mcmc_begin(static_cast<const double *>(sl.h_dev), dev, (int)up_words, prev_final, d_cur0, d_lp0, d_state, W, s));
     }
     StepDev sd{};
     sd.d = d; sd.n_walkers = W; sd.n_pops = n_pops;
@@ -901,11 +904,18 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     sd.set = (S + 1) & 1; sd.has_prev = 1; sd.derive_next = 0; sd.row = S - 1;
     sd.step = (unsigned long long)(blk->step0 + S);
     sd.rows = want_rows ? dev + o_rows : nullptr;
+    // a block whose chain record stays on the device needs no download: its last launch writes what the host reads (final
+    // state, accepted counts, summary rows) into the mapped mirror as well
+    const bool zero_copy = !blk->samples && !blk->lps;
+    double *const mirror = static_cast<double *>(sl.h_dev);
+    sd.host_state = zero_copy ? mirror + (((S + 1) & 1) ? o_st1 : o_st0) : nullptr;
+    sd.host_rows = (zero_copy && want_rows) ? mirror + o_rows : nullptr;
     HIPCHK(ctx, b9k_mcmc_finish(ctx->pk, sd, ctx->pr, s));
-    HIPCHK(ctx, hipEventRecord(sl.rows_ready, s));
+    const bool rows_event = want_rows && (blk->flags & B9_BLOCK_ROWS_EVENT) != 0;
+    if (rows_event) HIPCHK(ctx, hipEventRecord(sl.rows_ready, s));
     blk->d_rows = want_rows ? (void *)(dev + o_rows) : nullptr;
-    blk->rows_ready = want_rows ? (void *)sl.rows_ready : nullptr;
-    HIPCHK(ctx, hipMemcpyAsync(stage + o_nacc, dev + o_nacc, down_words * 8, hipMemcpyDeviceToHost, s));
+    blk->rows_ready = rows_event ? (void *)sl.rows_ready : nullptr;
+    if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(stage + o_nacc, dev + o_nacc, down_words * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipEventRecord(sl.done, s));
     sl.W = W; sl.final_parity = (S + 1) & 1;
     sl.o_nacc = o_nacc; sl.o_st0 = o_st0; sl.o_st1 = o_st1; sl.o_samp = o_samp; sl.o_lps = o_lps; sl.n_samp = n_samp; sl.n_lps = n_lps;

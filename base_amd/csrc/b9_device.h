@@ -124,6 +124,7 @@ struct McmcDev {
 #define B9_ST_LPRIOR 25          //   [25]     log-prior of that proposal; -inf = outside the grid or the prior's support
 #define B9_ST_SEL 26             //   [26]     0 / 1: which candidate that proposal was
 #define B9_ST_LOGU 27            //   [27]     log u of that proposal's accept test (drawn by the writer, so no other workgroup has to)
+#define B9_ST_NACC 28            //   [28]     proposals of this walker accepted so far in the block (carried from row to row: no atomic)
 
 struct StepDev {
     int d, n_walkers, n_pops;
@@ -154,6 +155,10 @@ struct StepDev {
     double *rows;                    // [W][15 + d + d*d]
     const double *row_origin;        // [d] common origin of the moments
     int n_steps;                     // steps of the block = rows of `samples` the summary covers
+    // k_mcmc_finish only, both nullable: the block's pinned host mirror mapped into the device.  The final state rows and
+    // the summary rows are ALSO written there, so a block whose chain record stays on the device needs no download copy.
+    double *host_state;              // [W][B9_STATE_STRIDE] (the mirror's rows of the final parity)
+    double *host_rows;               // [W][B9_ROW_LEN(d)]
 };
 
 // Summary row of one walker over one block (b9_mcmc_block::rows; include/base9_hip.h documents the layout).

@@ -284,6 +284,13 @@ hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &s
 #undef MS_ARGS
 }
 
+hipError_t b9k_mcmc_begin(const double *host_up, double *dev, int up_words, const double *prev_final, double *cur0, double *lp0,
+                          double *state0, int n_walkers, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_mcmc_begin, dim3(1), dim3(256), 0, stream, host_up, dev, up_words, prev_final, cur0, lp0, state0, n_walkers);
+    return hipGetLastError();
+}
+
 hipError_t b9k_mcmc_continue(const double *prev_final, double *cur0, double *lp0, double *state0, int n_walkers, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_mcmc_continue, dim3(n_walkers), dim3(64), 0, stream, prev_final, cur0, lp0, state0);

@@ -50,6 +50,9 @@ hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &s
 // resident workgroups per CU of k_mcmc_step's instantiation for this pack (occupancy query; no launch)
 hipError_t b9k_mcmc_step_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu);
 // B9_BLOCK_CONTINUE: previous block's final state rows -> this block's starting buffers
+// the block's opening: upload from the mapped host mirror (+ the previous block's final state when continuing), one launch
+hipError_t b9k_mcmc_begin(const double *host_up, double *dev, int up_words, const double *prev_final, double *cur0, double *lp0,
+                          double *state0, int n_walkers, hipStream_t stream);
 hipError_t b9k_mcmc_continue(const double *prev_final, double *cur0, double *lp0, double *state0, int n_walkers, hipStream_t stream);
 // the block's last decision only (one workgroup per walker)
 hipError_t b9k_mcmc_finish(const DevPack &pk, const StepDev &sd, const DevPriors &pr, hipStream_t stream);

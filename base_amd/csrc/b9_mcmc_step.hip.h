@@ -247,7 +247,7 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
     }
     if (s_state_out) {                                     // (k_mcmc_finish: the state after the block, for its summary row)
         if (tid < B9_NPARAM) s_state_out[tid] = ok ? prev_prop_v : cur_v;
-        if (tid == 0) s_state_out[B9_NPARAM] = lp_new;
+        if (tid == 0) { s_state_out[B9_NPARAM] = lp_new; s_state_out[B9_NPARAM + 1] = in[B9_ST_NACC] + ((sd.has_prev && ok) ? 1.0 : 0.0); }
     }
     const bool writer = (cand == 0 && pop == 0 && part == 0);
     if (writer && tid == 0 && sd.has_prev)                 // publish the outcome for workgroups that start later
@@ -261,15 +261,13 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
             const bool pv = ok ? v1 : v0;
             out[B9_ST_LPRIOR] = pv ? log_prior_cluster(pr, s_prop, n_pops) : NEG_INF;
             out[B9_ST_SEL] = ok ? 1.0 : 0.0;
+            out[B9_ST_NACC] = in[B9_ST_NACC] + ((sd.has_prev && ok) ? 1.0 : 0.0);
             {   // log u of the accept test of the proposal evaluated by THIS launch (draw index n_pairs of its step)
                 unsigned r[4];
                 philox4x32((unsigned)sd.step, (unsigned)(sd.step >> 32), (unsigned)sd.walker_ids[w], (unsigned)((d + 1) >> 1), sd.k0, sd.k1, r);
                 out[B9_ST_LOGU] = log(u01(r[0], r[1]));
             }
-            if (sd.has_prev) {
-                if (ok) atomicAdd(sd.n_acc, 1ull);
-                if (sd.lps) sd.lps[(size_t)sd.row * W + w] = lp_new;
-            }
+            if (sd.has_prev && sd.lps) sd.lps[(size_t)sd.row * W + w] = lp_new;
         }
         if (sd.has_prev && sd.samples && tid < d) sd.samples[((size_t)sd.row * W + w) * d + tid] = s_cur[fidx];
     }
@@ -327,11 +325,7 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
 #ifndef B9_STEP_NO_HEAVY     // (diagnostic builds only: what the hot + derivation roles need in registers on their own)
     if (role == 1) {
         const int w = b / heavy_parts, part = b - w * heavy_parts;
-        // the role is ONE long dependent chain per lane on a few workgroups; the hot waves it shares its SIMDs with are
-        // throughput work: let its instructions issue first
-#ifndef B9_NO_HEAVY_PRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
+        // (raising the role's wave priority -- s_setprio 3 -- was measured: no effect on its chain or on the hot waves)
         HSTAMP(0);
         B9_MARK("heavy-begin");
         const size_t rows = (size_t)W * NPOPS, c0 = (size_t)(sd.set * 2);
@@ -418,20 +412,55 @@ __device__ __forceinline__ void block_summary_row(const StepDev &sd, int w, cons
         __syncthreads();
     }
     double *row = sd.rows + (size_t)w * B9_ROW_LEN(d);
-    if (pair) row[B9_ROW_SUM + d + tid] = acc;
-    if (single) row[B9_ROW_SUM + (tid - 128)] = acc;
-    if (tid >= 192 && tid < 192 + B9_NPARAM) row[B9_ROW_POS + (tid - 192)] = s_last[tid - 192];
-    if (tid == 255) { row[B9_ROW_LP] = s_last[B9_NPARAM]; row[B9_ROW_MOVED] = (double)s_moved; row[B9_ROW_N] = (double)S; }
+    double *hrow = sd.host_rows ? sd.host_rows + (size_t)w * B9_ROW_LEN(d) : nullptr;        // the mapped host mirror
+    if (pair) { row[B9_ROW_SUM + d + tid] = acc; if (hrow) hrow[B9_ROW_SUM + d + tid] = acc; }
+    if (single) { row[B9_ROW_SUM + (tid - 128)] = acc; if (hrow) hrow[B9_ROW_SUM + (tid - 128)] = acc; }
+    if (tid >= 192 && tid < 192 + B9_NPARAM) {
+        row[B9_ROW_POS + (tid - 192)] = s_last[tid - 192];
+        if (hrow) hrow[B9_ROW_POS + (tid - 192)] = s_last[tid - 192];
+    }
+    if (tid == 255) {
+        row[B9_ROW_LP] = s_last[B9_NPARAM]; row[B9_ROW_MOVED] = (double)s_moved; row[B9_ROW_N] = (double)S;
+        if (hrow) { hrow[B9_ROW_LP] = s_last[B9_NPARAM]; hrow[B9_ROW_MOVED] = (double)s_moved; hrow[B9_ROW_N] = (double)S; }
+    }
 }
 
 // the block's last decision: one workgroup per walker, writer role only (+ the block's summary rows)
 __global__ __launch_bounds__(256) void k_mcmc_finish(DevPack pk, StepDev sd, DevPriors pr)
 {
-    __shared__ double s_last[B9_NPARAM + 1];
-    step_derive(pk, sd, pr, blockIdx.x, 0, 0, 0, 1, sd.rows ? s_last : nullptr);
+    __shared__ double s_last[B9_NPARAM + 2];
+    step_derive(pk, sd, pr, blockIdx.x, 0, 0, 0, 1, (sd.rows || sd.host_state) ? s_last : nullptr);
     if (sd.rows) {                                           // (uniform over the grid)
         __syncthreads();
         block_summary_row(sd, blockIdx.x, s_last);
+    }
+    if (sd.host_state) {
+        // what the host reads of the walker's final state row: position, log-posterior, accepted count (from LDS)
+        if (!sd.rows) __syncthreads();
+        double *h = sd.host_state + (size_t)blockIdx.x * B9_STATE_STRIDE;
+        if (threadIdx.x < B9_NPARAM) h[B9_ST_CUR + threadIdx.x] = s_last[threadIdx.x];
+        if (threadIdx.x == B9_NPARAM) { h[B9_ST_LP] = s_last[B9_NPARAM]; h[B9_ST_NACC] = s_last[B9_NPARAM + 1]; }
+    }
+}
+
+// The block's opening: ONE small launch copies the block's upload (starting state, proposal factor, moment origin,
+// RNG streams, cleared counters) from the pinned host mirror, mapped into the device, into the device block -- and, for a
+// block that continues its predecessor (B9_BLOCK_CONTINUE), takes the starting state from that block's final state
+// rows instead.  It replaces a host-to-device copy command and a separate continue kernel (two dispatch boundaries and
+// ~10 us of a short block's fixed cost).
+__global__ __launch_bounds__(256) void k_mcmc_begin(const double *__restrict__ host_up, double *__restrict__ dev, int up_words,
+                                                    const double *__restrict__ prev_final, double *__restrict__ cur0,
+                                                    double *__restrict__ lp0, double *__restrict__ state0, int n_walkers)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < up_words; i += 256) dev[i] = host_up[i];
+    if (!prev_final) return;
+    __syncthreads();
+    for (int w = 0; w < n_walkers; ++w) {
+        const double *src = prev_final + (size_t)w * B9_STATE_STRIDE;
+        double *dst = state0 + (size_t)w * B9_STATE_STRIDE;
+        if (tid < B9_NPARAM) { const double v = src[B9_ST_CUR + tid]; cur0[(size_t)w * B9_NPARAM + tid] = v; dst[B9_ST_CUR + tid] = v; }
+        if (tid == B9_NPARAM) { const double lp = src[B9_ST_LP]; lp0[w] = lp; dst[B9_ST_LP] = lp; dst[B9_ST_LPRIOR] = NEG_INF; }
     }
 }
 

@@ -245,8 +245,11 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
 //     (FeH, Y) corners -- is ONE flat list; each thread requests its elements at entry, all loads independent: one memory
 //     round trip (it used to be 6 + 4 NPOPS dependent ones).
 // A star occupies G = 2 NPOPS neighbouring lanes: (population, component) -- star_value_lanes.
+// staged elements a thread carries in registers: 256 doubles per unit; longer lists finish in a loop, a second round trip.
+// One population stages ~1900 doubles (8 units; more units cost the short lists their predicated loads' address
+// selects: 16 units measured +0.5 us on 1-population shapes), two populations ~3700 (16 units: -1 us).
 #ifndef B9_HEAVY_STAGE_E
-#define B9_HEAVY_STAGE_E 8          // staged elements a thread carries in registers (8 x 256 doubles; longer lists finish in a loop)
+#define B9_HEAVY_STAGE_E(NPOPS) ((NPOPS) == 2 ? 16 : 8)
 #endif
 template <int NFP, int NPOPS, int NC, class SelectFn>
 __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *const (&hdr)[NC],
@@ -262,7 +265,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     // corner columns follow in pass 2); per (candidate, population) the derived isochrone's mass column (a heavy
     // primary's companion, or a star that is heavy under one candidate only, is on the MS/RGB branch: its bracket search
     // then runs in LDS, as the hot role's does).
-    constexpr int NC0 = 7, NM0 = NC0 + 1, NSEG = NM0 + NPOPS * NC, E = B9_HEAVY_STAGE_E;
+    constexpr int NC0 = 7, NM0 = NC0 + 1, NSEG = NM0 + NPOPS * NC, E = B9_HEAVY_STAGE_E(NPOPS);
     const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1, n_tips = pk.n_feh * pk.n_y * na;
     const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
     const bool stage_wc_age = has_wd && (pk.wc_uniform || pk.n_wc_points <= B9_WC_AGE_LDS_MAX);       // (as heavy_lds_doubles sized the LDS)

@@ -109,6 +109,7 @@ class RcclExchange final : public Exchange {
     int world() const override { return world_; }
     const char *name() const override { return "RCCL all-gather (ncclAllGather over xGMI, device buffers, own high-priority stream)"; }
 
+    bool reads_device_rows() const override { return true; }
     bool start_device(int slot, const double *d_rows, void *ready_event, size_t count) override
     {
         Slot &s = slot_[slot & 1];

@@ -22,6 +22,7 @@ class Exchange {
     // `ready_event` (a hipEvent_t) and reads them in place; nothing waits on the host.  false = not supported by this
     // exchange (the caller then passes host rows to start_host).
     virtual bool start_device(int slot, const double *d_rows, void *ready_event, size_t count) { (void)slot; (void)d_rows; (void)ready_event; (void)count; return false; }
+    virtual bool reads_device_rows() const { return false; }      // true: start_device works (the runner then records the rows' event)
     // Rows on the host.
     virtual void start_host(int slot, const double *rows, size_t count) = 0;
     // Blocks until the exchange of `slot` is complete; returns world() * count doubles in rank order (valid until the

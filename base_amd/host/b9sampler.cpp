@@ -73,7 +73,7 @@ class DeviceRunner final : public BlockRunner {
         b.samples = host_chain ? s.samples.data() : nullptr;
         b.lps = host_chain ? s.lps.data() : nullptr;
         if (fused_) {
-            b.flags = B9_BLOCK_ASYNC | (first_ ? 0 : B9_BLOCK_CONTINUE);
+            b.flags = B9_BLOCK_ASYNC | (first_ ? 0 : B9_BLOCK_CONTINUE) | (job.want_device_rows ? B9_BLOCK_ROWS_EVENT : 0);
             b.row_origin = s.origin.data();
             b.rows = s.rows.data();
         }
@@ -83,7 +83,7 @@ class DeviceRunner final : public BlockRunner {
         if (!fused_) { params_ = s.params; logpost_ = s.logpost; }     // synchronous: the state is back already
         first_ = false;
         Submitted r;
-        if (fused_) { r.d_rows = static_cast<const double *>(b.d_rows); r.rows_ready = b.rows_ready; }
+        if (fused_ && job.want_device_rows) { r.d_rows = static_cast<const double *>(b.d_rows); r.rows_ready = b.rows_ready; }
         return r;
     }
 
@@ -329,7 +329,7 @@ void WalkerSampler::run(long n_steps, bool adapt, const RecordFn &record)
         const double t_a = trace ? now() : 0.0;
         struct Tr { bool on; double t; size_t b; decltype(now) &clk; ~Tr() { if (on) std::fprintf(stderr, "b9 sampler: block %zu enqueue %.1f us\n", b, clk() - t); } } tr{trace, t_a, b, now};
         for (size_t i = 0; i < chol_scaled.size(); ++i) chol_scaled[i] = scale_ * chol_[i];
-        BlockRunner::Job job{step0[b], sizes[b], chol_scaled.data(), origin_.data(), (bool)record};
+        BlockRunner::Job job{step0[b], sizes[b], chol_scaled.data(), origin_.data(), (bool)record, ex_->reads_device_rows()};
         const BlockRunner::Submitted sub = runner_->submit((int)(b & 1), job);
         // rows that will be in HBM: the collective is enqueued NOW, stream-ordered behind the block, and runs beside
         // the next block's kernels without the host

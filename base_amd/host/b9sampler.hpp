@@ -60,6 +60,7 @@ class BlockRunner {
         const double *chol;               // [d][d] scaled proposal factor
         const double *origin;             // [d] origin of the summary moments
         bool want_samples;                // the caller will read Done::samples / lps
+        bool want_device_rows;            // an exchange will read the rows in HBM (Submitted::d_rows / rows_ready)
     };
     struct Submitted { const double *d_rows = nullptr; void *rows_ready = nullptr; };   // non-null: the rows will be in HBM
     struct Done {

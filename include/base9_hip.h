@@ -225,8 +225,8 @@ typedef struct b9_mcmc_block {
      *     [15 .. 15+d) sum_s x_s    [15+d .. 15+d+d*d) sum_s x_s x_s^T (row-major),   x_s = sample_s - row_origin,
      * sums over the steps in ascending order, plain multiply and add.  These rows are what a walker-parallel driver
      * exchanges between GPUs for the adaptive proposal: d_rows is their DEVICE address (valid until the second-next
-     * block of this context is enqueued) and rows_ready a hipEvent_t recorded on the context's stream once they are
-     * written, so a collective on another stream can read them from HBM without a host round trip.  `rows` (host,
+     * block of this context is enqueued) and rows_ready (flag B9_BLOCK_ROWS_EVENT) a hipEvent_t recorded on the context's
+     * stream once they are written, so a collective on another stream can read them from HBM without a host round trip.  `rows` (host,
      * nullable) receives a copy when the block is collected. */
     const double *row_origin;    /* [n_free] or NULL                                          */
     double *rows;                /* out, nullable: [n_walkers][B9_ROW_DOUBLES(n_free)]         */
@@ -247,6 +247,7 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk);
  */
 #define B9_BLOCK_CONTINUE 1
 #define B9_BLOCK_ASYNC 2
+#define B9_BLOCK_ROWS_EVENT 4   /* with row_origin: also record rows_ready (a multi-GPU exchange waits on it); off, one event less in the stream */
 int b9_mcmc_wait(b9_ctx *ctx, b9_mcmc_block *blk);
 
 /*
