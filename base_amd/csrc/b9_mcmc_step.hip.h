@@ -24,32 +24,67 @@ __device__ __forceinline__ const double *step_state_in(const StepDev &sd, int w)
 #ifndef B9_SHORTCUT
 #define B9_SHORTCUT true
 #endif
+#define B9_DECIDE_K 6
+struct DecideLoads {           // everything one wave's decision reads (registers)
+    double lp_cur, lpr, lu, selp, h0, h1, v[B9_DECIDE_K];
+    unsigned long long flag;
+};
+
+// The loads: EVERYTHING the decision may need is requested here, before any of it is looked at, with clamped
+// indices instead of branches: the state words, the writer's flag, the first 64 K hot partials and the
+// heavy-star partials of BOTH candidate slots (which one counts is a state word).  One memory round trip;
+// the launch's first few microseconds are a chain of such round trips and nothing else.
 template <bool SHORTCUT>
-__device__ __forceinline__ bool step_decide(const StepDev &sd, int w, double &lp_new)
+__device__ __forceinline__ void decide_issue(const StepDev &sd, int w, DecideLoads &dl)
 {
     const int lane = threadIdx.x & 63;
     const double *in = step_state_in(sd, w);
-    const double lp_cur = in[B9_ST_LP];
-    if (!sd.has_prev) { lp_new = lp_cur; return false; }
-    if (SHORTCUT) {
-        const unsigned long long f = __hip_atomic_load(sd.decided + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((f >> 1) == sd.step) { lp_new = 0.0; return (f & 1ull) != 0; }      // wave-uniform: one word per walker
-    }
     const double *part = sd.partial + (size_t)w * sd.partial_stride + (size_t)(sd.set ^ 1) * (sd.partial_stride / 2);
-    // the hot waves' partials, then the heavy-star partials of the candidate that step evaluated (the heavy role wrote one
-    // set per candidate without waiting for its decision)
-    const int n_hot = sd.n_partial - sd.heavy_parts, skip = in[B9_ST_SEL] != 0.0 ? sd.heavy_parts : 0;
+    const int n_hot = sd.n_partial - sd.heavy_parts;
+    dl.lp_cur = in[B9_ST_LP]; dl.lpr = in[B9_ST_LPRIOR]; dl.lu = in[B9_ST_LOGU]; dl.selp = in[B9_ST_SEL];
+    dl.flag = SHORTCUT ? __hip_atomic_load(sd.decided + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+    for (int k = 0; k < B9_DECIDE_K; ++k) {
+        const int j = lane + 64 * k;
+        dl.v[k] = part[j < n_hot ? j : n_hot - 1];
+    }
+    const int hl = lane < sd.heavy_parts ? lane : sd.heavy_parts - 1;
+    dl.h0 = part[n_hot + hl]; dl.h1 = part[n_hot + sd.heavy_parts + hl];
+}
+
+template <bool SHORTCUT>
+__device__ __forceinline__ bool decide_finish(const StepDev &sd, int w, const DecideLoads &dl, double &lp_new)
+{
+    const int lane = threadIdx.x & 63;
+    if (!sd.has_prev) { lp_new = dl.lp_cur; return false; }
+    if (SHORTCUT && (dl.flag >> 1) == sd.step) { lp_new = 0.0; return (dl.flag & 1ull) != 0; }      // wave-uniform: one word per walker
+    const int n_hot = sd.n_partial - sd.heavy_parts;
+    // lane l: the hot waves' partials l, l + 64, ... in order, then heavy-star partial l of the candidate
+    // that step evaluated; then the shuffle tree.  The same bits in every workgroup.
     double acc = 0.0;
-    for (int j = lane; j < sd.n_partial; j += 64) acc += part[j < n_hot ? j : j + skip];
-    const double lpr = in[B9_ST_LPRIOR], lu = in[B9_ST_LOGU];
+#pragma unroll
+    for (int k = 0; k < B9_DECIDE_K; ++k) acc = (lane + 64 * k < n_hot) ? acc + dl.v[k] : acc;
+    if (n_hot > 64 * B9_DECIDE_K) {
+        const double *part = sd.partial + (size_t)w * sd.partial_stride + (size_t)(sd.set ^ 1) * (sd.partial_stride / 2);
+        for (int j = lane + 64 * B9_DECIDE_K; j < n_hot; j += 64) acc += part[j];
+    }
+    acc = (lane < sd.heavy_parts) ? acc + (dl.selp != 0.0 ? dl.h1 : dl.h0) : acc;          // (heavy_parts <= 64)
     STAMP(9);
     const double t = __shfl(wave_sum(acc), 0, 64);
     STAMP(10);
     STAMP(11);
-    const double lp_prop = (lpr != NEG_INF) ? lpr + t : NEG_INF;       // prior + sum, as k_finalize forms it
-    const bool ok = isfinite(lp_prop) && (lu < lp_prop - lp_cur);
-    lp_new = ok ? lp_prop : lp_cur;
+    const double lp_prop = (dl.lpr != NEG_INF) ? dl.lpr + t : NEG_INF;       // prior + sum, as k_finalize forms it
+    const bool ok = isfinite(lp_prop) && (dl.lu < lp_prop - dl.lp_cur);
+    lp_new = ok ? lp_prop : dl.lp_cur;
     return ok;
+}
+
+template <bool SHORTCUT>
+__device__ __forceinline__ bool step_decide(const StepDev &sd, int w, double &lp_new)
+{
+    DecideLoads dl;
+    decide_issue<SHORTCUT>(sd, w, dl);
+    return decide_finish<SHORTCUT>(sd, w, dl, lp_new);
 }
 
 // Asynchronous global -> LDS staging of one wave's 64 stars of a tile: observed magnitudes, weights, c0
@@ -101,6 +136,12 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     if (strided) tiles_per_block = -tiles_per_block;
     const int tile0 = strided ? group : group * tiles_per_block, tile_step = strided ? n_groups : 1;
     STAMP(0);
+    // The decision is taken by the workgroup's first wave alone and travels through LDS behind the barrier the mass
+    // columns need anyway: a quarter of the partial-sum traffic at the launch's start.  Its loads leave first.
+    __shared__ int s_sel;
+    const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    DecideLoads dl = {};
+    if (first_wave) decide_issue<B9_SHORTCUT>(sd, w, dl);
     int i = tile0 * 256 + tid;
     int il = i < st.n_pad ? i : st.n_pad - 1;
     double m1 = st.mass1[il], q = st.q[il], ea = st.ea[il];
@@ -121,12 +162,9 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
         const int c = f / half, j = f - c * half;
         return reinterpret_cast<const double2 *>(sd.cand_iso + (cb0 + (size_t)(c / NPOPS) * rows + (c % NPOPS)) * sd.iso_stride) + j;
     };
-    double2 fr[FR];
-#pragma unroll
-    for (int k = 0; k < FR; ++k) {
-        const int f = tid + k * 256;
-        fr[k] = f < total2 ? *src2(f) : double2{0.0, 0.0};
-    }
+    static_assert(FR == 4, "the four loads and stores are written out (a loop over an array of them ended in scratch)");
+    auto clamp2 = [&](int f) { return f < total2 ? f : total2 - 1; };           // (clamped, not branched: the loads leave back to back)
+    const double2 fr0 = *src2(clamp2(tid)), fr1 = *src2(clamp2(tid + 256)), fr2 = *src2(clamp2(tid + 512)), fr3 = *src2(clamp2(tid + 768));
     IsoHdr h[2][NPOPS];
     double pmod[2], pav[2], plam[2];
 #pragma unroll
@@ -136,17 +174,20 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
         const double *par = sd.cand_par + ((size_t)(sd.set * 2 + cand) * W + w) * B9_NPARAM;
         pmod[cand] = par[B9_P_MOD]; pav[cand] = par[B9_P_ABS]; plam[cand] = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
     }
-    double lp_new;
     STAMP(1);
-    const int sel = step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0;
-    STAMP(2);
-#pragma unroll
-    for (int k = 0; k < FR; ++k) {
-        const int f = tid + k * 256;
-        if (f < total2) lds2[f] = fr[k];
-    }
+    if (tid < total2) lds2[tid] = fr0;
+    if (tid + 256 < total2) lds2[tid + 256] = fr1;
+    if (tid + 512 < total2) lds2[tid + 512] = fr2;
+    if (tid + 768 < total2) lds2[tid + 768] = fr3;
     for (int f = tid + FR * 256; f < total2; f += 256) lds2[f] = *src2(f);     // very long isochrones only
-    __syncthreads();                                     // the LDS mass columns
+    if (first_wave) {
+        double lp_new;
+        const int sel0 = decide_finish<B9_SHORTCUT>(sd, w, dl, lp_new) ? 1 : 0;
+        if (tid == 0) s_sel = sel0;
+    }
+    STAMP(2);
+    __syncthreads();                                     // the LDS mass columns, the decision
+    const int sel = s_sel;
     STAMP(3);
     IsoView<NFP> iso[NPOPS];
     bool valid = true;
@@ -210,6 +251,10 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
 {
     const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers, n_pops = sd.n_pops;
     __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_prop[B9_NPARAM];
+    // (only the first wave's threads use the decision; its loads leave first)
+    const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    DecideLoads dl = {};
+    if (first_wave) decide_issue<false>(sd, w, dl);
     const AxisRegs axr = preload_axis(pk);                 // first round trip, needs no parameter
     // everything the role reads before the isochrone tables is requested now, in one round trip
     const double *in = step_state_in(sd, w);
@@ -239,8 +284,9 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
             s_z[2 * j + 1] = rad * sin(ang);
         }
     }
-    double lp_new;
-    const bool ok = step_decide<false>(sd, w, lp_new);
+    double lp_new = 0.0;
+    bool ok = false;
+    if (first_wave) ok = decide_finish<false>(sd, w, dl, lp_new);
     if (tid < B9_NPARAM) {
         s_cur[tid] = ok ? prev_prop_v : cur_v;             // state after step t-1
         s_prop[tid] = ok ? pc1 : pc0;                      // the proposal THIS launch's star workgroups evaluate
@@ -334,7 +380,20 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
         const double *const pr2[2] = {sd.cand_par + c0 * W * B9_NPARAM, sd.cand_par + (c0 + 1) * W * B9_NPARAM};
         double *const base = sd.partial + (size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) + (size_t)n_groups * 4;
         double *const out[2] = {base + part, base + heavy_parts + part};
-        auto decide = [&] { double lp_new; return step_decide<B9_SHORTCUT>(sd, w, lp_new) ? 1 : 0; };
+        // the first wave decides (its loads leave before everything else of the role); the others get it through LDS
+        const bool first_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+        DecideLoads dl = {};
+        if (first_wave) decide_issue<B9_SHORTCUT>(sd, w, dl);
+        auto decide = [&] {
+            __shared__ int s_hsel;
+            if (first_wave) {
+                double lp_new;
+                const int s0 = decide_finish<B9_SHORTCUT>(sd, w, dl, lp_new) ? 1 : 0;
+                if (threadIdx.x == 0) s_hsel = s0;
+            }
+            __syncthreads();
+            return s_hsel;
+        };
         heavy_stars<NFP, NPOPS, 2>(pk, st, hd, is, sd.iso_stride, sd.mass_cap, pr2, decide, w, part, heavy_parts, out, nullptr, smem);
         B9_MARK("heavy-end");
         return role;
