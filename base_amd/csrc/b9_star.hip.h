@@ -47,51 +47,83 @@ __device__ __forceinline__ double fdiv(double num, double den)
 // kernel's VALU instructions but 3.3 of its 20.5 us).
 // The index alone, for an ascending (DESC = false: largest i <= n-2 with ax[i] <= x) or descending (DESC = true:
 // largest i <= n-2 with ax[i] >= x) axis; equal to the oracle's binary searches, which return the same unique index.
+// Probes of a bracket search.  The N probes of a round are independent loads whose answers are needed together; left
+// to itself the compiler (a) turns `j < len && p[j] <= x` into seven branches with a load and a wait each, and (b)
+// under register pressure schedules unconditional probes one at a time through one register pair -- seven dependent
+// LDS round trips where one was meant (measured: a WD star's chain of ~10 searches took 7 us of its 9.7).  So: the
+// loads are unconditional (clamped index, never past the axis), written into an array before any is looked at, and
+// fenced so the scheduler keeps them together (B9_PROBE_FENCE).
+#ifndef B9_PROBE_FENCE
+#define B9_PROBE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <bool DESC>
+__device__ __forceinline__ int count7(const double (&v)[7], double x)
+{
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) c += (DESC ? v[j] >= x : v[j] <= x) ? 1 : 0;
+    return c;
+}
+// values at p[step], p[2 step], ... p[7 step]
+__device__ __forceinline__ void load7(const double *p, int step, double (&v)[7])
+{
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v[j] = p[(j + 1) * step];
+}
+// values at p[1] ... p[7], those at or past `len` replaced by p[0]'s (never reads past the axis)
+__device__ __forceinline__ void load7_tail(const double *p, int len, double (&v)[7])
+{
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v[j] = p[(j + 1) < len ? (j + 1) : 0];
+}
+template <bool DESC>
+__device__ __forceinline__ int count7_tail(const double (&v)[7], int len, double x)
+{
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) c += (int)((j + 1) < len) & (int)(DESC ? v[j] >= x : v[j] <= x);
+    return c;
+}
+
 template <bool DESC>
 __device__ __forceinline__ int bracket8(const double *ax, int n, double x)
 {
     int lo = 0, len = n - 1;                 // the answer lies in [lo, lo + len)
     if (n < 2) return 0;
+    double v[7];
     while (len >= 8) {                       // 7 probes at lo + j*step, all inside the range (7*step < len)
         const int step = len >> 3;
-        const double *p = ax + lo;
-        int c = 0;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) c += (DESC ? p[j * step] >= x : p[j * step] <= x) ? 1 : 0;
+        B9_PROBE_FENCE();
+        load7(ax + lo, step, v);
+        B9_PROBE_FENCE();
+        const int c = count7<DESC>(v, x);
         lo += c * step;
         len = (c == 7) ? len - 7 * step : step;
     }
-    {                                        // fewer than 8 candidates left: probe them all at once
-        const double *p = ax + lo;
-        int c = 0;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            const double v = j < len ? p[j] : p[0];             // never reads past the axis
-            c += (j < len && (DESC ? v >= x : v <= x)) ? 1 : 0;
-        }
-        lo += c;
-    }
-    return lo;
+    B9_PROBE_FENCE();                        // fewer than 8 candidates left: probe them all at once
+    load7_tail(ax + lo, len, v);
+    B9_PROBE_FENCE();
+    return lo + count7_tail<DESC>(v, len, x);
 }
 
 __device__ __forceinline__ void find_bracket(const double *mass, int n, double m, int &lo_out, double &t_out)
 {
     int lo = 0, len = n - 1;                 // the answer lies in [lo, lo + len)
+    double v[7];
     while (len >= 8) {                       // 7 probes at lo + j*step, all inside the range (7*step < len)
         const int step = len >> 3;
-        const double *p = mass + lo;
-        int c = 0;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) c += (p[j * step] <= m) ? 1 : 0;
+        B9_PROBE_FENCE();
+        load7(mass + lo, step, v);
+        B9_PROBE_FENCE();
+        const int c = count7<false>(v, m);
         lo += c * step;
         len = (c == 7) ? len - 7 * step : step;
     }
     {                                        // fewer than 8 candidates left: probe them all at once
-        const double *p = mass + lo;
-        int c = 0;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) c += (j < len && p[j] <= m) ? 1 : 0;     // reads stay inside the column: lo + 7 <= n + 6 < capacity
-        lo += c;
+        B9_PROBE_FENCE();
+        load7(mass + lo, 1, v);              // reads stay inside the column: lo + 7 <= n + 6 < capacity
+        B9_PROBE_FENCE();
+        lo += count7_tail<false>(v, len, m);
     }
     const double a = mass[lo], d = mass[lo + 1] - a;
 #ifdef B9_EXACT_DIV
@@ -187,32 +219,32 @@ __device__ __forceinline__ void bracket8_lockstep(const double *const (&ax)[N], 
     bool any = false;
 #pragma unroll
     for (int k = 0; k < N; ++k) { lo[k] = 0; len[k] = n[k] - 1; any = any || len[k] >= 8; }
+    double v[N][7];
     while (any) {
         any = false;
+        int step[N];
+        B9_PROBE_FENCE();
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            step[k] = len[k] >= 8 ? len[k] >> 3 : 0;             // an axis that is done probes its own lo (ignored)
+            load7(ax[k] + lo[k], step[k], v[k]);
+        }
+        B9_PROBE_FENCE();
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const bool on = len[k] >= 8;
-            const int step = on ? len[k] >> 3 : 0;               // an axis that is done probes its own lo (ignored)
-            const double *p = ax[k] + lo[k];
-            int c = 0;
-#pragma unroll
-            for (int j = 1; j < 8; ++j) c += (p[j * step] <= x) ? 1 : 0;
-            lo[k] += on ? c * step : 0;
-            len[k] = on ? ((c == 7) ? len[k] - 7 * step : step) : len[k];
+            const int c = count7<false>(v[k], x);
+            lo[k] += on ? c * step[k] : 0;
+            len[k] = on ? ((c == 7) ? len[k] - 7 * step[k] : step[k]) : len[k];
             any = any || len[k] >= 8;
         }
     }
+    B9_PROBE_FENCE();
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const double *p = ax[k] + lo[k];
-        int c = 0;
+    for (int k = 0; k < N; ++k) load7_tail(ax[k] + lo[k], len[k], v[k]);
+    B9_PROBE_FENCE();
 #pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            const double v = j < len[k] ? p[j] : p[0];           // never reads past the axis
-            c += (j < len[k] && v <= x) ? 1 : 0;
-        }
-        lo[k] += c;
-    }
+    for (int k = 0; k < N; ++k) lo[k] += count7_tail<false>(v[k], len[k], x);
 }
 
 // WD cooling model: (log Teff, log radius) of a WD of mass wd_mass at log cooling age log_cool.
@@ -299,36 +331,43 @@ __device__ __forceinline__ void prec_corners(const DevPack &pk, const double *co
         lo[c] = 0; len[c] = (heavy[c] || light[c]) ? 0 : na - 1;
         any = any || len[c] >= 8;
     }
+    double v[NC][7];
     while (any) {
         any = false;
+        int step[NC];
+        B9_PROBE_FENCE();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            step[c] = len[c] >= 8 ? len[c] >> 3 : 0;
+            load7(tips[c] + lo[c], step[c], v[c]);
+        }
+        B9_PROBE_FENCE();
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool on = len[c] >= 8;
-            const int step = on ? len[c] >> 3 : 0;
-            const double *p = tips[c] + lo[c];
-            int k = 0;
-#pragma unroll
-            for (int j = 1; j < 8; ++j) k += (p[j * step] >= m) ? 1 : 0;
-            lo[c] += on ? k * step : 0;
-            len[c] = on ? ((k == 7) ? len[c] - 7 * step : step) : len[c];
+            const int k = count7<true>(v[c], m);
+            lo[c] += on ? k * step[c] : 0;
+            len[c] = on ? ((k == 7) ? len[c] - 7 * step[c] : step[c]) : len[c];
             any = any || len[c] >= 8;
         }
     }
+    B9_PROBE_FENCE();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) load7_tail(tips[c] + lo[c], len[c], v[c]);
+    B9_PROBE_FENCE();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) lo[c] += count7_tail<true>(v[c], len[c], m);
+    double ta[NC], tb[NC], la[NC], lb[NC];
+    B9_PROBE_FENCE();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { ta[c] = tips[c][lo[c]]; tb[c] = tips[c][lo[c] + 1]; la[c] = log_age[lo[c]]; lb[c] = log_age[lo[c] + 1]; }
+    B9_PROBE_FENCE();
+    const double la_last = log_age[na - 1];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const double *p = tips[c] + lo[c];
-        int k = 0;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            const double v = j < len[c] ? p[j] : p[0];
-            k += (j < len[c] && v >= m) ? 1 : 0;
-        }
-        lo[c] += k;
-        const double a = tips[c][lo[c]], b = tips[c][lo[c] + 1];
-        const double t = (b != a) ? fdiv(m - a, b - a) : 0.0;
-        double v = lerp(log_age[lo[c]], log_age[lo[c] + 1], t);
-        v = light[c] ? log_age[na - 1] : v;
-        out[c] = v;
+        const double t = (tb[c] != ta[c]) ? fdiv(m - ta[c], tb[c] - ta[c]) : 0.0;
+        const double val = lerp(la[c], lb[c], t);
+        out[c] = light[c] ? la_last : val;
     }
     // heavier than a column's youngest tip: extrapolated (rare; the logarithm is only paid when some lane needs it)
 #pragma unroll
@@ -531,15 +570,29 @@ struct LaneView {
 // half of them), and the populations swap log-likelihoods.  Every magnitude is formed by star_value's operations; the
 // chi^2 is the sum of two half-sums instead of one chain over the filters (a 1e-16 relative difference).  All lanes of a
 // group must call (full EXEC); the result is valid in every lane of the group.
+// What the head of a heavy star's chain needs (heavy-order arrays, DevStars::hv_*): nothing here depends on the
+// candidate, so the caller requests a chunk's while the previous chunk -- or the decision -- is still under way.  (The
+// observations are used at the chain's END: star_value_lanes requests them itself and they arrive long before.)
+struct HeavyStar {
+    double m1, q, c0, la;
+    int flags;
+};
+
+__device__ __forceinline__ HeavyStar load_heavy_star(const DevStars &st, int j /* index in the descending-mass list */)
+{
+    HeavyStar h;
+    h.m1 = st.heavy_mass[j]; h.q = st.hv_q[j]; h.c0 = st.hv_c0[j]; h.la = st.hv_la[j]; h.flags = st.hv_flags[j];
+    return h;
+}
+
 template <int NFP, int NPOPS>
 __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const LaneView<NFP> &lv, const DevStars &st,
-                                                   int j /* index in the descending-mass list */, int sub, double m1)
+                                                   int j /* index in the descending-mass list */, const HeavyStar &hs, int sub)
 {
     const int comp = sub & 1;
     constexpr int HF = NFP / 2;                                       // filters per lane of a (population) pair
-    // everything the star needs from memory is requested here, in one round trip (heavy-order arrays: DevStars::hv_*)
-    const double q = st.hv_q[j], c0 = st.hv_c0[j], la = st.hv_la[j];
-    const int wd_type = st.hv_flags[j] & 1;
+    const double m1 = hs.m1, q = hs.q, c0 = hs.c0, la = hs.la;
+    const int wd_type = hs.flags & 1;
     double obs[HF], wgt[HF];
 #pragma unroll
     for (int k = 0; k < HF; ++k) {

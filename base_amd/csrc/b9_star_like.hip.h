@@ -262,10 +262,10 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     double *s_axes = smem + 8;
     // ---- the staged list, pass 1: everything whose address needs no isochrone header -- requested at entry, in the same
     // memory round trip as the headers.  Segments: NC0 common axes; the whole AGB-tip table when it is small (else the
-    // corner columns follow in pass 2); per (candidate, population) the derived isochrone's mass column (a heavy
+    // corner columns follow in pass 2); each candidate's parameter row; per (candidate, population) the derived isochrone's mass column (a heavy
     // primary's companion, or a star that is heavy under one candidate only, is on the MS/RGB branch: its bracket search
     // then runs in LDS, as the hot role's does).
-    constexpr int NC0 = 7, NM0 = NC0 + 1, NSEG = NM0 + NPOPS * NC, E = B9_HEAVY_STAGE_E(NPOPS);
+    constexpr int NC0 = 7, NM0 = NC0 + 1, NP0 = NM0 + NPOPS * NC, NSEG = NP0 + NC, E = B9_HEAVY_STAGE_E(NPOPS);
     const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1, n_tips = pk.n_feh * pk.n_y * na;
     const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
     const bool stage_wc_age = has_wd && (pk.wc_uniform || pk.n_wc_points <= B9_WC_AGE_LDS_MAX);       // (as heavy_lds_doubles sized the LDS)
@@ -290,6 +290,10 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
                 seg_src[k] = iso_data[c] + (size_t)(w * NPOPS + kp) * iso_stride;
                 seg_off[k + 1] = seg_off[k] + mass_cap;
             }
+        // ... and each candidate's parameter row: the chain reads a parameter here and there, behind branches the
+        // compiler cannot lift a global load over -- each was its own memory round trip on the chain
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { seg_src[NP0 + c] = params[c] + (size_t)w * B9_NPARAM; seg_off[NP0 + c + 1] = seg_off[NP0 + c] + B9_NPARAM; }
     }
     const int n_stage = seg_off[NSEG], tip_lo = seg_off[NC0], tip_hi = seg_off[NM0];
     auto stage_src = [&](int e) {
@@ -303,6 +307,13 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     double sv[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) { const int e = tid + k * 256; sv[k] = in_pass1(e) ? *stage_src(e) : 0.0; }
+    // the first chunk's stars (which chunk is a matter of part / wave / lane alone), also requested now: chunks of PER
+    // stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over the waves second
+    constexpr int G = 2 * NPOPS, PER = 64 / G, WPC = 4;
+    const int sub2 = lane % G;
+    int c = part + parts * wave;
+    int j = c * PER + lane / G, jj = j < st.n ? j : st.n - 1;
+    HeavyStar cur = load_heavy_star(st, jj);
     // (both candidates' headers are requested BEFORE the selection is known -- one round trip fewer on the chain; a
     //  candidate that does not exist yet, in the first launch of a block, holds anything: its fields are only used once
     //  selected, and it never is)
@@ -347,8 +358,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     HSTAMP(3);
     // this lane's (candidate, population, component)
     // A star occupies G = 2 NPOPS neighbouring lanes (population, component) of the evaluated candidate's chain.
-    constexpr int G = 2 * NPOPS, PER = 64 / G, WPC = 4;
-    const int sub2 = lane % G, pop = sub2 >> 1, cand = sel, wslot = wave;
+    const int pop = sub2 >> 1, cand = sel;
     LaneView<NFP> lv;
     {
         const int cs = (cand ? valid[NC - 1] : valid[0]) ? cand : safe;          // the candidate whose views this lane reads
@@ -362,7 +372,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
 #undef B9_PICK
         const int ck = (C ? NC - 1 : 0) * NPOPS + (B ? NPOPS - 1 : 0);
         lv.is_mass = s_axes + seg_off[NM0] + ck * mass_cap;                      // the LDS copy of the mass column
-        lv.par = (C ? params[NC - 1] : params[0]) + (size_t)w * B9_NPARAM;
+        lv.par = s_axes + seg_off[NP0] + (C ? NC - 1 : 0) * B9_NPARAM;           // the LDS copy of the candidate's parameter row
         lv.ax.log_age = s_axes + seg_off[0];
         lv.ax.wc_log_age_lds = stage_wc_age ? s_axes + seg_off[1] : nullptr;
         lv.ax.wc_mass = s_axes + seg_off[2]; lv.ax.wc_carb = s_axes + seg_off[3];
@@ -379,22 +389,19 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     double acc = 0.0;
     // chunks of PER stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over a
     // candidate's waves second (a short list spreads over as many CUs as there are parts); a wave stops at its first chunk
-    // without a heavy star (masses descend).  Wave-uniform trip count: the shuffles see full EXEC.  The next chunk's masses
+    // without a heavy star (masses descend).  Wave-uniform trip count: the shuffles see full EXEC.  The next chunk's star data
     // are requested before this chunk is evaluated.
-    int c = part + parts * wslot;
-    int j = c * PER + lane / G, jj = j < st.n ? j : st.n - 1;
-    double m1 = st.heavy_mass[jj];
     while (c * PER < st.n) {
-        const bool live = j < st.n && my_valid && m1 > my_tip;
+        const bool live = j < st.n && my_valid && cur.m1 > my_tip;
         if (__ballot(live) == 0ull) break;
         const int c_n = c + parts * WPC, j_n = c_n * PER + lane / G, jj_n = j_n < st.n ? j_n : st.n - 1;
-        const double m1_n = st.heavy_mass[jj_n];
-        const double v = star_value_lanes<NFP, NPOPS>(pk, lv, st, jj, sub2, m1);
+        const HeavyStar nxt = load_heavy_star(st, jj_n);
+        const double v = star_value_lanes<NFP, NPOPS>(pk, lv, st, jj, cur, sub2);
         if (live && sub2 == 0) {
             if (perstar) perstar[(size_t)w * st.n + st.hv_perm[jj]] = v;
             acc += v;
         }
-        c = c_n; j = j_n; jj = jj_n; m1 = m1_n;
+        c = c_n; j = j_n; jj = jj_n; cur = nxt;
     }
     HSTAMP(4);
     // the evaluated candidate's partial: fixed-order sum over the waves (the other candidate's slot gets 0)

@@ -73,10 +73,13 @@ if eng.lib.b9_debug_read_gantt_heavy(hb.ctypes.data) == 0:
 h2 = np.zeros((64, 16), dtype=np.uint64)
 eng.lib.b9_debug_read_gantt_heavy2.argtypes = [C.c_void_p]
 if eng.lib.b9_debug_read_gantt_heavy2(h2.ctypes.data) == 0:
-    h = h2.astype(np.int64)
-    h = h[h[:, 9] > 0]
-    print("inside one heavy star (one lane), us since entry: data 1 | prec 2 | exp/log 4 | cooling 6 | desc 7 | loop start 8 | loop end 9 | MS search 11-12")
-    for k, r in enumerate(h[:4]):
-        print("   wg %2d: " % k + " ".join("%d:%5.2f" % (j, (r[j] - r[0]) / 100) if r[j] else "%d:  -  " % j for j in (1, 2, 4, 6, 7, 8, 9, 11, 12)))
-periods = np.diff([s[:, 0].min() for s in steps]) / 100.0
-print("launch period (first start -> next first start):", np.round(periods, 2))
+    g = h2.astype(np.int64)
+    hb64 = hb.astype(np.int64)
+    print("inside one heavy star (lane HS2_LANE of wave 0), us since the role's stars phase began (heavy stamp 3): "
+          "MS search 11-12 | prec 2 | exp/log 4 | cooling 6 | desc 7")
+    for k in range(12):
+        if g[k, 7] <= 0 and g[k, 12] <= 0:
+            continue
+        t0 = hb64[k, 3]
+        print("   wg %2d: " % k + " ".join("%d:%5.2f" % (j, (g[k, j] - t0) / 100) if g[k, j] else "%d:  -  " % j for j in (11, 12, 2, 4, 6, 7))
+              + "   | stars phase ends %5.2f" % ((hb64[k, 4] - t0) / 100))
