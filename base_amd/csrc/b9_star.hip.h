@@ -505,7 +505,7 @@ __device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, c
         prec_corners<2>(pk, two, ax.log_age, m, pc);
         vf0 = pc[0]; vf1 = pc[1];
     }
-    HS2(2);
+    HS2(2); B9_MARK("hv-prec-done");
     const double prec = lerp(vf0, vf1, t_feh);
     const double log_age = par[B9_P_LOGAGE];
     if (prec >= log_age) { c.kind = 3; return c; }
@@ -515,10 +515,10 @@ __device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, c
 #else
     const double log_cool = log10(exp10(log_age) - exp10(prec));
 #endif
-    HS2(4);
+    HS2(4); B9_MARK("hv-explog-done");
     double tr[2];
     wd_cooling(pk, ax, par, wd_mass, log_cool, tr[0], tr[1]);
-    HS2(6);
+    HS2(6); B9_MARK("hv-cooling-done");
     const double log_teff = tr[0];
 #ifdef B9_ABL_HEAVY_CHEAPMATH
     const double logg = LOG_G_PLUS_LOG_MSUN + (wd_mass - 1.0) * 0.43 - 2.0 * tr[1];
@@ -533,7 +533,7 @@ __device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, c
     c.r0 = pk.at_mags + (((size_t)ty * pk.n_at_logg + ig) * pk.n_at_teff + it) * NFP;
     c.r1 = c.r0 + (size_t)pk.n_at_teff * NFP;
     c.kind = 2;
-    HS2(7);
+    HS2(7); B9_MARK("hv-desc-done");
     return c;
 }
 

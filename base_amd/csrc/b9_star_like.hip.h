@@ -254,7 +254,7 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
 template <int NFP, int NPOPS, int NC, class SelectFn>
 __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *const (&hdr)[NC],
                                             const double *const (&iso_data)[NC], long long iso_stride, int mass_cap,
-                                            const double *const (&params)[NC], SelectFn select, int w, int part, int parts,
+                                            const double *const (&params)[NC], SelectFn select, bool both_exist, int w, int part, int parts,
                                             double *const (&out_partial)[NC], double *__restrict__ perstar, double *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,13 +307,14 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     double sv[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) { const int e = tid + k * 256; sv[k] = in_pass1(e) ? *stage_src(e) : 0.0; }
-    // the first chunk's stars (which chunk is a matter of part / wave / lane alone), also requested now: chunks of PER
-    // stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over the waves second
-    constexpr int G = 2 * NPOPS, PER = 64 / G, WPC = 4;
+    // the first chunk's stars (which chunk is a matter of part / wave / lane and of the mode below), also requested now:
+    // chunks of PER stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over
+    // the waves second
+    constexpr int G = 2 * NPOPS, PER = 64 / G;
     const int sub2 = lane % G;
-    int c = part + parts * wave;
-    int j = c * PER + lane / G, jj = j < st.n ? j : st.n - 1;
-    HeavyStar cur = load_heavy_star(st, jj);
+    const int j_a = (part + parts * wave) * PER + lane / G, j_b = (part + parts * (wave & 1)) * PER + lane / G;
+    const HeavyStar cur_a = load_heavy_star(st, j_a < st.n ? j_a : st.n - 1);
+    const HeavyStar cur_b = NC == 2 ? load_heavy_star(st, j_b < st.n ? j_b : st.n - 1) : cur_a;
     // (both candidates' headers are requested BEFORE the selection is known -- one round trip fewer on the chain; a
     //  candidate that does not exist yet, in the first launch of a block, holds anything: its fields are only used once
     //  selected, and it never is)
@@ -322,17 +323,45 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     double tip_min[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) valid[c] = load_iso_views<NFP, NPOPS>(hdr[c], iso_data[c], iso_stride, mass_cap, w, iso[c], tip_min[c]);
-    const int sel = NC == 2 ? select() : 0;
+    // How long a candidate's heavy list is needs no search: the list descends, so "at most T stars above the tip" is
+    // heavy_mass[T] <= tip -- one load at an address known at entry.
+    // SPECULATIVE mode (the sampler step, both candidates derived): when each candidate's heavy stars fit one round of
+    // HALF the workgroups' waves (T = parts * 2 * PER), waves 0-1 evaluate candidate 0 and waves 2-3 candidate 1 side by
+    // side, and the role never waits for the decision (the next launch's decision picks the partial of the candidate
+    // that counted).  Longer lists wait for the decision and evaluate that candidate alone with all four waves
+    // (evaluating both would double the rounds).
+    const int T = parts * 2 * PER;
+    const double m_first = st.heavy_mass[0], m_T = T < st.n ? st.heavy_mass[T] : -__builtin_inf();
+    bool none[NC];                                                               // no star above the candidate's tip
 #pragma unroll
-    for (int c = 0; c < NC; ++c) if (c != sel) { valid[c] = false; tip_min[c] = __builtin_inf(); }
-    if (!(sel ? valid[NC - 1] : valid[0])) {
-        if (tid == 0) {
+    for (int c = 0; c < NC; ++c) none[c] = !(m_first > tip_min[c]);
+    bool spec = false;
+#ifdef B9_HEAVY_SPECULATE      // measured: a loss (the chain does not start earlier -- the role's first round trip, not the decision, is what it
+                               // waits for -- and a heavy star under EITHER candidate now costs its chain: C2 16.5 -> 17.7 us/step)
+    if (NC == 2 && both_exist) spec = (!valid[0] || m_T <= tip_min[0]) && (!valid[NC - 1] || m_T <= tip_min[NC - 1]);
+#else
+    (void)m_T; (void)both_exist;
+#endif
+    const int sel = (NC == 2 && !spec) ? select() : 0;
+    const int wpc = spec ? 2 : 4;                                                // waves per candidate
+    const int cand = spec ? (wave >> 1) : sel;                                   // this wave's candidate
+    if (!spec) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) *out_partial[c] = 0.0;
-        }
-        return;
+        for (int c = 0; c < NC; ++c) if (c != sel) { valid[c] = false; tip_min[c] = __builtin_inf(); }
     }
-    const int safe = sel;
+    {   // nothing to do: no valid candidate, or no heavy star under any candidate this workgroup evaluates
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) any = any || (valid[c] && !none[c]);
+        if (!any) {
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) *out_partial[c] = 0.0;
+            }
+            return;
+        }
+    }
+    const int safe = valid[0] ? 0 : NC - 1;                                      // a candidate whose views are real
     HSTAMP(1);
 #pragma unroll
     for (int k = 0; k < E; ++k) { const int e = tid + k * 256; if (in_pass1(e)) s_axes[e] = sv[k]; }
@@ -355,10 +384,10 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         }
     }
     __syncthreads();
-    HSTAMP(3);
+    HSTAMP(3); B9_MARK("hv-stars-begin");
     // this lane's (candidate, population, component)
     // A star occupies G = 2 NPOPS neighbouring lanes (population, component) of the evaluated candidate's chain.
-    const int pop = sub2 >> 1, cand = sel;
+    const int pop = sub2 >> 1;
     LaneView<NFP> lv;
     {
         const int cs = (cand ? valid[NC - 1] : valid[0]) ? cand : safe;          // the candidate whose views this lane reads
@@ -391,10 +420,13 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     // candidate's waves second (a short list spreads over as many CUs as there are parts); a wave stops at its first chunk
     // without a heavy star (masses descend).  Wave-uniform trip count: the shuffles see full EXEC.  The next chunk's star data
     // are requested before this chunk is evaluated.
+    int c = part + parts * (spec ? (wave & 1) : wave);
+    int j = c * PER + lane / G, jj = j < st.n ? j : st.n - 1;
+    HeavyStar cur = spec ? cur_b : cur_a;
     while (c * PER < st.n) {
         const bool live = j < st.n && my_valid && cur.m1 > my_tip;
         if (__ballot(live) == 0ull) break;
-        const int c_n = c + parts * WPC, j_n = c_n * PER + lane / G, jj_n = j_n < st.n ? j_n : st.n - 1;
+        const int c_n = c + parts * wpc, j_n = c_n * PER + lane / G, jj_n = j_n < st.n ? j_n : st.n - 1;
         const HeavyStar nxt = load_heavy_star(st, jj_n);
         const double v = star_value_lanes<NFP, NPOPS>(pk, lv, st, jj, cur, sub2);
         if (live && sub2 == 0) {
@@ -403,8 +435,9 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         }
         c = c_n; j = j_n; jj = jj_n; cur = nxt;
     }
-    HSTAMP(4);
-    // the evaluated candidate's partial: fixed-order sum over the waves (the other candidate's slot gets 0)
+    HSTAMP(4); B9_MARK("hv-stars-end");
+    // the partials: fixed-order sums over the waves (decision first: the evaluated candidate's, 0 in the other slot;
+    // speculative: each candidate's two waves)
     {
         const double sum = wave_sum(acc);
         if (lane == 0) s_red[wave] = sum;
@@ -412,9 +445,14 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     __syncthreads();
     HSTAMP(5);
     if (tid == 0) {
-        const double tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (spec) {
+            *out_partial[0] = s_red[0] + s_red[1];
+            *out_partial[NC - 1] = s_red[2] + s_red[3];
+        } else {
+            const double tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) *out_partial[c] = c == sel ? tot : 0.0;
+            for (int c = 0; c < NC; ++c) *out_partial[c] = c == sel ? tot : 0.0;
+        }
     }
 }
 
@@ -440,7 +478,7 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevP
             const IsoHdr *const h1[1] = {hdr};
             const double *const i1[1] = {iso_data}, *const p1[1] = {params};
             double *const o1[1] = {partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part};
-            heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, iso_stride, mass_cap, p1, [] { return 0; }, w, part, heavy_parts, o1, perstar, smem);
+            heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, iso_stride, mass_cap, p1, [] { return 0; }, false, w, part, heavy_parts, o1, perstar, smem);
         }
 #else
         if (threadIdx.x == 0) partial[(size_t)w * partial_stride + (size_t)n_groups * 4 + part] = 0.0;   // ablation build
