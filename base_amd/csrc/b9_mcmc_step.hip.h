@@ -407,6 +407,23 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
     return role;
 }
 
+// (-DB9_KERNARG_WARM, measured and left off.)  The kernel's arguments are ~1 KB of structs by value; the compiler fetches
+// a field where it first needs it, and every 64-byte line of the freshly written argument buffer touched for the first
+// time is a memory round trip.  Touching every line at entry brings them in with one round trip -- 0.9 us faster on the
+// 200-star shape, 0.5 us SLOWER on the 50k-star one (3072 waves x 17 extra scalar loads at the launch's start).
+template <size_t BYTES>
+__device__ __forceinline__ void warm_kernargs()
+{
+#ifdef B9_KERNARG_WARM
+    typedef const __attribute__((address_space(4))) unsigned *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned acc = 0;
+#pragma unroll
+    for (size_t i = 0; i < (BYTES + 63) / 64; ++i) acc |= ka[i * 16];
+    asm volatile("" :: "s"(acc));
+#endif
+}
+
 template <int NFP, int NPOPS>
 __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS))
 void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_per_block, int n_groups,
@@ -416,6 +433,7 @@ void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_pe
 #ifdef B9_GANTT
     const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
 #endif
+    warm_kernargs<sizeof(DevPack) + sizeof(DevStars) + sizeof(StepDev) + sizeof(DevPriors) + 7 * sizeof(int)>();
     const int role = step_body<NFP, NPOPS>(pk, st, sd, pr, tiles_per_block, n_groups, front_blocks, hot_blocks, heavy_parts, derive_parts, derive_first, smem);
 #ifdef B9_GANTT
     __syncthreads();          // the workgroup's last wave
