@@ -61,6 +61,14 @@ s = steps[len(steps) // 2]
 a, b, role, xcc = s[:, 0], s[:, 1], s[:, 2] & 0xFF, (s[:, 2] >> 8) & 0xF
 t0 = a.min()
 last = np.argsort(b)[-6:]
+hot = np.where(role == 0)[0]
+dur = (b[hot] - a[hot]) / 100.0
+slow = hot[dur > np.percentile(dur, 90)]
+first_hot = hot.min()
+print("slowest 10% of the hot workgroups (id - first hot id, xcc, us):", [(int(i - first_hot), int(xcc[i]), round((b[i] - a[i]) / 100, 1)) for i in slow][:70])
+for r_, nm in ((0, "hot"), (1, "heavy"), (2, "derive")):
+    m_ = role == r_
+    print(f"   per XCC, {nm}: " + " ".join(f"{x}: n={int((m_ & (xcc == x)).sum())} mean {((b - a)[m_ & (xcc == x)].mean() / 100 if (m_ & (xcc == x)).any() else 0):.2f}" for x in range(8)))
 print("last finishers of a middle launch (workgroup, role, xcc, start, end):", [(int(i), ROLE[int(role[i])], int(xcc[i]), round((a[i] - t0) / 100, 2), round((b[i] - t0) / 100, 2)) for i in last])
 hb = np.zeros((64, 8), dtype=np.uint64)
 eng.lib.b9_debug_read_gantt_heavy.argtypes = [C.c_void_p]
