@@ -428,7 +428,11 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         if (__ballot(live) == 0ull) break;
         const int c_n = c + parts * wpc, j_n = c_n * PER + lane / G, jj_n = j_n < st.n ? j_n : st.n - 1;
         const HeavyStar nxt = load_heavy_star(st, jj_n);
-        const double v = star_value_lanes<NFP, NPOPS>(pk, lv, st, jj, cur, sub2);
+        // (the lanes of a star that is NOT above the tip -- most of a short list's last chunk -- present mass 0: "no star",
+        //  the shortest path; left alone they would walk the MS/RGB branch, serialised with the live lanes' WD branch)
+        HeavyStar hs = cur;
+        hs.m1 = live ? cur.m1 : 0.0;
+        const double v = star_value_lanes<NFP, NPOPS>(pk, lv, st, jj, hs, sub2);
         if (live && sub2 == 0) {
             if (perstar) perstar[(size_t)w * st.n + st.hv_perm[jj]] = v;
             acc += v;
