@@ -264,11 +264,13 @@ __device__ __forceinline__ void wd_cooling_tracks(const DevPack &pk, const WdAxe
         n[k] = (int)(w & 0xFFFFFFFFull); off[k] = (int)(w >> 32);
         axes[k] = age_base + off[k];
     }
+    HS2(13);
     double vt[NT], vr[NT];
     if (pk.wc_uniform) {          // a rectangular table: the tracks share one age axis -- one search, one weight for all of them
         const int i0 = bracket8<false>(age_base, n[0], log_cool);
         const double a0 = age_base[i0], a1 = age_base[i0 + 1];
         const double ta = fdiv(log_cool - a0, a1 - a0);
+        HS2(14);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const size_t b = (size_t)off[k] + i0;
@@ -495,6 +497,7 @@ __device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, c
     if (!(m <= pk.m_wd_up)) return c;                            // NS / BH
     if (pk.n_wc_mass < 2 || pk.n_at_teff < 2) return c;          // no WD models loaded
     // WD (wd_mags): precursor age -> cooling age -> (Teff, radius) -> atmosphere rows
+    HS2(3);
     double pc[4];
     double vf0, vf1;
     if (pk.n_y > 1) {
@@ -601,6 +604,7 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const Lane
     }
     const double mod = lv.par[B9_P_MOD], av = lv.par[B9_P_ABS];
     const bool binary = q > 0.0;
+    HS2(1);
     // 1. each lane of the pair reduces ITS component to a descriptor (the long chain; the two run side by side)
     Comp d; d.kind = 0; d.r0 = lv.is_mags; d.r1 = lv.is_mags; d.t = 0.0; d.tg = 0.0;
     if (comp == 0 || binary)
@@ -626,6 +630,7 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const Lane
         const double dd = (p + (mod + pk.abs_m1[f] * av)) - obs[k];
         chi2 = fma(wgt[k] * dd, dd, chi2);
     }
+    HS2(8);
     chi2 += __shfl_xor(chi2, 1, 64);                                  // (the sum of the two halves: the same bits in both lanes)
     const double ll = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
     double l = ll;

@@ -84,10 +84,10 @@ if eng.lib.b9_debug_read_gantt_heavy2(h2.ctypes.data) == 0:
     g = h2.astype(np.int64)
     hb64 = hb.astype(np.int64)
     print("inside one heavy star (lane HS2_LANE of wave 0), us since the role's stars phase began (heavy stamp 3): "
-          "MS search 11-12 | prec 2 | exp/log 4 | cooling 6 | desc 7")
+          "entry 1 | MS search 11-12 | WD branch entered 3 | prec 2 | exp/log 4 | cooling: axes 13, age 14, done 6 | desc 7 | chi2 done 8")
     for k in range(12):
         if g[k, 7] <= 0 and g[k, 12] <= 0:
             continue
         t0 = hb64[k, 3]
-        print("   wg %2d: " % k + " ".join("%d:%5.2f" % (j, (g[k, j] - t0) / 100) if g[k, j] else "%d:  -  " % j for j in (11, 12, 2, 4, 6, 7))
+        print("   wg %2d: " % k + " ".join("%d:%5.2f" % (j, (g[k, j] - t0) / 100) if g[k, j] else "%d:  -  " % j for j in (1, 11, 12, 3, 2, 4, 13, 14, 6, 7, 8))
               + "   | stars phase ends %5.2f" % ((hb64[k, 4] - t0) / 100))
