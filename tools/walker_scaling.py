@@ -10,11 +10,11 @@ eng = engine.Engine(abi.make_pack(pack_d), abi.make_stars(cl), synth.default_pri
 free = np.array(mcmc.DEFAULT_FREE); chol = np.diag([1e-5, 2e-5, 1e-5, 1e-5])
 _w = synth.walker_params(truth, 8, seed=1, scale=0.02)           # discard run: clocks / first-use effects
 eng.mcmc_run_block(_w, eng.logpost(_w), np.arange(8), free, chol, 1, 0, 1500)
-print("| walkers | us/step | star-evals/s | algorithmic GB/s of the whole step |\n|---|---|---|---|")
+print("| walkers | us/step | star-evals/s | algorithmic GB/s (152 B per star-eval, SURVEY 8d; an L2-served rate below ~16 walkers) |\n|---|---|---|---|")
 for W in (1, 2, 4, 8, 16, 32, 64, 128):
     start = synth.walker_params(truth, W, seed=42, scale=0.02)
     lp = eng.logpost(start)
     eng.mcmc_run_block(start, lp, np.arange(W), free, chol, 1, 0, 100)
     n = 600 if W <= 16 else 200
     t0 = time.perf_counter(); eng.mcmc_run_block(start, lp, np.arange(W), free, chol, 1, 0, n); dt = time.perf_counter() - t0
-    print(f"| {W} | {1e6*dt/n:.1f} | {50000*W*n/dt:.3e} | {164*50000*W*n/dt/1e9:.0f} |", flush=True)
+    print(f"| {W} | {1e6*dt/n:.1f} | {50000*W*n/dt:.3e} | {152*50000*W*n/dt/1e9:.0f} |", flush=True)
