@@ -573,18 +573,20 @@ struct LaneView {
 // half of them), and the populations swap log-likelihoods.  Every magnitude is formed by star_value's operations; the
 // chi^2 is the sum of two half-sums instead of one chain over the filters (a 1e-16 relative difference).  All lanes of a
 // group must call (full EXEC); the result is valid in every lane of the group.
-// What the head of a heavy star's chain needs (heavy-order arrays, DevStars::hv_*): nothing here depends on the
-// candidate, so the caller requests a chunk's while the previous chunk -- or the decision -- is still under way.  (The
-// observations are used at the chain's END: star_value_lanes requests them itself and they arrive long before.)
+// What the HEAD of a heavy star's chain needs (heavy-order arrays, DevStars::hv_*): nothing here depends on the
+// candidate, so the caller requests the first chunk's at the role's entry.  Everything else of the star -- the
+// observations and weights, its two constants -- is used at the chain's END and requested there, together with the
+// table rows (one round trip for all of it): the role is short of registers, not of loads (carrying the 20 values
+// through the chain cost spills and 0.5-0.8 us per step).
 struct HeavyStar {
-    double m1, q, c0, la;
+    double m1, q;
     int flags;
 };
 
 __device__ __forceinline__ HeavyStar load_heavy_star(const DevStars &st, int j /* index in the descending-mass list */)
 {
     HeavyStar h;
-    h.m1 = st.heavy_mass[j]; h.q = st.hv_q[j]; h.c0 = st.hv_c0[j]; h.la = st.hv_la[j]; h.flags = st.hv_flags[j];
+    h.m1 = st.heavy_mass[j]; h.q = st.hv_q[j]; h.flags = st.hv_flags[j];
     return h;
 }
 
@@ -594,14 +596,8 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const Lane
 {
     const int comp = sub & 1;
     constexpr int HF = NFP / 2;                                       // filters per lane of a (population) pair
-    const double m1 = hs.m1, q = hs.q, c0 = hs.c0, la = hs.la;
+    const double m1 = hs.m1, q = hs.q;
     const int wd_type = hs.flags & 1;
-    double obs[HF], wgt[HF];
-#pragma unroll
-    for (int k = 0; k < HF; ++k) {
-        const int f = comp * HF + k;
-        obs[k] = st.hv_obs[(size_t)f * st.hv_pad + j]; wgt[k] = st.hv_w[(size_t)f * st.hv_pad + j];
-    }
     const double mod = lv.par[B9_P_MOD], av = lv.par[B9_P_ABS];
     const bool binary = q > 0.0;
     HS2(1);
@@ -620,6 +616,13 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const Lane
     c2.kind = comp ? d.kind : o.kind; c2.r0 = comp ? d.r0 : o.r0; c2.r1 = comp ? d.r1 : o.r1; c2.t = comp ? d.t : o.t; c2.tg = comp ? d.tg : o.tg;
     // 3. ... and each takes HALF of the filters (the secondary's lane is not idle through the flux combines; a single
     //    star's second lane, idle until now, takes half of the primary's filters)
+    const double c0 = st.hv_c0[j], la = st.hv_la[j];
+    double obs[HF], wgt[HF];
+#pragma unroll
+    for (int k = 0; k < HF; ++k) {
+        const int f = comp * HF + k;
+        obs[k] = st.hv_obs[(size_t)f * st.hv_pad + j]; wgt[k] = st.hv_w[(size_t)f * st.hv_pad + j];
+    }
     double chi2 = 0.0;
 #pragma unroll
     for (int k = 0; k < HF; ++k) {

@@ -427,7 +427,6 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         const bool live = j < st.n && my_valid && cur.m1 > my_tip;
         if (__ballot(live) == 0ull) break;
         const int c_n = c + parts * wpc, j_n = c_n * PER + lane / G, jj_n = j_n < st.n ? j_n : st.n - 1;
-        const HeavyStar nxt = load_heavy_star(st, jj_n);
         // (the lanes of a star that is NOT above the tip -- most of a short list's last chunk -- present mass 0: "no star",
         //  the shortest path; left alone they would walk the MS/RGB branch, serialised with the live lanes' WD branch)
         HeavyStar hs = cur;
@@ -437,7 +436,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
             if (perstar) perstar[(size_t)w * st.n + st.hv_perm[jj]] = v;
             acc += v;
         }
-        c = c_n; j = j_n; jj = jj_n; cur = nxt;
+        c = c_n; j = j_n; jj = jj_n; cur = load_heavy_star(st, jj_n);
     }
     HSTAMP(4); B9_MARK("hv-stars-end");
     // the partials: fixed-order sums over the waves (decision first: the evaluated candidate's, 0 in the other slot;
