@@ -598,7 +598,6 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const Lane
     constexpr int HF = NFP / 2;                                       // filters per lane of a (population) pair
     const double m1 = hs.m1, q = hs.q;
     const int wd_type = hs.flags & 1;
-    const double mod = lv.par[B9_P_MOD], av = lv.par[B9_P_ABS];
     const bool binary = q > 0.0;
     HS2(1);
     // 1. each lane of the pair reduces ITS component to a descriptor (the long chain; the two run side by side)
@@ -617,6 +616,7 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const Lane
     // 3. ... and each takes HALF of the filters (the secondary's lane is not idle through the flux combines; a single
     //    star's second lane, idle until now, takes half of the primary's filters)
     const double c0 = st.hv_c0[j], la = st.hv_la[j];
+    const double mod = lv.par[B9_P_MOD], av = lv.par[B9_P_ABS];      // (LDS; read here, not carried through the chain)
     double obs[HF], wgt[HF];
 #pragma unroll
     for (int k = 0; k < HF; ++k) {

@@ -388,16 +388,25 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     // this lane's (candidate, population, component)
     // A star occupies G = 2 NPOPS neighbouring lanes (population, component) of the evaluated candidate's chain.
     const int pop = sub2 >> 1;
+    // With one population and the decision taken, everything the lane view holds is the same in every lane of the wave:
+    // say so (readfirstlane), and it lives in scalar registers -- ~25 VGPRs in a role that spills for want of them.
+    auto uni_i = [](int x) { return (NPOPS == 1) ? __builtin_amdgcn_readfirstlane(x) : x; };
+    auto uni_d = [](double x) {
+        if (NPOPS != 1) return x;
+        const unsigned long long b = __double_as_longlong(x);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    };
     LaneView<NFP> lv;
     {
-        const int cs = (cand ? valid[NC - 1] : valid[0]) ? cand : safe;          // the candidate whose views this lane reads
+        const int cs = uni_i((cand ? valid[NC - 1] : valid[0]) ? cand : safe);   // the candidate whose views this lane reads
         const bool B = NPOPS == 2 && pop;
         const bool C = cs != 0;
         // (field-by-field selects with constant indices: a run-time index would put the views in scratch memory)
 #define B9_PICK(field) (C ? (B ? iso[NC - 1][NPOPS - 1].field : iso[NC - 1][0].field) : (B ? iso[0][NPOPS - 1].field : iso[0][0].field))
-        lv.is_mags = B9_PICK(mags); lv.is_n = B9_PICK(n); lv.is_tip = B9_PICK(tip);
-        lv.t_feh = B9_PICK(t_feh); lv.t_y = B9_PICK(t_y);
-        const int v_feh = B9_PICK(i_feh), v_y = B9_PICK(i_y);
+        lv.is_mags = B9_PICK(mags); lv.is_n = uni_i(B9_PICK(n)); lv.is_tip = uni_d(B9_PICK(tip));
+        lv.t_feh = uni_d(B9_PICK(t_feh)); lv.t_y = uni_d(B9_PICK(t_y));
+        const int v_feh = uni_i(B9_PICK(i_feh)), v_y = uni_i(B9_PICK(i_y));
 #undef B9_PICK
         const int ck = (C ? NC - 1 : 0) * NPOPS + (B ? NPOPS - 1 : 0);
         lv.is_mass = s_axes + seg_off[NM0] + ck * mass_cap;                      // the LDS copy of the mass column
@@ -413,8 +422,8 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
             lv.ax.tips[q] = s_axes + tip_lo + col * na;
         }
     }
-    const bool my_valid = cand ? valid[NC - 1] : valid[0];
-    const double my_tip = cand ? tip_min[NC - 1] : tip_min[0];
+    const bool my_valid = uni_i((cand ? valid[NC - 1] : valid[0]) ? 1 : 0) != 0;
+    const double my_tip = uni_d(cand ? tip_min[NC - 1] : tip_min[0]);
     double acc = 0.0;
     // chunks of PER stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over a
     // candidate's waves second (a short list spreads over as many CUs as there are parts); a wave stops at its first chunk
@@ -426,7 +435,6 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     while (c * PER < st.n) {
         const bool live = j < st.n && my_valid && cur.m1 > my_tip;
         if (__ballot(live) == 0ull) break;
-        const int c_n = c + parts * wpc, j_n = c_n * PER + lane / G, jj_n = j_n < st.n ? j_n : st.n - 1;
         // (the lanes of a star that is NOT above the tip -- most of a short list's last chunk -- present mass 0: "no star",
         //  the shortest path; left alone they would walk the MS/RGB branch, serialised with the live lanes' WD branch)
         HeavyStar hs = cur;
@@ -436,7 +444,8 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
             if (perstar) perstar[(size_t)w * st.n + st.hv_perm[jj]] = v;
             acc += v;
         }
-        c = c_n; j = j_n; jj = jj_n; cur = load_heavy_star(st, jj_n);
+        c += parts * wpc; j = c * PER + lane / G; jj = j < st.n ? j : st.n - 1;
+        cur = load_heavy_star(st, jj);
     }
     HSTAMP(4); B9_MARK("hv-stars-end");
     // the partials: fixed-order sums over the waves (decision first: the evaluated candidate's, 0 in the other slot;
