@@ -552,6 +552,29 @@ int b9_load_pack(b9_ctx *ctx, const b9_pack *p)
             std::memcpy(&at[i * d.nfp], &p->at_mags[i * d.nf], sizeof(double) * d.nf);
         if ((rc = upload(ctx, A, at.data(), at.size(), &d.at_mags))) return rc;
     }
+    {   // the heavy-star role's LDS image of the axes (DevPack::heavy_const)
+        std::vector<double> hc;
+        auto seg = [&](int k, const double *src, size_t n) { d.hc_off[k] = (int)hc.size(); if (src && n) hc.insert(hc.end(), src, src + n); };
+        seg(0, p->log_age, (size_t)p->n_age);
+        d.hc_age_staged = has_wd && (d.wc_uniform || d.n_wc_points <= B9_WC_AGE_LDS_MAX) ? 1 : 0;
+        if (d.hc_age_staged) seg(1, p->wc_log_age + (d.wc_uniform ? d.wc_off0 : 0), (size_t)(d.wc_uniform ? d.wc_n0 : d.n_wc_points));
+        else seg(1, nullptr, 0);
+        if (has_wd) {
+            const double zero = 0.0;
+            seg(2, p->wc_mass, (size_t)p->n_wc_mass);
+            seg(3, p->n_wc_carb >= 1 ? p->wc_carb : &zero, (size_t)d.n_wc_carb);
+            seg(4, p->at_log_teff, (size_t)p->n_at_teff);
+            seg(5, p->at_logg, (size_t)p->n_at_logg);
+            std::vector<double> packed(wc_n.size());
+            for (size_t t = 0; t < wc_n.size(); ++t) {
+                const unsigned long long w = (unsigned long long)(unsigned)wc_n[t] | ((unsigned long long)(unsigned)wc_off[t] << 32);
+                std::memcpy(&packed[t], &w, sizeof w);
+            }
+            seg(6, packed.data(), packed.size());
+        } else for (int k = 2; k < 7; ++k) seg(k, nullptr, 0);
+        d.hc_len = (int)hc.size();
+        if ((rc = upload(ctx, A, hc.data(), hc.size(), &d.heavy_const))) return rc;
+    }
     d.ifmr_id = p->ifmr_id;
     d.m_wd_up = p->m_wd_up;
     d.log_mass_norm = log_mass_norm(p->m_wd_up);

@@ -32,6 +32,12 @@ struct DevPack {
     // WD atmospheres, rows padded to nfp
     int n_at_type, n_at_logg, n_at_teff;
     const double *at_logg, *at_log_teff, *at_mags;
+    // The axes the heavy-star role searches, packed back to back in the order [log_age | cooling-age axes (the shared one of
+    // a rectangular table, all tracks' of a ragged one; absent when too long for LDS) | wc_mass | wc_carb | at_log_teff |
+    // at_logg | wc_track]: the role copies this ONE run to LDS at its entry (7 runs of 5-100 entries cost 7 loads per thread).
+    const double *heavy_const;
+    int hc_len, hc_off[7];           // entries; where each axis starts; hc_age_staged: the cooling-age axes are part of it
+    int hc_age_staged;
     int ifmr_id;
     double m_wd_up;
     double log_mass_norm;

@@ -104,15 +104,11 @@ hipError_t b9k_derive_iso_rows(const DevPack &pk, const double *host_rows, doubl
 // and the mass column + each candidate's parameter row
 static size_t heavy_lds_doubles(const DevPack &pk, int n_pops, int n_cand, int mass_cap)
 {
-    auto blk = [](size_t n) { return n; };
-    const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
-    const size_t wc_age = !has_wd ? 0 : (pk.wc_uniform ? (size_t)pk.wc_n0 : (pk.n_wc_points <= B9_WC_AGE_LDS_MAX ? (size_t)pk.n_wc_points : 0));
+    // [8 words of reduction scratch][the packed axes, DevPack::heavy_const][AGB tips: the whole table, or the corner columns]
+    // [mass columns][parameter rows][find_bracket's over-read]
     const size_t n_tips = (size_t)pk.n_feh * pk.n_y * pk.n_age;
-    const size_t tips = n_tips <= B9_TIPS_LDS_MAX ? n_tips : (size_t)4 * n_pops * n_cand * pk.n_age;       // the whole table, or the corner columns
-    size_t n = 8 + blk(pk.n_age) + blk(wc_age) + blk(tips) + (size_t)n_pops * n_cand * blk(mass_cap) + (size_t)n_cand * B9_NPARAM + 8;
-    if (has_wd) n += blk(pk.n_wc_mass) + blk(pk.n_wc_carb) + blk(pk.n_at_teff) + blk(pk.n_at_logg) + blk((size_t)pk.n_wc_carb * pk.n_wc_mass);
-    else n += 5 * 0;
-    return n;
+    const size_t tips = n_tips <= B9_TIPS_LDS_MAX ? n_tips : (size_t)4 * n_pops * n_cand * pk.n_age;
+    return 8 + (size_t)pk.hc_len + tips + (size_t)n_pops * n_cand * mass_cap + (size_t)n_cand * B9_NPARAM + 8;
 }
 
 template <int NFP, int NPOPS, int WB>

@@ -265,23 +265,17 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     // corner columns follow in pass 2); each candidate's parameter row; per (candidate, population) the derived isochrone's mass column (a heavy
     // primary's companion, or a star that is heavy under one candidate only, is on the MS/RGB branch: its bracket search
     // then runs in LDS, as the hot role's does).
-    constexpr int NC0 = 7, NM0 = NC0 + 1, NP0 = NM0 + NPOPS * NC, NSEG = NP0 + NC, E = B9_HEAVY_STAGE_E(NPOPS);
+    // segments: 0 = the packed axes (DevPack::heavy_const), 1 = AGB tips, then the mass columns, then the parameter rows
+    constexpr int NC0 = 1, NM0 = NC0 + 1, NP0 = NM0 + NPOPS * NC, NSEG = NP0 + NC;
     const int na = pk.n_age, ny = pk.n_y > 1 ? 2 : 1, n_tips = pk.n_feh * pk.n_y * na;
-    const bool has_wd = pk.n_wc_mass >= 2 && pk.n_at_teff >= 2;
-    const bool stage_wc_age = has_wd && (pk.wc_uniform || pk.n_wc_points <= B9_WC_AGE_LDS_MAX);       // (as heavy_lds_doubles sized the LDS)
+    const bool stage_wc_age = pk.hc_age_staged != 0;                                                 // (as heavy_lds_doubles sized the LDS)
     const bool tips_all = n_tips <= B9_TIPS_LDS_MAX;
     const double *seg_src[NSEG];
     int seg_off[NSEG + 1];
     {
-        // (cooling-age axes: all tracks', or the one shared axis of a rectangular table)
-        const double *src0[NM0] = {pk.log_age, pk.wc_log_age + (pk.wc_uniform ? pk.wc_off0 : 0), pk.wc_mass, pk.wc_carb, pk.at_log_teff,
-                                   pk.at_logg, pk.wc_track, pk.tips};
-        const int len0[NM0] = {na, stage_wc_age ? (pk.wc_uniform ? pk.wc_n0 : pk.n_wc_points) : 0, has_wd ? pk.n_wc_mass : 0, has_wd ? pk.n_wc_carb : 0,
-                               has_wd ? pk.n_at_teff : 0, has_wd ? pk.n_at_logg : 0, has_wd ? pk.n_wc_carb * pk.n_wc_mass : 0,
-                               tips_all ? n_tips : 4 * NPOPS * NC * na};
         seg_off[0] = 0;
-#pragma unroll
-        for (int a = 0; a < NM0; ++a) { seg_src[a] = src0[a]; seg_off[a + 1] = seg_off[a] + len0[a]; }
+        seg_src[0] = pk.heavy_const; seg_off[1] = pk.hc_len;
+        seg_src[NC0] = pk.tips; seg_off[NM0] = seg_off[NC0] + (tips_all ? n_tips : 4 * NPOPS * NC * na);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -295,18 +289,41 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
 #pragma unroll
         for (int c = 0; c < NC; ++c) { seg_src[NP0 + c] = params[c] + (size_t)w * B9_NPARAM; seg_off[NP0 + c + 1] = seg_off[NP0 + c] + B9_NPARAM; }
     }
-    const int n_stage = seg_off[NSEG], tip_lo = seg_off[NC0], tip_hi = seg_off[NM0];
-    auto stage_src = [&](int e) {
-        const double *src = seg_src[0] + e;
+    const int tip_lo = seg_off[NC0];
+    // Segment by segment, the first RC[g] x 256 elements of each travel through registers (requested here, written to LDS
+    // after the decision): a thread's element of chunk i of segment g is seg_src[g][tid + 256 i] -- no search for "which
+    // segment is element e in" (the flat-list version spent ~40 VALU instructions per element on that: 16 elements per
+    // thread with two populations, 2.3 us of the role's entry).  Longer segments finish in a loop after the decision.
+    // Pass 1 skips the AGB-tip columns of large grids: their addresses need the headers (pass 2).
+    auto rc = [](int g) constexpr { return g == 0 ? 2 : (g == NC0 ? 8 : (g >= NM0 && g < NP0 ? 2 : 1)); };      // chunks in registers
+    constexpr int NSV = 2 + 8 + 2 * NPOPS * NC + NC;
+    double sv[NSV];
+    {
+        int idx = 0;
 #pragma unroll
-        for (int g = 1; g < NSEG; ++g) src = e >= seg_off[g] ? seg_src[g] + (e - seg_off[g]) : src;
-        return src;
+        for (int g = 0; g < NSEG; ++g) {
+            const int len = (g == NC0 && !tips_all) ? 0 : seg_off[g + 1] - seg_off[g];
+#pragma unroll
+            for (int i = 0; i < rc(g); ++i, ++idx) {
+                const int e = tid + 256 * i;
+                sv[idx] = 0.0;
+                if (len > 256 * i) sv[idx] = seg_src[g][e < len ? e : len - 1];          // (clamped, not branched per lane)
+            }
+        }
+    }
+    auto stage_store = [&](const double (&v)[NSV]) {
+        int idx = 0;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) {
+            const int len = (g == NC0 && !tips_all) ? 0 : seg_off[g + 1] - seg_off[g];
+#pragma unroll
+            for (int i = 0; i < rc(g); ++i, ++idx) {
+                const int e = tid + 256 * i;
+                if (e < len) s_axes[seg_off[g] + e] = v[idx];
+            }
+            for (int e = tid + 256 * rc(g); e < len; e += 256) s_axes[seg_off[g] + e] = seg_src[g][e];     // very long segments only
+        }
     };
-    // (pass 1 skips the AGB-tip columns of large grids: their addresses need the headers -- pass 2)
-    auto in_pass1 = [&](int e) { return e < n_stage && (tips_all || e < tip_lo || e >= tip_hi); };
-    double sv[E];
-#pragma unroll
-    for (int k = 0; k < E; ++k) { const int e = tid + k * 256; sv[k] = in_pass1(e) ? *stage_src(e) : 0.0; }
     // the first chunk's stars (which chunk is a matter of part / wave / lane and of the mode below), also requested now:
     // chunks of PER stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over
     // the waves second
@@ -363,9 +380,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     }
     const int safe = valid[0] ? 0 : NC - 1;                                      // a candidate whose views are real
     HSTAMP(1);
-#pragma unroll
-    for (int k = 0; k < E; ++k) { const int e = tid + k * 256; if (in_pass1(e)) s_axes[e] = sv[k]; }
-    for (int e = tid + E * 256; e < n_stage; e += 256) if (in_pass1(e)) s_axes[e] = *stage_src(e);       // very long lists only
+    stage_store(sv);
     if (!tips_all) {
         // pass 2 (large grids only): the AGB-tip columns of each (candidate, population)'s four (FeH, Y) corners, whose
         // addresses the headers give
@@ -411,10 +426,10 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         const int ck = (C ? NC - 1 : 0) * NPOPS + (B ? NPOPS - 1 : 0);
         lv.is_mass = s_axes + seg_off[NM0] + ck * mass_cap;                      // the LDS copy of the mass column
         lv.par = s_axes + seg_off[NP0] + (C ? NC - 1 : 0) * B9_NPARAM;           // the LDS copy of the candidate's parameter row
-        lv.ax.log_age = s_axes + seg_off[0];
-        lv.ax.wc_log_age_lds = stage_wc_age ? s_axes + seg_off[1] : nullptr;
-        lv.ax.wc_mass = s_axes + seg_off[2]; lv.ax.wc_carb = s_axes + seg_off[3];
-        lv.ax.at_log_teff = s_axes + seg_off[4]; lv.ax.at_logg = s_axes + seg_off[5]; lv.ax.wc_track = s_axes + seg_off[6];
+        lv.ax.log_age = s_axes + pk.hc_off[0];
+        lv.ax.wc_log_age_lds = stage_wc_age ? s_axes + pk.hc_off[1] : nullptr;
+        lv.ax.wc_mass = s_axes + pk.hc_off[2]; lv.ax.wc_carb = s_axes + pk.hc_off[3];
+        lv.ax.at_log_teff = s_axes + pk.hc_off[4]; lv.ax.at_logg = s_axes + pk.hc_off[5]; lv.ax.wc_track = s_axes + pk.hc_off[6];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int df = q >> 1, dy = q & 1;
