@@ -261,7 +261,7 @@ static hipError_t launch_mcmc_step(const DevPack &pk, const DevStars &st, const 
     const int hot = 8 * ((n_groups + 7) / 8) * W;
     const int derive_first = derive_order >= 0 ? 1 : 0;
     const int n_derive = W * 2 * NPOPS * derive_parts;
-    const int front = (W * heavy_parts + (derive_first ? n_derive : W) + 7) / 8 * 8;
+    const int front = (W * heavy_parts + W + (derive_first ? n_derive : 0) + 7) / 8 * 8;     // heavy, writers, (derivation), pad
     const int back = (!derive_first && sd.derive_next) ? n_derive : 0;
     hipLaunchKernelGGL(kern, dim3(front + hot + back), dim3(256), lds, stream, pk, st, sd, pr, tiles_per_block, n_groups,
                        front, hot, heavy_parts, derive_parts, derive_first);

@@ -247,7 +247,8 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
 // Candidate-derivation role (and, for candidate 0 / population 0 / part 0 of each walker, the
 // WRITER of the new state and of the chain record).
 __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd, const DevPriors &pr,
-                                            int w, int cand, int pop, int part, int parts, double *s_state_out = nullptr)
+                                            int w, int cand, int pop, int part, int parts, double *s_state_out = nullptr,
+                                            int mode = 2 /* 0: derive only  1: writer only  2: (cand 0, pop 0, part 0) is also the writer */)
 {
     const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers, n_pops = sd.n_pops;
     __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_prop[B9_NPARAM];
@@ -295,7 +296,7 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
         if (tid < B9_NPARAM) s_state_out[tid] = ok ? prev_prop_v : cur_v;
         if (tid == 0) { s_state_out[B9_NPARAM] = lp_new; s_state_out[B9_NPARAM + 1] = in[B9_ST_NACC] + ((sd.has_prev && ok) ? 1.0 : 0.0); }
     }
-    const bool writer = (cand == 0 && pop == 0 && part == 0);
+    const bool writer = mode != 0 && (cand == 0 && pop == 0 && part == 0);
     if (writer && tid == 0 && sd.has_prev)                 // publish the outcome for workgroups that start later
         __hip_atomic_store(sd.decided + w, (sd.step << 1) | (ok ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -317,7 +318,7 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
         }
         if (sd.has_prev && sd.samples && tid < d) sd.samples[((size_t)sd.row * W + w) * d + tid] = s_cur[fidx];
     }
-    if (!sd.derive_next) return;
+    if (mode == 1 || !sd.derive_next) return;
     // candidate `cand` of step t+1:  base = state (step t rejected) or step t's proposal (accepted);
     // row[free[i]] += sum_j chol[i][j] z_j  (j ascending, plain multiply-add -- as the host twin does)
     if (tid < B9_NPARAM) s_par[tid] = cand ? s_prop[tid] : s_cur[tid];
@@ -333,10 +334,9 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
                      sd.iso_stride, sd.mass_cap, part, parts, axr);
 }
 
-// Grid: [heavy-star workgroups][one WRITER per walker][pad to 8][hot workgroups][derivation workgroups].
-// The writers lead so that the new state and the published decision exist early; the other
-// derivation workgroups trail the grid -- nobody in this launch waits for their output, so they
-// fill the slots the last hot workgroups leave free.  (B9_DERIVE_FIRST=1 puts them in front.)
+// Grid: [heavy-star workgroups][one WRITER per walker][derivation workgroups][pad to 8][hot workgroups]
+// (B9_DERIVE_ORDER < 0: the derivation workgroups trail the grid instead).  The heavy-star chains and the writers -- the
+// new state and the published decision -- start first.
 template <int NFP, int NPOPS>
 __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, int tiles_per_block, int n_groups,
                  int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first, double *smem)
@@ -349,8 +349,8 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
         if (b < n_heavy) role = 1;
         else {
             b -= n_heavy;
-            if (derive_first) role = b < n_derive ? 2 : 3;
-            else if (b < W) { role = 2; b *= 2 * NPOPS * derive_parts; }       // the writer of walker b: (cand 0, pop 0, part 0)
+            if (b < W) role = 4;                                               // the writer of walker b
+            else if (derive_first && b - W < n_derive) { role = 2; b -= W; }
             else role = 3;
         }
     } else {
@@ -358,8 +358,7 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
         if (b < hot_blocks) role = 0;
         else {                                                                  // trailing derivation workgroups (derive_first == 0)
             b -= hot_blocks;
-            const bool writer = (b % (2 * NPOPS * derive_parts)) == 0;          // those already ran in front
-            role = (b < n_derive && !writer && sd.derive_next) ? 2 : 3;
+            role = (!derive_first && b < n_derive && sd.derive_next) ? 2 : 3;
         }
     }
     if (role == 0) {
@@ -402,8 +401,12 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
     if (role == 2) {       // b = ((w * 2 + cand) * NPOPS + pop) * derive_parts + part
         const int part = b % derive_parts; b /= derive_parts;
         const int pop = b % NPOPS; b /= NPOPS;
-        step_derive(pk, sd, pr, b >> 1, b & 1, pop, part, derive_parts);
+        step_derive(pk, sd, pr, b >> 1, b & 1, pop, part, derive_parts, nullptr, 0);
     }
+    // The WRITER of a walker (decision, new state, chain record) is a workgroup of its own: as part 0 of a derivation
+    // it made that workgroup the launch's last (state + prior + log u before its share of the isochrone: 9.1 against
+    // 7.1 us on the small shapes, where the derivation is the critical path).
+    if (role == 4) step_derive(pk, sd, pr, b, 0, 0, 0, 1, nullptr, 1);
     return role;
 }
 

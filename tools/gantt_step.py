@@ -39,7 +39,7 @@ order = np.argsort(t[:, 0, 3])                      # by step number
 steps = [t[k][t[k][:, 1] > 0] for k in order]
 steps = [s for s in steps if len(s)]
 print(f"{name}: {ns} stars x {nf} filters, {npops} pop(s), {W} walkers; {len(steps[0])} workgroups per launch; times in us")
-ROLE = {0: "hot", 1: "heavy", 2: "derive", 3: "pad"}
+ROLE = {0: "hot", 1: "heavy", 2: "derive", 3: "pad", 4: "writer"}
 prev_end = None
 for s in steps[1:-1]:                                # (the first and last launches of the window neighbour other kernels)
     a, b, role = s[:, 0], s[:, 1], s[:, 2] & 0xFF
@@ -49,7 +49,7 @@ for s in steps[1:-1]:                                # (the first and last launc
         line += f"  gap after previous launch's last end {(t0 - prev_end) / 100:.2f}"
     print(line)
     prev_end = b.max()
-    for r in (1, 2, 0):
+    for r in (1, 4, 2, 0):
         m = role == r
         if not m.any():
             continue
