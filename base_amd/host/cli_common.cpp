@@ -1,3 +1,4 @@
+#include <signal.h>
 #include "cli_common.hpp"
 
 #include <algorithm>
@@ -157,12 +158,21 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
         }
         kids.push_back(pid);
     }
+    // wait for all of them, in whatever order they end; a rank that fails takes the others with it (a peer blocked in the
+    // communicator's initialisation would wait for it for ever) -- exactly the processes forked above, by pid
     int worst = 0;
-    for (pid_t k : kids) {
+    size_t left = kids.size();
+    while (left > 0) {
         int status = 0;
-        if (waitpid(k, &status, 0) < 0) { worst = std::max(worst, 1); continue; }
+        const pid_t k = waitpid(-1, &status, 0);
+        if (k < 0) { worst = std::max(worst, 1); break; }
+        auto it = std::find(kids.begin(), kids.end(), k);
+        if (it == kids.end()) continue;
+        *it = -1; --left;
         const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
         worst = std::max(worst, code);
+        if (code != 0)
+            for (pid_t other : kids) if (other > 0) kill(other, SIGTERM);
     }
     std::remove((std::string(dir) + "/rccl_id").c_str());
     rmdir(dir);

@@ -61,9 +61,21 @@ def launch_ranks(args) -> int:
         logs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out, stderr=subprocess.STDOUT if out else None))
-    rc = 0
-    for r, p in enumerate(procs):
-        rc = max(rc, abs(p.wait()))
+    # wait for all of them; a rank that fails takes the others with it (a peer blocked in the communicator's
+    # initialisation would wait for it for ever) -- exactly the processes started above, by pid
+    rc, live = 0, dict(enumerate(procs))
+    while live:
+        for r, p in list(live.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del live[r]
+            rc = max(rc, abs(code))
+            if code != 0:
+                for q in live.values():
+                    q.terminate()
+        if live:
+            time.sleep(0.05)
     for r, f in enumerate(logs):
         if f:
             f.close()
