@@ -84,7 +84,8 @@ struct b9_ctx {
     int tiles_per_block = 0;   // 0 = auto
     int walkers_per_lane = 1;  // WB template parameter of k_star_like (1 or 2)
     int derive_parts = 0;      // fused sampler step: workgroups per candidate isochrone (0 = one value per thread)
-    int derive_order = 0;      // fused sampler step: >= 0 derivation workgroups lead the grid, < 0 they trail it (B9_DERIVE_ORDER)
+    int derive_order = 1;      // fused sampler step: 1 writers + derivation lead the grid and the heavy-star workgroups follow them (default),
+                               // 0 heavy-star workgroups first, < 0 derivation workgroups trail the hot ones (B9_DERIVE_ORDER)
     bool two_launch_steps = false;   // B9_TWO_LAUNCH_STEPS=1: the derive + star launch pair per step also in given-mass mode
 
     // timing of the dominant kernel

@@ -259,7 +259,7 @@ static hipError_t launch_mcmc_step(const DevPack &pk, const DevStars &st, const 
     }
     const int W = sd.n_walkers;
     const int hot = 8 * ((n_groups + 7) / 8) * W;
-    const int derive_first = derive_order >= 0 ? 1 : 0;
+    const int derive_first = derive_order >= 0 ? (derive_order == 1 ? 2 : 1) : 0;
     const int n_derive = W * 2 * NPOPS * derive_parts;
     const int front = (W * heavy_parts + W + (derive_first ? n_derive : 0) + 7) / 8 * 8;     // heavy, writers, (derivation), pad
     const int back = (!derive_first && sd.derive_next) ? n_derive : 0;

@@ -334,9 +334,8 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
                      sd.iso_stride, sd.mass_cap, part, parts, axr);
 }
 
-// Grid: [heavy-star workgroups][one WRITER per walker][derivation workgroups][pad to 8][hot workgroups]
-// (B9_DERIVE_ORDER < 0: the derivation workgroups trail the grid instead).  The heavy-star chains and the writers -- the
-// new state and the published decision -- start first.
+// Grid: [one WRITER per walker][derivation workgroups][heavy-star workgroups][pad to 8][hot workgroups]
+// (B9_DERIVE_ORDER=0: heavy-star workgroups first; < 0: the derivation workgroups trail the grid instead).
 template <int NFP, int NPOPS>
 __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, int tiles_per_block, int n_groups,
                  int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first, double *smem)
@@ -346,6 +345,14 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
     // role of this workgroup: 0 hot, 1 heavy, 2 derivation (index b within the role), 3 none (padding)
     int role;
     if (b < front_blocks) {
+        // Default order (derive_first == 2): writers and derivation lead, the heavy-star workgroups follow them.  With the
+        // heavy-star workgroups in front (B9_DERIVE_ORDER=0) the hot workgroups at grid positions 512.. -- the third
+        // workgroups of the compute units the first heavy-star workgroups landed on -- ran 4 us longer than their peers and
+        // set the launch's end on the two-population shape (24.1 -> 21.6 us/step); the other shapes do not care.
+        if (derive_first == 2) {
+            const int n_wd = W + n_derive;
+            b = b < n_wd ? b + n_heavy : (b < n_wd + n_heavy ? b - n_wd : b);
+        }
         if (b < n_heavy) role = 1;
         else {
             b -= n_heavy;

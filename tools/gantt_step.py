@@ -24,7 +24,7 @@ truth = synth.default_params(pack_d)
 cl = synth.make_cluster(pack_d, ns, seed=9001 + int(name[1]), truth=truth, wd_frac=wd, n_pops=npops)
 eng = engine.Engine(abi.make_pack(pack_d), abi.make_stars(cl), synth.default_priors(pack_d, truth, npops), abi.make_options(n_pops=npops))
 free = np.array(mcmc.DEFAULT_FREE if npops == 1 else mcmc.DEFAULT_FREE + (abi.P_Y, abi.P_Y2, abi.P_LAMBDA), dtype=np.int32)
-start = synth.walker_params(truth, W, seed=7, n_pops=npops, scale=0.02)
+start = synth.walker_params(truth, W, seed=int(os.environ.get("B9_GANTT_SEED", "7")), n_pops=npops, scale=0.02)
 lp = eng.logpost(start)
 chol = np.diag([mcmc.DEFAULT_STEP[int(k)] for k in free]) * 0.3
 ids = np.arange(W, dtype=np.int32)
