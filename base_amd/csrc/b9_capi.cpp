@@ -371,6 +371,11 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     if (parts <= 0) {
         const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_groups * n_walkers - (long long)n_walkers * ctx->heavy_parts;
         parts = (int)std::max<long long>(2, room / ((long long)n_walkers * 2 * n_pops));
+        // ... but no more than ~3/8 of the CUs' worth of derivation workgroups in all: beyond that they only crowd the hot
+        // ones (two populations x 8 walkers: 3 parts = 96 workgroups 21.0 us/step, 4 parts 21.8, 2 parts 23.4; one
+        // population x 8 walkers is flat between 5 and 6 parts = 80-96 workgroups)
+        const int target = std::max(1, (ctx->n_cu * 3 / 8 + n_walkers * n_pops) / (n_walkers * 2 * n_pops));
+        parts = std::max(2, std::min(parts, target));
     }
     sp.derive_parts = std::max(1, std::min(parts, full_parts));
     // one round: a workgroup's tiles are strided over the slot order (binary and single-star tiles mixed)
