@@ -65,8 +65,9 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         const int is_n = (NPOPS == 2 && k) ? iso[NPOPS - 1].n : iso[0].n;
         int lo1, lo2 = 0;
         double t1, t2 = 0.0;
-        const bool dark1 = !(m1 > 0.0) || m1 < is_mass[0];
-        const bool dark2 = !(m2 > 0.0) || m2 < is_mass[0];
+        const double mass0 = is_mass[0];                    // (read once, unconditionally: `||` made it two branches with an LDS round trip each)
+        const bool dark1 = !(m1 > 0.0) | (m1 < mass0);
+        const bool dark2 = !(m2 > 0.0) | (m2 < mass0);
 #ifdef B9_ABL_NOSEARCH
         lo1 = (int)(m1 * 100.0) % (is_n - 1); t1 = m1 - (int)m1; lo2 = lo1 / 2; t2 = t1;
 #else
