@@ -256,7 +256,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "mcmc_steps_per_s": args.steps / dt,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3: 50k-star x 8-filter synthetic cluster, PARSEC-shaped synthetic pack "
+            "config": {"workload": "BASELINE configs[2] (C2 in DESIGN.md): 50k-star x 8-filter synthetic cluster, PARSEC-shaped synthetic pack "
                                    "(10 FeH x 60 ages x 400 EEPs), given-mass mode, 8 walkers per GPU; one LANE per star "
                                    "(64-star chunks, per-wave shuffle reduction, fixed-order sum of the per-wave partials) -- "
                                    "not one wavefront per star: with one interpolation per star a wave per star would idle 63 "
