@@ -60,6 +60,8 @@ def test_walker_sampler_on_device_recovers_truth():
     {"B9_TILES_PER_BLOCK": "5", "B9_CONTIGUOUS_TILES": "1"},                      # consecutive tiles, ragged last group
     {"B9_TILES_PER_BLOCK": "7"},                                                  # strided tiles, groups without a last tile
     {"B9_TWO_LAUNCH_STEPS": "1"},                                                 # the two-launch step (what marginalised mode runs)
+    {"B9_DERIVE_ORDER": "0", "B9_HEAVY_PARTS": "3"},                               # heavy-star workgroups lead the grid; few, long heavy lists
+    {"B9_DERIVE_ORDER": "1", "B9_HEAVY_PARTS": "16", "B9_DERIVE_PARTS": "2"},      # (default order) many heavy parts, most of them idle
 ])
 @pytest.mark.parametrize("n_steps", [1, 2, 9])
 def test_fused_step_plans_all_give_the_same_chain(monkeypatch, env, n_steps):
