@@ -240,18 +240,14 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
 //     in the same memory round trip as the previous step's accept/reject; only the candidate that decision selects is then
 //     evaluated (evaluating both cost more than it saved: usually only one of them has heavy stars at all).
 //   * It does NOT search for the number of heavy stars: stars are also listed by descending mass (heavy_mass and the
-//     hv_* copies of their data), a wave walks that list in chunks and stops at the first chunk in which no star of either
-//     candidate is above its AGB tip.
-//   * Everything it stages in LDS -- the WD axes and, per (candidate, population), the AGB-tip columns of the four
-//     (FeH, Y) corners -- is ONE flat list; each thread requests its elements at entry, all loads independent: one memory
-//     round trip (it used to be 6 + 4 NPOPS dependent ones).
+//     hv_* copies of their data), a wave walks that list in chunks and stops at the first chunk in which no star of the
+//     evaluated candidate is above its AGB tip ("none at all" is one load: heavy_mass[0] <= tip).
+//   * Everything it stages in LDS -- the searched axes (packed into one run at load time, DevPack::heavy_const), the
+//     AGB-tip table, per (candidate, population) the mass column, per candidate the parameter row -- is requested at
+//     entry, segment by segment, all loads independent: one memory round trip (it used to be 6 + 4 NPOPS dependent ones).
+//   * It is short of REGISTERS (it wants ~190 VGPRs under the kernel's cap of 168): what the chain does not need until
+//     its end is requested there, and with one population the lane view lives in scalar registers.
 // A star occupies G = 2 NPOPS neighbouring lanes: (population, component) -- star_value_lanes.
-// staged elements a thread carries in registers: 256 doubles per unit; longer lists finish in a loop, a second round trip.
-// One population stages ~1900 doubles (8 units; more units cost the short lists their predicated loads' address
-// selects: 16 units measured +0.5 us on 1-population shapes), two populations ~3700 (16 units: -1 us).
-#ifndef B9_HEAVY_STAGE_E
-#define B9_HEAVY_STAGE_E(NPOPS) ((NPOPS) == 2 ? 16 : 8)
-#endif
 template <int NFP, int NPOPS, int NC, class SelectFn>
 __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *const (&hdr)[NC],
                                             const double *const (&iso_data)[NC], long long iso_stride, int mass_cap,
