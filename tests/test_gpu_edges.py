@@ -305,3 +305,41 @@ def test_load_stars_rejects_non_finite_photometry():
     st2 = abi.make_stars(c2)
     got = engine.Engine(pack, st2, priors, options).logpost(cl["truth"][None, :])
     assert np.isfinite(got[0]) and _err(got, oracle.Oracle(pack, st2, priors, options).logpost(cl["truth"][None, :])) <= 1e-9
+
+
+@pytest.mark.parametrize("case", ["big_grid", "no_wd_tables", "big_grid_two_pops"])
+def test_heavy_role_staging_variants(case):
+    """The heavy-star role's LDS staging has two layouts the BASELINE shapes never reach: a (FeH, Y, age) grid too large
+    for the whole AGB-tip table in LDS (> 2048 isochrones: only the candidates' corner columns are staged, after the
+    headers are known), and a pack without WD tables (the packed axes are the age axis alone; stars above the tip have
+    no flux).  Log-posterior and the fused sampler's chain against the oracle / the host twin."""
+    from base_amd import engine, mcmc
+    if case == "no_wd_tables":
+        pack_d = synth.make_pack("parsec", 8, wd=False, n_feh=4, n_age=8, n_eep=90)
+        n_pops, wd_frac = 1, 0.0
+    else:
+        n_pops = 2 if case.endswith("two_pops") else 1
+        pack_d = synth.make_pack("parsec", 8, n_y=3, n_feh=13, n_age=60, n_eep=40)      # 13 x 3 x 60 = 2340 isochrones
+        wd_frac = 0.06
+    truth = synth.default_params(pack_d)
+    cl = synth.make_cluster(pack_d, 700, seed=31, truth=truth, wd_frac=wd_frac, n_pops=n_pops)
+    pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
+    priors, options = synth.default_priors(pack_d, truth, n_pops), abi.make_options(abi.MODE_GIVEN_MASS, n_pops, 4, 4)
+    eng = engine.Engine(pack, stars, priors, options)
+    params = synth.walker_params(truth, 4, seed=5, n_pops=n_pops, scale=0.2)
+    got = eng.logpost(params, perstar=True)
+    want = oracle.Oracle(pack, stars, priors, options).logpost(params, perstar=True)
+    assert _err(got[1], want[1]) <= 1e-9 and _err(got[0], want[0]) <= 1e-9
+    if case != "no_wd_tables":
+        tips = [eng.derive_isochrone(params[0])[3]]
+        assert (cl["mass1"] > min(tips)).sum() >= 10                              # the role had stars to evaluate
+    free = np.array(mcmc.DEFAULT_FREE if n_pops == 1 else mcmc.DEFAULT_FREE + (abi.P_Y, abi.P_Y2, abi.P_LAMBDA))
+    chol = np.diag([mcmc.DEFAULT_STEP[int(k)] for k in free]) * 0.3
+    start = synth.walker_params(truth, 3, seed=6, n_pops=n_pops, scale=0.05)
+    lp0 = eng.logpost(start)
+    ids = np.arange(3)
+    host = mcmc.HostBlockRunner(eng.logpost).run(start, lp0, ids, free, chol, 9, 1000, 12)
+    dev = mcmc.DeviceBlockRunner(eng).run(start, lp0, ids, free, chol, 9, 1000, 12)
+    assert dev[4] == host[4]
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
