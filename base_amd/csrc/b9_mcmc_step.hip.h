@@ -34,12 +34,8 @@ struct DecideLoads {           // everything one wave's decision reads (register
 // indices instead of branches: the state words, the writer's flag, the first 64 K hot partials and the
 // heavy-star partials of BOTH candidate slots (which one counts is a state word).  One memory round trip;
 // the launch's first few microseconds are a chain of such round trips and nothing else.
-// `active`: the wave that will take the decision.  The others make the same loads from ONE address each (a single cache
-// line per wave, nothing to speak of) instead of branching around them: behind a branch the loaded words met the
-// "not loaded" defaults in a phi, the compiler made the writer's flag scalar right there (v_readfirstlane -- a wait), and
-// the first wave sat out a whole memory round trip before it requested its stars: two trips where one was meant.
 template <bool SHORTCUT>
-__device__ __forceinline__ void decide_issue(const StepDev &sd, int w, DecideLoads &dl, bool active = true)
+__device__ __forceinline__ void decide_issue(const StepDev &sd, int w, DecideLoads &dl)
 {
     const int lane = threadIdx.x & 63;
     const double *in = step_state_in(sd, w);
@@ -50,10 +46,10 @@ __device__ __forceinline__ void decide_issue(const StepDev &sd, int w, DecideLoa
 #pragma unroll
     for (int k = 0; k < B9_DECIDE_K; ++k) {
         const int j = lane + 64 * k;
-        dl.v[k] = part[active ? (j < n_hot ? j : n_hot - 1) : 0];
+        dl.v[k] = part[j < n_hot ? j : n_hot - 1];
     }
     const int hl = lane < sd.heavy_parts ? lane : sd.heavy_parts - 1;
-    dl.h0 = part[active ? n_hot + hl : 0]; dl.h1 = part[active ? n_hot + sd.heavy_parts + hl : 0];
+    dl.h0 = part[n_hot + hl]; dl.h1 = part[n_hot + sd.heavy_parts + hl];
 }
 
 template <bool SHORTCUT>
@@ -144,8 +140,8 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     // columns need anyway: a quarter of the partial-sum traffic at the launch's start.  Its loads leave first.
     __shared__ int s_sel;
     const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
-    DecideLoads dl;
-    decide_issue<B9_SHORTCUT>(sd, w, dl, first_wave);
+    DecideLoads dl = {};
+    if (first_wave) decide_issue<B9_SHORTCUT>(sd, w, dl);
     int i = tile0 * 256 + tid;
     int il = i < st.n_pad ? i : st.n_pad - 1;
     double m1 = st.mass1[il], q = st.q[il], ea = st.ea[il];
@@ -258,8 +254,8 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
     __shared__ double s_par[B9_NPARAM], s_z[12], s_cur[B9_NPARAM], s_prop[B9_NPARAM];
     // (only the first wave's threads use the decision; its loads leave first)
     const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
-    DecideLoads dl;
-    decide_issue<false>(sd, w, dl, first_wave);
+    DecideLoads dl = {};
+    if (first_wave) decide_issue<false>(sd, w, dl);
     const AxisRegs axr = preload_axis(pk);                 // first round trip, needs no parameter
     // everything the role reads before the isochrone tables is requested now, in one round trip
     const double *in = step_state_in(sd, w);
@@ -392,8 +388,8 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
         double *const out[2] = {base + part, base + heavy_parts + part};
         // the first wave decides (its loads leave before everything else of the role); the others get it through LDS
         const bool first_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
-        DecideLoads dl;
-        decide_issue<B9_SHORTCUT>(sd, w, dl, first_wave);
+        DecideLoads dl = {};
+        if (first_wave) decide_issue<B9_SHORTCUT>(sd, w, dl);
         auto decide = [&] {
             __shared__ int s_hsel;
             if (first_wave) {
