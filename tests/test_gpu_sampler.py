@@ -90,6 +90,58 @@ def test_device_sampler_equals_the_host_twin_and_one_rank_rccl():
     np.testing.assert_array_equal(st_rccl["chol"], st_dev["chol"])
 
 
+def test_two_ranks_on_one_gpu_match_one_rank():
+    """World size 2 through the PRODUCT block runner (device-resident fused steps, pipelined blocks) on one GPU: two
+    threads, each with its own context and half of the walkers; only the all-gather is bridged by the test (a callback
+    exchange -- RCCL refuses two ranks on one device).  Chains, proposal factor, scale and the replicated ensemble
+    state are the bits of the one-rank run."""
+    import threading
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=3000, wd_frac=0.02, small=False, seed=8)
+    start = synth.walker_params(cl["truth"], 8, seed=42, scale=0.05)
+    eng1 = engine.Engine(pack, stars, priors, options)
+    st1, samples1, lps1 = _device_run(eng1, hostlib.Exchange.local(), start)
+    eng1.close()
+
+    slots, bar = [None, None], threading.Barrier(2, timeout=120)
+
+    def make_gather(rank):
+        def gather(rows):
+            slots[rank] = np.array(rows, copy=True)
+            bar.wait()
+            out = np.concatenate([slots[0], slots[1]])
+            bar.wait()                                   # nobody overwrites a slot the other rank still reads
+            return out
+        return gather
+
+    results, errors = [None, None], []
+
+    def rank_main(rank):
+        try:
+            eng = engine.Engine(pack, stars, priors, options)
+            ex = hostlib.Exchange.callback(make_gather(rank), rank, 2)
+            results[rank] = _device_run(eng, ex, start)
+            eng.close()
+        except BaseException as e:                       # noqa: BLE001  (reported by the main thread)
+            errors.append(e)
+            bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    (st_a, samples_a, lps_a), (st_b, samples_b, lps_b) = results
+    np.testing.assert_array_equal(np.concatenate([samples_a, samples_b], axis=1), samples1)
+    np.testing.assert_array_equal(np.concatenate([lps_a, lps_b], axis=1), lps1)
+    for st in (st_a, st_b):
+        np.testing.assert_array_equal(st["chol"], st1["chol"])
+        assert st["scale"] == st1["scale"]
+        np.testing.assert_array_equal(st["all_params"], st1["all_params"])
+        np.testing.assert_array_equal(st["all_logpost"], st1["all_logpost"])
+
+
 def test_marginalised_mode_through_the_sampler():
     """Marginalised mode has no fused step: synchronous two-launch blocks, rows condensed on the host from the chain."""
     from base_amd import engine
