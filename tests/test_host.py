@@ -319,3 +319,26 @@ def test_mcmc_cli_marginalised_mode(hostlib, tmp_path):
     # the .res holds 6 decimals of each parameter: compare at the rounded position, allowing for the posterior's slope
     # over half a unit of the last place (|dlogPost/dlogAge| ~ 1e3-1e4 here)
     assert abs(res[-1, -2] - want) <= 1e-2, (res[-1, -2], want)
+
+
+def test_mcmc_cli_without_a_gpu_fails_loudly_and_at_once(hostlib, tmp_path):
+    """The product has no CPU fallback: on a box without a HIP device the sampler CLI says so and exits non-zero -- also
+    as `--gpus 2`, where the launcher must bring every rank down promptly instead of leaving one blocked.  (Skipped where a
+    GPU is present: there the same command simply runs.)"""
+    import time
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    pack_d = synth.make_pack("dsed", 8, n_feh=4, n_age=8, n_eep=90)
+    truth = synth.default_params(pack_d)
+    cl = synth.make_cluster(pack_d, 60, seed=2, truth=truth)
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    phot = synth.write_phot(cl, pack_d["filters"], str(tmp_path / "c.phot"))
+    y = synth.write_yaml(str(tmp_path / "base9.yaml"), phot, root, str(tmp_path / "run"), truth, ms_model="dsed", burn=20, run=10, walkers=4)
+    for extra in ([], ["--gpus", "2"]):
+        t0 = time.time()
+        r = _cli("singlePopMcmc", "--config", y, *extra)
+        assert r.returncode != 0, r.stdout
+        assert "no HIP device" in r.stderr or "hip" in r.stderr.lower(), r.stderr
+        assert time.time() - t0 < 60
+        assert not os.path.exists(str(tmp_path / "run.res"))
