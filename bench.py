@@ -45,7 +45,8 @@ CLOCK_GHZ, N_SIMD = 2.4, 1024   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GH
 N_STARS, N_FILT, WALKERS_PER_GPU = 50000, 8, 8
 MCMC_BLOCK = 100        # steps between adaptation points (= between all-gathers)
 TIMING_EVERY = 25       # a HIP-event bracket opens at every 25th launch of the dominant kernel in the timed region and spans 8 launches
-PREWARM_STEPS = 300     # untimed, BEFORE the W warm-up steps: clocks, first touch of every buffer, RCCL channels
+PREWARM_STEPS = 1000    # untimed, BEFORE the W warm-up steps: clocks, first touch of every buffer, RCCL channels, and the sampler's
+                        # own burn-in (10 adaptation blocks: the timed steps run with the adapted proposal, as a real run's do)
 PROFILE_TAG = "r02"     # profiles/<tag>_summary.json: rocprofv3 PMC passes of this command (tools/profile_round.sh)
 
 
