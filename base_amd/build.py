@@ -53,6 +53,18 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return HIP_LIB
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources and the ABI header, in name order: which build a measured profile belongs to
+    (tools/profile_summary.py stores it; bench.py drops the profile's counters when the tree it runs in has another)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
+    for f in files + [os.path.join(ROOT, "include", "base9_hip.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
     try:

@@ -72,7 +72,6 @@ struct b9_ctx {
     } slot[2];
     int next_slot = 0, last_slot = -1;
     double *h_lp = nullptr, *h_lp_dev = nullptr;   // b9_logpost: 8 log-posteriors in mapped pinned host memory (host / device view)
-    bool no_kernarg_rows = false;    // B9_NO_KERNARG_ROWS=1: always upload the rows with a copy
     size_t mcmc_cap = 0;
 
     // launch plan
@@ -86,7 +85,11 @@ struct b9_ctx {
     int derive_parts = 0;      // fused sampler step: workgroups per candidate isochrone (0 = one value per thread)
     int derive_order = 1;      // fused sampler step: 1 writers + derivation lead the grid and the heavy-star workgroups follow them (default),
                                // 0 heavy-star workgroups first, < 0 derivation workgroups trail the hot ones (B9_DERIVE_ORDER)
-    bool two_launch_steps = false;   // B9_TWO_LAUNCH_STEPS=1: the derive + star launch pair per step also in given-mass mode
+    bool two_launch_steps = false;   // b9_tuning.two_launch_steps: the derive + star launch pair per step also in given-mass mode
+    bool contiguous_tiles = false;   // b9_tuning.contiguous_tiles: a hot workgroup's tiles are consecutive even in a one-round plan
+    bool plan_debug = false;         // b9_tuning.plan_debug: print the fused step's launch plan to stderr when it changes
+    bool chunk_bounds = true;        // marginalised kernel: chunk-level pruning table (b9_tuning.no_chunk_bounds turns it off)
+    int heavy_parts_fixed = 0;       // b9_tuning.heavy_parts: 0 = sized from the catalogue (check_ready)
 
     // timing of the dominant kernel
     int timing = 0;            // 0 off, n > 0: bracket every n-th launch of the dominant kernel with events
@@ -346,7 +349,6 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     if (ctx->step_occ_key != key) {
         int per_cu = 0;
         if (b9k_mcmc_step_occupancy(ctx->pk, n_pops, ctx->mass_cap, &per_cu) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (const char *s = getenv("B9_STEP_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(s));      // experiments only
         ctx->step_blocks_per_cu = per_cu;
         ctx->step_occ_key = key;
     }
@@ -363,10 +365,6 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
     sp.plan.tiles_per_block = tpb;
     sp.plan.n_groups = (n_tiles + tpb - 1) / tpb;
-    if (const char *e = getenv("B9_N_GROUPS")) {         // experiments: tile groups per walker (strided plans only)
-        sp.plan.n_groups = std::max(1, std::min(atoi(e), n_tiles));
-        sp.plan.tiles_per_block = tpb = (n_tiles + sp.plan.n_groups - 1) / sp.plan.n_groups;
-    }
     int parts = ctx->derive_parts;
     if (parts <= 0) {
         const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_groups * n_walkers - (long long)n_walkers * ctx->heavy_parts;
@@ -379,14 +377,54 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     }
     sp.derive_parts = std::max(1, std::min(parts, full_parts));
     // one round: a workgroup's tiles are strided over the slot order (binary and single-star tiles mixed)
-    sp.strided = (long long)sp.plan.n_groups * n_walkers <= slots && !getenv("B9_CONTIGUOUS_TILES");
-    if (getenv("B9_PLAN_DEBUG") && ctx->plan_debug_key != key * 64 + n_walkers) {
+    sp.strided = (long long)sp.plan.n_groups * n_walkers <= slots && !ctx->contiguous_tiles;
+    if (ctx->plan_debug && ctx->plan_debug_key != key * 64 + n_walkers) {
         ctx->plan_debug_key = key * 64 + n_walkers;
         std::fprintf(stderr, "b9 step plan: %d CUs x %d workgroups = %d slots; %d walkers x %d tile groups (%d tiles each, %s) + %d heavy + %d derivation workgroups (%d parts)\n",
                      ctx->n_cu, ctx->step_blocks_per_cu, slots, n_walkers, sp.plan.n_groups, tpb, sp.strided ? "strided" : "contiguous",
                      n_walkers * ctx->heavy_parts, n_walkers * 2 * n_pops * sp.derive_parts, sp.derive_parts);
     }
     return sp;
+}
+
+// b9_tuning -> the context's plan fields (0 = leave automatic)
+void apply_tuning(b9_ctx *ctx, const b9_tuning &t)
+{
+    ctx->tiles_per_block = std::max(0, t.tiles_per_block);
+    ctx->derive_parts = std::max(0, t.derive_parts);
+    ctx->derive_order = t.derive_order == 2 ? 0 : (t.derive_order == 3 ? -1 : 1);
+    ctx->heavy_parts_fixed = std::max(0, t.heavy_parts);
+    ctx->walkers_per_lane = t.walkers_per_lane >= 2 ? 2 : 1;
+    ctx->contiguous_tiles = t.contiguous_tiles != 0;
+    ctx->two_launch_steps = t.two_launch_steps != 0;
+    ctx->chunk_bounds = t.no_chunk_bounds == 0;
+    ctx->timing_group = t.timing_group > 0 ? t.timing_group : 8;
+    ctx->plan_debug = t.plan_debug != 0;
+    ctx->step_occ_key = -1; ctx->plan_debug_key = -1;
+}
+
+// The B9_* environment overrides of the same fields (true when any is set).  Parsed once per context, at creation.
+bool tuning_from_env(b9_tuning *t)
+{
+    bool any = false;
+    auto num = [&](const char *name, int32_t *dst, bool flip_order = false) {
+        const char *v = getenv(name);
+        if (!v || !*v) return;
+        const int x = atoi(v);
+        *dst = flip_order ? (x == 0 ? 2 : (x < 0 ? 3 : 1)) : x;      // B9_DERIVE_ORDER keeps its historical coding (1, 0, < 0)
+        any = true;
+    };
+    num("B9_TILES_PER_BLOCK", &t->tiles_per_block);
+    num("B9_DERIVE_PARTS", &t->derive_parts);
+    num("B9_DERIVE_ORDER", &t->derive_order, true);
+    num("B9_HEAVY_PARTS", &t->heavy_parts);
+    num("B9_WALKERS_PER_LANE", &t->walkers_per_lane);
+    num("B9_CONTIGUOUS_TILES", &t->contiguous_tiles);
+    num("B9_TWO_LAUNCH_STEPS", &t->two_launch_steps);
+    num("B9_NO_CHUNK_BOUNDS", &t->no_chunk_bounds);
+    num("B9_TIMING_GROUP", &t->timing_group);
+    num("B9_PLAN_DEBUG", &t->plan_debug);
+    return any;
 }
 
 }  // namespace
@@ -419,7 +457,7 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     // get in at the next kernel boundary instead of waiting behind the whole train (measured with a 1-rank RCCL
     // group: the gather took 1.4 ms = the rest of the block; B9_STREAM_PRIORITY=default restores the default).
     int least = 0, greatest = 0;
-    const char *prio = getenv("B9_STREAM_PRIORITY");
+    const char *prio = getenv("B9_STREAM_PRIORITY");       // (read here: the stream is made before any b9_set_tuning could run)
     const bool low = !(prio && std::string(prio) == "default") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
     const hipError_t se = low ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, least)
                               : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -428,13 +466,10 @@ int b9_ctx_create(int device_id, b9_ctx **out)
     }
     for (int k = 0; k < 12; ++k) { ctx->pr.mean[k] = 0.0; ctx->pr.var[k] = 0.0; }
     ctx->pr.log_age_min = -INFINITY; ctx->pr.log_age_max = INFINITY;
-    if (const char *s = getenv("B9_TILES_PER_BLOCK")) ctx->tiles_per_block = atoi(s);
-    if (const char *s = getenv("B9_WALKERS_PER_LANE")) ctx->walkers_per_lane = atoi(s) >= 2 ? 2 : 1;
-    if (const char *s = getenv("B9_DERIVE_PARTS")) ctx->derive_parts = atoi(s);
-    if (const char *s = getenv("B9_TIMING_GROUP")) ctx->timing_group = std::max(1, atoi(s));
-    if (const char *s = getenv("B9_NO_KERNARG_ROWS")) ctx->no_kernarg_rows = atoi(s) != 0;
-    if (const char *s = getenv("B9_DERIVE_ORDER")) ctx->derive_order = atoi(s);
-    if (const char *s = getenv("B9_TWO_LAUNCH_STEPS")) ctx->two_launch_steps = atoi(s) != 0;
+    {   // environment overrides of the launch-plan tuning, read ONCE, here (include/base9_hip.h: b9_tuning documents them)
+        b9_tuning t{};
+        if (tuning_from_env(&t)) apply_tuning(ctx, t);
+    }
     *out = ctx;
     return B9_OK;
 }
@@ -642,6 +677,16 @@ int b9_set_priors(b9_ctx *ctx, const b9_priors *p)
     return B9_OK;
 }
 
+int b9_set_tuning(b9_ctx *ctx, const b9_tuning *t)
+{
+    if (!ctx) return B9_ERR_INVALID;
+    for (auto &sl : ctx->slot)
+        if (sl.in_flight) return fail(ctx, B9_ERR_STATE, "b9_set_tuning: a block is outstanding");
+    b9_tuning z{};
+    apply_tuning(ctx, t ? *t : z);
+    return B9_OK;
+}
+
 int b9_set_options(b9_ctx *ctx, const b9_options *o)
 {
     if (!ctx || !o) return B9_ERR_INVALID;
@@ -673,13 +718,6 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
                         hipStream_t stream)
 {
     const int n_pops = ctx->opt.n_pops;
-    if (ctx->opt.mode == B9_MODE_MARGINALISED) {
-        const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
-        const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
-        HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, nullptr, stream));
-        return B9_OK;
-    }
     size_t slot = 0;
     const bool timed = ctx->timing > 0 && (ctx->launch_no++ % (unsigned)ctx->timing) == 0;
     if (timed) {
@@ -694,9 +732,16 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
         ctx->ev_count[slot] = 1;
         HIPCHK(ctx, hipEventRecord(ctx->ev_start[slot], stream));
     }
-    HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                              n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, ctx->st.n_pad, d_perstar,
-                              plan.tiles_per_block, plan.n_groups, ctx->heavy_parts, stream));
+    if (ctx->opt.mode == B9_MODE_MARGINALISED) {
+        const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
+        const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
+        HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
+                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, nullptr, ctx->chunk_bounds, stream));
+    } else {
+        HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
+                                  n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, ctx->st.n_pad, d_perstar,
+                                  plan.tiles_per_block, plan.n_groups, ctx->heavy_parts, stream));
+    }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
     return B9_OK;
 }
@@ -738,7 +783,7 @@ static int check_ready(b9_ctx *ctx)
         // a lane evaluates one descriptor, rarely two.
         const int est = (ctx->n_wd_stage + ctx->hs.n / 50) * 2 * ctx->opt.n_pops;
         ctx->heavy_parts = std::max(4, std::min(16, (est + 255) / 256));
-        if (const char *e = getenv("B9_HEAVY_PARTS")) ctx->heavy_parts = std::max(1, std::min(64, atoi(e)));
+        if (ctx->heavy_parts_fixed > 0) ctx->heavy_parts = std::max(1, std::min(64, ctx->heavy_parts_fixed));
     }
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && ctx->hs.min_mass1 <= 0.0)
         return fail(ctx, B9_ERR_INVALID, "given-mass mode needs mass1 > 0 for every star (the marginalised mode takes mass1 as a hint only)");
@@ -1077,7 +1122,7 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lp, sizeof(double) * 8, hipHostMallocMapped));
         HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_lp_dev, ctx->h_lp, 0));
     }
-    const bool small = n_walkers <= 8 && !ctx->no_kernarg_rows;
+    const bool small = n_walkers <= 8;
     if (small) {
         rc = launch_logpost(ctx, ctx->d_params, n_walkers, ctx->h_lp_dev, out_perstar ? ctx->d_perstar : nullptr, ctx->stream, params);
         if (rc) return rc;
@@ -1126,7 +1171,7 @@ int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t s
         B9MargSample smp{d_out, d_out + per, d_out + 2 * per, d_pop, (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), (long long)(row0 + r0)};
         // the kernel indexes its outputs [row][n_stars] with the launch's own row count: rows are contiguous for any m
         if (e == hipSuccess) e = b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params, m, n_pops,
-                                               ctx->d_partial, nullptr, K, Q, &smp, s);
+                                               ctx->d_partial, nullptr, K, Q, &smp, ctx->chunk_bounds, s);
         const size_t cnt = (size_t)m * n, o = (size_t)r0 * n;
         if (e == hipSuccess) e = hipMemcpyAsync(out_mass + o, d_out, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(out_ratio + o, d_out + per, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
@@ -1176,6 +1221,16 @@ int b9_bytes_per_star_eval(const b9_ctx *ctx)
     if (!ctx || !ctx->have_pack) return 0;
     // obs + 1/sigma^2 per (real) filter, mass1, q, c0, la (8 B each), flags (4 B)
     return 16 * ctx->pk.nf + 4 * 8 + 4;
+}
+
+int b9_step_tiles_per_block(b9_ctx *ctx, int32_t n_walkers)
+{
+    if (!ctx || n_walkers < 1) return B9_ERR_INVALID;
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)ctx->st.n_pad * n_walkers, false);   // (the plan keys on mass_cap)
+    if (rc) return rc;
+    return make_step_plan(ctx, n_walkers, ctx->opt.n_pops).plan.tiles_per_block;
 }
 
 int b9_enable_timing(b9_ctx *ctx, int on)

@@ -171,13 +171,13 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
 template <int NFP, int NPOPS, bool SAMPLE>
 static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                      long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                     double *vals, double *perstar, int K, int Q, const B9MargSample *smp, hipStream_t stream)
+                                     double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool chunk_bounds, hipStream_t stream)
 {
     size_t lds = sizeof(double) * (size_t)NPOPS * mass_cap * (NFP + 1);
     int chunk_cap = ((mass_cap - 1) * K + 63) / 64 + 1;                     // chunk-bound table, when LDS has room for it
     // three planes + per wave: 2 NFP doubles of the star's offsets/weights and a list of surviving chunks
     const size_t with_table = lds + sizeof(double) * ((size_t)NPOPS * chunk_cap * NFP * 3 + 4 * 2 * NFP) + sizeof(int) * 4 * ((size_t)chunk_cap + 1);
-    if (with_table <= 160 * 1024 && !getenv("B9_NO_CHUNK_BOUNDS")) lds = with_table; else chunk_cap = 0;
+    if (with_table <= 160 * 1024 && chunk_bounds) lds = with_table; else chunk_cap = 0;
     auto kern = k_star_marg<NFP, NPOPS, SAMPLE>;
     MargSample ms{};
     if (SAMPLE) { ms.mass = smp->mass; ms.ratio = smp->ratio; ms.member = smp->member; ms.pop = smp->pop; ms.k0 = smp->k0; ms.k1 = smp->k1; ms.row0 = smp->row0; }
@@ -194,17 +194,17 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
 template <int NFP, int NPOPS>
 static hipError_t launch_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                    long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                   double *vals, double *perstar, int K, int Q, const B9MargSample *smp, hipStream_t stream)
+                                   double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool chunk_bounds, hipStream_t stream)
 {
-    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, stream)
-               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, stream);
+    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, chunk_bounds, stream)
+               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, chunk_bounds, stream);
 }
 
 hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
-                         double *vals, double *perstar, int K, int Q, const B9MargSample *smp, hipStream_t stream)
+                         double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool chunk_bounds, hipStream_t stream)
 {
-#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, stream
+#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, chunk_bounds, stream
 #define SM2(NFP) launch_star_marg<NFP, 2>(SM_ARGS)
 #define SM1(NFP) launch_star_marg<NFP, 1>(SM_ARGS)
     B9_SWITCH_NFP(SM2, SM1)

@@ -79,6 +79,15 @@ class Engine:
         self._check(self.lib.b9_set_options(self._ctx, C.byref(options)))
         self.options = options
 
+    def set_tuning(self, **fields) -> None:
+        """b9_set_tuning: launch-plan fields of abi.b9_tuning by name (tiles_per_block=3, ...); no argument = automatic."""
+        t = abi.b9_tuning()
+        for k, v in fields.items():
+            if not hasattr(t, k):
+                raise AttributeError(f"b9_tuning has no field {k}")
+            setattr(t, k, int(v))
+        self._check(self.lib.b9_set_tuning(self._ctx, C.byref(t)))
+
     # -- hot path -------------------------------------------------------------------------
     def logpost(self, params: np.ndarray, perstar: bool = False):
         params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, abi.B9_NPARAM)
@@ -166,6 +175,12 @@ class Engine:
     # -- introspection --------------------------------------------------------------------
     def bytes_per_star_eval(self) -> int:
         return int(self.lib.b9_bytes_per_star_eval(self._ctx))
+
+    def step_tiles_per_block(self, n_walkers: int) -> int:
+        r = int(self.lib.b9_step_tiles_per_block(self._ctx, int(n_walkers)))
+        if r < 0:
+            self._check(r)
+        return r
 
     def device_id(self) -> int:
         return int(self.lib.b9_device_id(self._ctx))

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cctype>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +18,26 @@
 #include <unistd.h>
 
 namespace b9h {
+
+// One string per launch, shared by its ranks: the launcher's own (B9_LAUNCH_NONCE), or torchrun's run id + restart count.
+std::string launch_nonce()
+{
+    if (const char *n = std::getenv("B9_LAUNCH_NONCE")) return n;
+    const char *run = std::getenv("TORCHELASTIC_RUN_ID"), *restart = std::getenv("TORCHELASTIC_RESTART_COUNT");
+    std::string s = std::string(run ? run : "0") + "_" + (restart ? restart : "0");
+    for (char &c : s) if (!(std::isalnum((unsigned char)c) || c == '_' || c == '-')) c = '_';
+    return s;
+}
+
+// Test hook (tests/test_launcher.py): B9_TEST_STALL="<where>:<rank>" parks that rank for ever at the named point, so that
+// the launchers' start-up deadline can be exercised without a GPU or a real RCCL hang.
+void test_stall(const char *where, int rank)
+{
+    const char *v = std::getenv("B9_TEST_STALL");
+    if (!v) return;
+    if (std::string(v) == std::string(where) + ":" + std::to_string(rank))
+        for (;;) std::this_thread::sleep_for(std::chrono::seconds(3600));
+}
 
 namespace {
 
@@ -49,13 +71,25 @@ class RcclExchange final : public Exchange {
     RcclExchange(int rank, int world, const std::string &dir, int device, double timeout_s) : rank_(rank), world_(world), device_(device)
     {
         if (world < 1 || rank < 0 || rank >= world) fail("bad rank / world");
+        test_stall("before-init", rank);
         HIPX(hipSetDevice(device));
         ncclUniqueId id;
-        const std::string path = dir + "/rccl_id";
+        // The id file carries this LAUNCH's nonce in its name, so an id a crashed or restarted attempt left in a reused
+        // directory (torchrun elastic restart, a user-supplied B9_DIST_DIR) is never read; the directory must be ours.
+        const std::string path = dir + "/rccl_id." + launch_nonce();
         if (rank == 0) {
             NCCLX(ncclGetUniqueId(&id));
-            ::mkdir(dir.c_str(), 0700);                       // may exist already (the launcher made it)
+            if (::mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) fail("cannot create " + dir);
+        }
+        {   // (ranks > 0 check it once it exists: see the wait below)
+            struct stat sb;
+            if (::stat(dir.c_str(), &sb) == 0 && (sb.st_uid != ::geteuid() || (sb.st_mode & 022)))
+                fail(dir + " is not owned by this user or is writable by others: refusing to bootstrap RCCL through it");
+        }
+        if (rank == 0) {
             const std::string tmp = path + ".tmp";
+            std::remove(path.c_str());
+            std::remove(tmp.c_str());
             FILE *f = std::fopen(tmp.c_str(), "wb");
             if (!f) fail("cannot write " + tmp);
             const size_t n = std::fwrite(&id, 1, sizeof id, f);
@@ -74,7 +108,12 @@ class RcclExchange final : public Exchange {
                     fail("rank " + std::to_string(rank) + " timed out waiting for " + path);
                 std::this_thread::sleep_for(std::chrono::milliseconds(5));
             }
+            struct stat sb;
+            if (::stat(dir.c_str(), &sb) != 0 || sb.st_uid != ::geteuid() || (sb.st_mode & 022))
+                fail(dir + " is not owned by this user or is writable by others: refusing to bootstrap RCCL through it");
         }
+        // (ncclCommInitRank has no deadline of its own: a launcher that made B9_DIST_DIR watches for the ready markers
+        //  written below and ends the launch when they do not appear in time -- cli_common.cpp, bench.py)
         NCCLX(ncclCommInitRank(&comm_, world, id, rank));
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
@@ -86,6 +125,31 @@ class RcclExchange final : public Exchange {
         HIPX(hipHostMalloc((void **)&h_scalar_, sizeof(double) * 2, hipHostMallocDefault));
         barrier();                                            // everyone has read the id
         if (rank == 0) std::remove(path.c_str());
+        // what the communicator itself says about the group: its rank count, and every rank's GPU (PCI bus id),
+        // all-gathered through it -- a record that N distinct devices took part, not an echo of the arguments
+        NCCLX(ncclCommCount(comm_, &comm_count_));
+        {
+            constexpr int L = 32;
+            char mine[L] = {0};
+            HIPX(hipDeviceGetPCIBusId(mine, L, device));
+            char *d_all = nullptr;
+            HIPX(hipMalloc((void **)&d_all, (size_t)L * world));
+            HIPX(hipMemcpyAsync(d_all + (size_t)L * rank, mine, L, hipMemcpyHostToDevice, stream_));
+            NCCLX(ncclAllGather(d_all + (size_t)L * rank, d_all, L, ncclChar, comm_, stream_));
+            std::vector<char> all((size_t)L * world);
+            HIPX(hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, stream_));
+            HIPX(hipStreamSynchronize(stream_));
+            (void)hipFree(d_all);
+            for (int r = 0; r < world; ++r) {
+                all[(size_t)L * r + L - 1] = '\0';
+                devices_ += (r ? "," : "") + std::string(&all[(size_t)L * r]);
+            }
+        }
+        test_stall("after-init", rank);
+        {   // ready marker for the launcher's start-up deadline
+            const std::string ready = dir + "/ready." + std::to_string(rank);
+            if (FILE *f = std::fopen(ready.c_str(), "w")) std::fclose(f);
+        }
     }
 
     ~RcclExchange() override
@@ -108,6 +172,9 @@ class RcclExchange final : public Exchange {
     int rank() const override { return rank_; }
     int world() const override { return world_; }
     const char *name() const override { return "RCCL all-gather (ncclAllGather over xGMI, device buffers, own high-priority stream)"; }
+
+    int comm_ranks() const override { return comm_count_; }
+    std::string devices() const override { return devices_; }
 
     bool reads_device_rows() const override { return true; }
     bool start_device(int slot, const double *d_rows, void *ready_event, size_t count) override
@@ -181,7 +248,8 @@ class RcclExchange final : public Exchange {
         HIPX(hipEventRecord(s.done, stream_));
     }
 
-    int rank_, world_, device_;
+    int rank_, world_, device_, comm_count_ = 0;
+    std::string devices_;
     ncclComm_t comm_ = nullptr;
     hipStream_t stream_ = nullptr;
     Slot slot_[2];
@@ -203,6 +271,12 @@ std::string default_bootstrap_dir()
     const char *port = std::getenv("MASTER_PORT");
     const char *tmp = std::getenv("TMPDIR");
     return std::string(tmp && *tmp ? tmp : "/tmp") + "/b9dist_" + std::to_string((long)getppid()) + "_" + (port ? port : "0");
+}
+
+bool forced_ranks()
+{
+    const char *v = std::getenv("B9_FORCE_RANKS");
+    return v && std::atoi(v) != 0;
 }
 
 void rank_from_env(int &rank, int &world, int &local_rank)

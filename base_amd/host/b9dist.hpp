@@ -32,14 +32,20 @@ class Exchange {
     virtual double all_reduce_max(double v) { return v; }
     virtual void barrier() {}
     virtual const char *name() const = 0;
+    // What the communicator reports about itself: its rank count (ncclCommCount; 0 = no communicator) and the PCI bus
+    // ids of the ranks' GPUs in rank order, comma-separated, gathered THROUGH the communicator.
+    virtual int comm_ranks() const { return 0; }
+    virtual std::string devices() const { return ""; }
 };
 
 // One rank: every "exchange" is a copy.
 std::unique_ptr<Exchange> make_local_exchange();
 
 // RCCL over xGMI.  Collective among `world` processes, one per GPU: rank 0 creates the unique id and publishes it as
-// <dir>/rccl_id (written under a temporary name, then renamed); the others wait for the file (up to timeout_s), and
-// every rank calls ncclCommInitRank on `device`.  The exchange owns a non-blocking HIP stream of the HIGHEST priority
+// <dir>/rccl_id.<nonce> (written under a temporary name, then renamed; the nonce names the launch -- B9_LAUNCH_NONCE, or
+// torchrun's run id and restart count -- so an id left behind by an earlier attempt is never picked up; <dir> must
+// belong to this user and not be writable by others); the others wait for the file (up to timeout_s), and every rank
+// calls ncclCommInitRank on `device`, then touches <dir>/ready.<rank> (a launcher's start-up deadline watches these).  The exchange owns a non-blocking HIP stream of the HIGHEST priority
 // (the sampler's context stream has the lowest: the gather gets in between two of its kernels), device and pinned
 // host buffers for two slots, and reads device rows in place.  Throws std::runtime_error.
 std::unique_ptr<Exchange> make_rccl_exchange(int rank, int world, const std::string &dir, int device, double timeout_s = 120.0);
@@ -51,5 +57,16 @@ std::string default_bootstrap_dir();
 // RANK / WORLD_SIZE / LOCAL_RANK of this process as the launchers export them (B9_RANK ... take precedence); 0 / 1 / 0
 // when absent.
 void rank_from_env(int &rank, int &world, int &local_rank);
+
+// true when this process is a rank of one of OUR launchers (singlePopMcmc --gpus N, bench.py --gpus N) and was told to use
+// the multi-rank route whatever the rank count (B9_FORCE_RANKS=1: --forceRanks / --force-ranks with one GPU)
+bool forced_ranks();
+
+// One string per launch, shared by its ranks (names the RCCL id file): B9_LAUNCH_NONCE, or torchrun's run id + restart count.
+std::string launch_nonce();
+
+// Test hook: B9_TEST_STALL="<where>:<rank>" parks that rank for ever at the named point ("start": before anything touches
+// a GPU; "before-init" / "after-init": around ncclCommInitRank), so the launchers' deadlines can be exercised.
+void test_stall(const char *where, int rank);
 
 }  // namespace b9h

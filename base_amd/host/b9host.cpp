@@ -122,7 +122,7 @@ const std::map<std::string, std::string> &Settings::flag_map()
         {"runIter", "singlePopMcmc.runIter"}, {"thin", "singlePopMcmc.thin"},
         {"seed", "general.seed"}, {"verbose", "general.verbose"},
         {"walkers", "gpu.walkers"}, {"device", "gpu.device"}, {"block", "gpu.block"}, {"gpus", "gpu.gpus"},
-        {"mode", "gpu.mode"}, {"marginalise", "gpu.marginalise"},
+        {"mode", "gpu.mode"}, {"marginalise", "gpu.marginalise"}, {"forceRanks", "gpu.forceRanks"}, {"tilesPerBlock", "gpu.tilesPerBlock"},
         {"margIsoIncrem", "sampleMass.margIsoIncrem"}, {"nMassRatios", "sampleMass.nMassRatios"},
     };
     return m;
@@ -137,7 +137,7 @@ void Settings::parse_args(int argc, char **argv)
         std::string value;
         size_t eq = a.find('=');
         if (eq != std::string::npos) { value = a.substr(eq + 1); a = a.substr(0, eq); }
-        else if (a == "verbose" || a == "marginalise") value = "1";
+        else if (a == "verbose" || a == "marginalise" || a == "forceRanks") value = "1";
         else { if (i + 1 >= argc) fail("flag --" + a + " needs a value"); value = argv[++i]; }
         if (a == "config") { load_yaml(value); continue; }
         auto it = flag_map().find(a);
@@ -451,10 +451,11 @@ Photometry read_photometry(const std::string &path, double min_mag, double max_m
 // ---------------------------------------------------------------------------------------------
 // Results
 // ---------------------------------------------------------------------------------------------
-ResultWriter::ResultWriter(const std::string &path, const std::vector<std::string> &columns)
+ResultWriter::ResultWriter(const std::string &path, const std::vector<std::string> &columns, const std::string &comment)
 {
     FILE *f = std::fopen(path.c_str(), "w");
     if (!f) fail("cannot write " + path);
+    if (!comment.empty()) std::fprintf(f, "# %s\n", comment.c_str());
     for (auto &c : columns) std::fprintf(f, "%12s ", c.c_str());
     std::fprintf(f, "%14s %5s\n", "logPost", "stage");
     fp = f;

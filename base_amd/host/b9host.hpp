@@ -74,10 +74,11 @@ struct Photometry {
 Photometry read_photometry(const std::string &path, double min_mag = -1e300, double max_mag = 1e300, int index = 0);
 
 // ---- results ------------------------------------------------------------------------------------
-// [RECALL] .res: header naming the sampled columns + logPost + stage, one row per kept iteration.
+// [RECALL] .res: header naming the sampled columns + logPost + stage, one row per kept iteration.  [OWN] a first line
+// "# <comment>" (when given) says which posterior the file holds: evaluation mode, ABI version, populations, walkers.
 class ResultWriter {
   public:
-    ResultWriter(const std::string &path, const std::vector<std::string> &columns);
+    ResultWriter(const std::string &path, const std::vector<std::string> &columns, const std::string &comment = "");
     ~ResultWriter();
     void row(const std::vector<double> &values, double logpost, int stage);
   private:

@@ -88,6 +88,16 @@ int b9h_exchange_barrier(void *e) { return guard([&] { static_cast<b9h::Exchange
 int b9h_exchange_max(void *e, double v, double *out) { return guard([&] { *out = static_cast<b9h::Exchange *>(e)->all_reduce_max(v); }); }
 int b9h_exchange_world(void *e) { return static_cast<b9h::Exchange *>(e)->world(); }
 const char *b9h_exchange_name(void *e) { return static_cast<b9h::Exchange *>(e)->name(); }
+int b9h_exchange_comm_ranks(void *e) { return static_cast<b9h::Exchange *>(e)->comm_ranks(); }
+int b9h_exchange_devices(void *e, char *out, int cap)
+{
+    const std::string d = static_cast<b9h::Exchange *>(e)->devices();
+    if (!out || cap < 1 || (int)d.size() + 1 > cap) return -1;
+    std::memcpy(out, d.c_str(), d.size() + 1);
+    return 0;
+}
+int b9h_forced_ranks(void) { return b9h::forced_ranks() ? 1 : 0; }
+void b9h_test_stall(const char *where, int rank) { b9h::test_stall(where, rank); }
 
 // ---- sampler --------------------------------------------------------------------------------------------------------
 namespace {

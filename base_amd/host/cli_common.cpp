@@ -131,26 +131,76 @@ void open_session(Session &s, int argc, char **argv, int n_pops, bool need_phot)
     }
     check(b9_set_priors(s.ctx, &s.priors));
     check(b9_set_options(s.ctx, &s.options));
+    // --tilesPerBlock n pins how a walker's star terms are grouped into partial sums (b9_tuning): with it a walker's chain
+    // is the same bits for every --gpus; left automatic, the grouping follows the number of walkers per GPU
+    if (const long tpb = st.integer("gpu.tilesPerBlock", 0)) {
+        b9_tuning t{};
+        t.tiles_per_block = (int32_t)std::max<long>(0, tpb);
+        check(b9_set_tuning(s.ctx, &t));
+    }
 }
+
+namespace {
+
+double env_seconds(const char *name, double def)
+{
+    const char *v = std::getenv(name);
+    if (!v || !*v) return def;
+    char *end = nullptr;
+    const double x = std::strtod(v, &end);
+    return (end && end != v && x >= 0.0) ? x : def;
+}
+
+void remove_bootstrap_dir(const std::string &dir, int n)
+{
+    // only what a launch of ours can have put there: the id file of THIS launch's nonce and the ranks' ready markers
+    const char *nonce = std::getenv("B9_LAUNCH_NONCE");
+    if (nonce) { std::remove((dir + "/rccl_id." + nonce).c_str()); std::remove((dir + "/rccl_id." + nonce + ".tmp").c_str()); }
+    for (int r = 0; r < n; ++r) std::remove((dir + "/ready." + std::to_string(r)).c_str());
+    rmdir(dir.c_str());
+}
+
+}  // namespace
 
 bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
 {
     if (std::getenv("B9_RANK") || std::getenv("RANK")) return false;           // already a rank of some launcher
     Settings st;
     st.parse_args(argc, argv);                                                  // (flags and YAML only: nothing touches a GPU)
-    const int n = (int)st.integer("gpu.gpus", 1);
-    if (n <= 1) return false;
+    int n = (int)st.integer("gpu.gpus", 1);
+    // --forceRanks (or B9_FORCE_LAUNCHER=1): one GPU still takes the whole multi-rank route -- a child process started
+    // before any GPU call, the id file, ncclCommInitRank (world 1), the device-row all-gather, the part-file merge --
+    // so that route can be rehearsed (and is tested) on a one-GPU machine
+    const char *fl = std::getenv("B9_FORCE_LAUNCHER");
+    const bool force = st.integer("gpu.forceRanks", 0) != 0 || (fl && std::atoi(fl) != 0);
+    if (n <= 1 && !force) return false;
+    n = std::max(1, n);
     char dir[] = "/tmp/b9dist_XXXXXX";
     if (!mkdtemp(dir)) throw std::runtime_error("cannot create a directory for the RCCL bootstrap");
+    const auto t0 = std::chrono::steady_clock::now();
+    const std::string nonce = std::to_string((long)getpid()) + "_" + std::to_string((long long)t0.time_since_epoch().count());
+    setenv("B9_LAUNCH_NONCE", nonce.c_str(), 1);
+    // Deadlines.  B9_LAUNCH_TIMEOUT_S (default 300): every rank must have its communicator up (ready marker written after
+    // ncclCommInitRank and the first collective) by then -- ncclCommInitRank itself never gives up on a peer that does
+    // not come.  B9_RUN_TIMEOUT_S (default: none): the whole run.  Either one ends the launch: the ranks are killed and
+    // the launcher exits 124.
+    const double init_deadline = env_seconds("B9_LAUNCH_TIMEOUT_S", 300.0), run_deadline = env_seconds("B9_RUN_TIMEOUT_S", 0.0);
     std::vector<pid_t> kids;
     for (int r = 0; r < n; ++r) {
         const pid_t pid = fork();
-        if (pid < 0) throw std::runtime_error("fork failed");
+        if (pid < 0) {
+            // the ranks already started would wait for the missing ones: end them, reap them, leave nothing behind
+            for (pid_t k : kids) kill(k, SIGTERM);
+            for (pid_t k : kids) { int st_ = 0; waitpid(k, &st_, 0); }
+            remove_bootstrap_dir(dir, n);
+            throw std::runtime_error("fork failed");
+        }
         if (pid == 0) {
             setenv("B9_RANK", std::to_string(r).c_str(), 1);
             setenv("B9_WORLD_SIZE", std::to_string(n).c_str(), 1);
             setenv("B9_LOCAL_RANK", std::to_string(r).c_str(), 1);
             setenv("B9_DIST_DIR", dir, 1);
+            if (force) setenv("B9_FORCE_RANKS", "1", 1);
             setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      // dmabuf IPC (what this driver supports) unless the user chose
             execv("/proc/self/exe", argv);
             std::perror("execv");
@@ -158,25 +208,46 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
         }
         kids.push_back(pid);
     }
-    // wait for all of them, in whatever order they end; a rank that fails takes the others with it (a peer blocked in the
-    // communicator's initialisation would wait for it for ever) -- exactly the processes forked above, by pid
-    int worst = 0;
+    // Wait for all of them, in whatever order they end.  A rank that fails takes the others with it (a peer blocked in
+    // the communicator would wait for it for ever) -- exactly the processes forked above, by pid; the launch's exit code is
+    // the FIRST failure seen (the peers then die of our SIGTERM: their 143 says nothing).
+    int first_fail = 0;
     size_t left = kids.size();
+    bool all_ready = false, killing = false;
+    auto kill_time = t0;
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    auto end_all = [&](int sig) { for (pid_t k : kids) if (k > 0) kill(k, sig); };
     while (left > 0) {
         int status = 0;
-        const pid_t k = waitpid(-1, &status, 0);
-        if (k < 0) { worst = std::max(worst, 1); break; }
-        auto it = std::find(kids.begin(), kids.end(), k);
-        if (it == kids.end()) continue;
-        *it = -1; --left;
-        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
-        worst = std::max(worst, code);
-        if (code != 0)
-            for (pid_t other : kids) if (other > 0) kill(other, SIGTERM);
+        const pid_t k = waitpid(-1, &status, WNOHANG);
+        if (k < 0) { if (!first_fail) first_fail = 1; break; }
+        if (k > 0) {
+            auto it = std::find(kids.begin(), kids.end(), k);
+            if (it == kids.end()) continue;
+            *it = -1; --left;
+            const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+            if (code != 0 && !first_fail) first_fail = code;
+            if (code != 0 && !killing) { end_all(SIGTERM); killing = true; kill_time = std::chrono::steady_clock::now(); }
+            continue;
+        }
+        if (!all_ready) {
+            all_ready = true;
+            for (int r = 0; r < n && all_ready; ++r) all_ready = access((std::string(dir) + "/ready." + std::to_string(r)).c_str(), F_OK) == 0;
+        }
+        const bool late_start = !all_ready && init_deadline > 0.0 && elapsed() > init_deadline;
+        const bool late_run = run_deadline > 0.0 && elapsed() > run_deadline;
+        if ((late_start || late_run) && !killing) {
+            std::fprintf(stderr, "launcher: %s after %.0f s (%s): ending the %zu remaining rank(s)\n",
+                         late_start ? "not every rank brought its RCCL communicator up" : "the run did not finish", elapsed(),
+                         late_start ? "B9_LAUNCH_TIMEOUT_S" : "B9_RUN_TIMEOUT_S", left);
+            if (!first_fail) first_fail = 124;
+            end_all(SIGTERM); killing = true; kill_time = std::chrono::steady_clock::now();
+        }
+        if (killing && std::chrono::duration<double>(std::chrono::steady_clock::now() - kill_time).count() > 5.0) end_all(SIGKILL);
+        usleep(20000);
     }
-    std::remove((std::string(dir) + "/rccl_id").c_str());
-    rmdir(dir);
-    *exit_code = worst;
+    remove_bootstrap_dir(dir, n);
+    *exit_code = first_fail;
     return true;
 }
 
@@ -198,8 +269,16 @@ McmcResult run_mcmc(Session &s, Exchange &ex, const std::vector<std::string> &co
         throw std::runtime_error("the starting parameters have zero posterior probability (outside the model grid or the prior support)");
 
     const std::string final_path = s.output_base + ".res";
-    const std::string my_path = ex.world() > 1 ? final_path + ".part" + std::to_string(ex.rank()) : final_path;
-    std::unique_ptr<ResultWriter> out(new ResultWriter(my_path, columns));
+    const bool parts_route = ex.world() > 1 || forced_ranks();      // (--forceRanks: one rank still writes a part and merges it)
+    const std::string my_path = parts_route ? final_path + ".part" + std::to_string(ex.rank()) : final_path;
+    // the file says what it is: which posterior was sampled (the evaluation mode decides that) and by which ABI
+    std::string what = "base9_hip ABI " + std::to_string(b9_abi_version()) + "; mode=" +
+                       (s.options.mode == B9_MODE_MARGINALISED
+                            ? "marginalised (margIsoIncrem=" + std::to_string(s.options.marg_iso_increm) + ", nMassRatios=" + std::to_string(s.options.marg_n_q) + ")"
+                            : std::string("givenMass")) +
+                       "; populations=" + std::to_string(s.options.n_pops) + "; walkers=" + std::to_string(W);
+    std::unique_ptr<ResultWriter> out(new ResultWriter(my_path, columns, what));
+    long rows_written = 0;
     const long total = cfg.burn_iter + cfg.run_iter;
     std::vector<double> v(d);
     auto sink = [&](const BlockRecord &r) {
@@ -210,6 +289,7 @@ McmcResult run_mcmc(Session &s, Exchange &ex, const std::vector<std::string> &co
             for (int w = 0; w < r.n_local; ++w) {
                 std::copy(r.samples + ((size_t)st * r.n_local + w) * d, r.samples + ((size_t)st * r.n_local + w + 1) * d, v.begin());
                 out->row(v, r.lps[(size_t)st * r.n_local + w], stage);
+                ++rows_written;
             }
         }
         if (cfg.verbose && ex.rank() == 0)
@@ -225,25 +305,44 @@ McmcResult run_mcmc(Session &s, Exchange &ex, const std::vector<std::string> &co
     res.accepted = sampler.accepted_local();
     res.star_evals_per_s = (double)res.steps * W * s.phot.n_stars() / res.seconds;
     out.reset();
-    if (ex.world() > 1) {
+    if (parts_route) {
         ex.barrier();                                 // every part file is complete
         if (ex.rank() == 0) {
+            // Interleave the parts in walker order.  Nothing is deleted unless the merged file was written completely: every
+            // part must deliver exactly the rows its rank wrote (the same count on every rank), and every write is checked.
+            const int world = ex.world();
             std::vector<std::ifstream> parts;
-            for (int r = 0; r < ex.world(); ++r) {
+            for (int r = 0; r < world; ++r) {
                 parts.emplace_back(final_path + ".part" + std::to_string(r));
                 if (!parts.back()) throw std::runtime_error("cannot read " + final_path + ".part" + std::to_string(r));
             }
             std::ofstream fin(final_path);
+            if (!fin) throw std::runtime_error("cannot write " + final_path + " (the part files are kept)");
             std::string line;
-            for (int r = 0; r < ex.world(); ++r) { std::getline(parts[r], line); if (r == 0) fin << line << "\n"; }     // header
+            for (int r = 0; r < world; ++r)              // leading comment lines and the column header: part 0's
+                while (std::getline(parts[r], line)) {
+                    if (r == 0) fin << line << "\n";
+                    if (line.empty() || line[0] != '#') break;
+                }
+            std::vector<long> got(world, 0);
             for (bool more = true; more;)
-                for (int r = 0; r < ex.world() && more; ++r)
+                for (int r = 0; r < world && more; ++r)
                     for (int w = 0; w < per; ++w) {
                         if (!std::getline(parts[r], line)) { more = false; break; }
                         fin << line << "\n";
+                        ++got[r];
                     }
+            for (int r = 0; r < world; ++r) {
+                if (std::getline(parts[r], line)) ++got[r];                  // anything left over is a mismatch too
+                if (got[r] != rows_written)
+                    throw std::runtime_error(final_path + ".part" + std::to_string(r) + " holds " + std::to_string(got[r]) + " rows, expected " +
+                                             std::to_string(rows_written) + " (truncated or mismatched part; the part files are kept)");
+            }
+            fin.flush();
+            if (!fin) throw std::runtime_error("writing " + final_path + " failed (disk full?); the part files are kept");
+            fin.close();
             parts.clear();
-            for (int r = 0; r < ex.world(); ++r) std::remove((final_path + ".part" + std::to_string(r)).c_str());
+            for (int r = 0; r < world; ++r) std::remove((final_path + ".part" + std::to_string(r)).c_str());
         }
         ex.barrier();
     }

@@ -21,15 +21,22 @@ int main(int argc, char **argv)
     try {
         int code = 0;
         if (b9h::launch_ranks_if_requested(argc, argv, &code)) return code;     // the launcher of a --gpus N run
+        {
+            int r0 = 0, w0 = 1, l0 = 0;
+            b9h::rank_from_env(r0, w0, l0);
+            b9h::test_stall("start", r0);                                        // (test hook; nothing has touched a GPU yet)
+        }
         b9h::Session s;
         b9h::open_session(s, argc, argv, B9_N_POPS, true);
-        std::unique_ptr<b9h::Exchange> ex = s.world > 1 ? b9h::make_rccl_exchange(s.rank, s.world, b9h::default_bootstrap_dir(), b9_device_id(s.ctx))
+        std::unique_ptr<b9h::Exchange> ex = (s.world > 1 || b9h::forced_ranks()) ? b9h::make_rccl_exchange(s.rank, s.world, b9h::default_bootstrap_dir(), b9_device_id(s.ctx))
                                                          : b9h::make_local_exchange();
         std::vector<std::string> cols;
         for (int idx : s.mcmc.free_idx) cols.push_back(B9_N_POPS == 2 && idx == B9_P_Y ? "YA" : b9h::param_name(idx));
         if (s.rank == 0) {
-            std::fprintf(stderr, "%s: %d stars x %zu filters, %d walker(s) on %d GPU(s) [%s], %s mode, sampling", prog, s.phot.n_stars(),
-                         s.phot.filters.size(), s.mcmc.n_walkers, s.world, ex->name(), s.options.mode == B9_MODE_MARGINALISED ? "marginalised" : "given-mass");
+            std::fprintf(stderr, "%s: %d stars x %zu filters, %d walker(s) on %d GPU(s) [%s", prog, s.phot.n_stars(),
+                         s.phot.filters.size(), s.mcmc.n_walkers, s.world, ex->name());
+            if (ex->comm_ranks() > 0) std::fprintf(stderr, "; communicator of %d rank(s) on %s", ex->comm_ranks(), ex->devices().c_str());
+            std::fprintf(stderr, "], %s mode, sampling", s.options.mode == B9_MODE_MARGINALISED ? "marginalised" : "given-mass");
             for (auto &c : cols) std::fprintf(stderr, " %s", c.c_str());
             std::fprintf(stderr, "\n");
         }

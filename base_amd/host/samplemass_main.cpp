@@ -31,7 +31,9 @@ int main(int argc, char **argv)
         std::ifstream in(res_path);
         if (!in) throw std::runtime_error("cannot read " + res_path + " (run singlePopMcmc first)");
         std::string line;
-        if (!std::getline(in, line)) throw std::runtime_error(res_path + " is empty");
+        do {                                                     // (leading "# ..." lines say how the chain was made)
+            if (!std::getline(in, line)) throw std::runtime_error(res_path + " is empty");
+        } while (!line.empty() && line[0] == '#');
         std::vector<int> col_param;
         {
             std::istringstream hs(line);

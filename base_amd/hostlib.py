@@ -30,7 +30,8 @@ LOGPOST_FN = C.CFUNCTYPE(C.c_int, vp, _dp, C.c_int, _dp)
 HOST_SYMBOLS = [
     "b9h_last_error", "b9h_rank_from_env", "b9h_device_synchronize",
     "b9h_exchange_local", "b9h_exchange_rccl", "b9h_exchange_callback", "b9h_exchange_free", "b9h_exchange_barrier",
-    "b9h_exchange_max", "b9h_exchange_world", "b9h_exchange_name",
+    "b9h_exchange_max", "b9h_exchange_world", "b9h_exchange_name", "b9h_exchange_comm_ranks", "b9h_exchange_devices",
+    "b9h_forced_ranks", "b9h_test_stall",
     "b9h_sampler_create", "b9h_sampler_create_callback", "b9h_sampler_free", "b9h_sampler_initialise", "b9h_sampler_run",
     "b9h_sampler_n_local", "b9h_sampler_state", "b9h_summary_rows",
     "b9h_load_pack", "b9h_free_pack", "b9h_read_phot", "b9h_free_phot", "b9h_settings_dump",
@@ -60,6 +61,10 @@ def load() -> C.CDLL:
     lib.b9h_exchange_world.argtypes = [vp]
     lib.b9h_exchange_name.argtypes = [vp]
     lib.b9h_exchange_name.restype = C.c_char_p
+    lib.b9h_exchange_comm_ranks.argtypes = [vp]
+    lib.b9h_exchange_devices.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.b9h_test_stall.argtypes = [C.c_char_p, C.c_int]
+    lib.b9h_test_stall.restype = None
     lib.b9h_sampler_create.argtypes = [vp, C.c_int, C.c_int, _ip, _dp, C.c_int, C.c_uint64, C.c_int, vp, C.POINTER(vp)]
     lib.b9h_sampler_create_callback.argtypes = [BLOCK_FN, LOGPOST_FN, vp, C.c_int, _ip, _dp, C.c_int, C.c_uint64, C.c_int, vp, C.POINTER(vp)]
     lib.b9h_sampler_free.argtypes = [vp]
@@ -144,6 +149,20 @@ class Exchange:
     @property
     def name(self) -> str:
         return load().b9h_exchange_name(self._h).decode()
+
+    @property
+    def comm_ranks(self) -> int:
+        """ncclCommCount of the exchange's communicator (0: it has none)."""
+        return int(load().b9h_exchange_comm_ranks(self._h))
+
+    @property
+    def devices(self):
+        """PCI bus ids of the ranks' GPUs in rank order, gathered through the communicator ([] without one)."""
+        buf = C.create_string_buffer(4096)
+        if load().b9h_exchange_devices(self._h, buf, len(buf)) != 0:
+            raise HostError("b9h_exchange_devices: buffer too small")
+        txt = buf.value.decode()
+        return txt.split(",") if txt else []
 
     def close(self) -> None:
         if self._h:

@@ -535,3 +535,29 @@ gpu:
     with open(path, "w") as f:
         f.write(txt)
     return path
+
+
+# ------------------------------------------------------------------------------------------
+# the five BASELINE.json configurations at ONE GPU's share (SURVEY 8d shapes; seeds 9001 + index)
+# ------------------------------------------------------------------------------------------
+BASELINE_CONFIGS = {
+    # name: (pack, n_filt, n_stars, wd_frac, n_y, n_pops, walkers on one GPU, note)
+    "C0": ("girardi", 3, 200, 0.0, 1, 1, 1, "200-star, Girardi-shaped, 3 filters, 1 chain (the reference's CPU plumbing case)"),
+    "C1": ("dsed", 8, 10000, 0.0, 1, 1, 1, "10k-star, DSED-shaped, 8 filters, 1 chain, 1 GPU"),
+    "C2": ("parsec", 8, 50000, 0.0, 1, 1, 8, "50k-star, PARSEC-shaped, 8 filters, 64 walkers / 8 GPUs -> 8 per GPU (bench.py workload)"),
+    "C3": ("parsec", 8, 20000, 0.05, 1, 1, 1, "20k-star mixed MS+WD (5% WD: Bergeron-like atmospheres + IFMR), 8 filters, 1 GPU"),
+    "C4": ("parsec", 8, 30000, 0.0, 3, 2, 8, "two-population 30k-star, 8 filters, 32 walkers / 4 GPUs -> 8 per GPU"),
+}
+
+
+def make_baseline_config(name: str, wd_ragged: bool = False) -> Dict:
+    """Synthetic pack + cluster of BASELINE.json configs[int(name[1])], pinned into ABI structs.
+    Returns dict(pack_d, cluster, pack, stars, priors, options, truth, walkers, n_pops, free, note)."""
+    pk, nf, ns, wd, ny, npops, walkers, note = BASELINE_CONFIGS[name]
+    pack_d = make_pack(pk, nf, n_y=ny, wd_ragged=wd_ragged)
+    truth = default_params(pack_d)
+    cl = make_cluster(pack_d, ns, seed=9001 + int(name[1]), truth=truth, wd_frac=wd, n_pops=npops)
+    free = (abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS) + ((abi.P_Y, abi.P_Y2, abi.P_LAMBDA) if npops == 2 else ())
+    return dict(pack_d=pack_d, cluster=cl, pack=abi.make_pack(pack_d), stars=abi.make_stars(cl),
+                priors=default_priors(pack_d, truth, npops), options=abi.make_options(n_pops=npops), truth=truth,
+                walkers=walkers, n_pops=npops, free=free, note=note)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define B9_ABI_VERSION 2
+#define B9_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------ */
 typedef enum b9_status {
@@ -157,6 +157,33 @@ typedef struct b9_options {
     int32_t marg_n_q;         /* mass-ratio quadrature nodes                              */
 } b9_options;
 
+/*
+ * Launch-plan tuning (ABI 3).  Every field 0 = automatic (what a context starts with); results are the same for every
+ * setting to the stated tolerance -- these only regroup the same work (tests/test_gpu_mcmc.py runs the combinations).
+ * The one field with a contract is tiles_per_block: a hot workgroup sums its waves' star terms over the tiles it owns,
+ * so the ROUNDING of a walker's log-posterior depends on it; the automatic choice depends on the number of walkers
+ * on the GPU and on the device's occupancy.  A driver that wants a walker's chain to be the same BITS whatever the
+ * number of GPUs the walkers are spread over must pin it (singlePopMcmc --tilesPerBlock n does).
+ * The same fields can be set through the environment, read ONCE when the context is created: B9_TILES_PER_BLOCK,
+ * B9_DERIVE_PARTS, B9_DERIVE_ORDER (historical coding: 1 default, 0 heavy first, < 0 derivation trails), B9_HEAVY_PARTS,
+ * B9_WALKERS_PER_LANE, B9_CONTIGUOUS_TILES, B9_TWO_LAUNCH_STEPS, B9_NO_CHUNK_BOUNDS, B9_TIMING_GROUP, B9_PLAN_DEBUG;
+ * B9_STREAM_PRIORITY=default gives the context's stream the default priority instead of the lowest.
+ */
+typedef struct b9_tuning {
+    int32_t tiles_per_block;   /* star tiles (256 stars) per hot workgroup of k_star_like / k_mcmc_step                    */
+    int32_t derive_parts;      /* fused step: workgroups per candidate isochrone                                         */
+    int32_t derive_order;      /* fused step grid: 1 writers + derivation lead (default), 2 heavy-star workgroups lead,  */
+                               /* 3 derivation workgroups trail the hot ones                                            */
+    int32_t heavy_parts;       /* workgroups per walker for the stars above the AGB tip (default: sized from the catalogue) */
+    int32_t walkers_per_lane;  /* k_star_like: 2 = two walkers per lane (halves L2 traffic, doubles the chain); default 1 */
+    int32_t contiguous_tiles;  /* 1: a hot workgroup's tiles are consecutive even when the launch is one occupancy round  */
+    int32_t two_launch_steps;  /* 1: the derive + star launch pair per sampler step also in given-mass mode                */
+    int32_t no_chunk_bounds;   /* 1: marginalised kernel without its chunk-level pruning table                           */
+    int32_t timing_group;      /* launches per HIP-event bracket of b9_enable_timing in the fused step (default 8)        */
+    int32_t plan_debug;        /* 1: print the fused step's launch plan to stderr whenever it changes                    */
+    int32_t reserved[6];
+} b9_tuning;
+
 typedef struct b9_ctx b9_ctx;
 
 /* ---- lifecycle ---------------------------------------------------------------------- */
@@ -173,6 +200,8 @@ int b9_load_pack(b9_ctx *ctx, const b9_pack *pack);
 int b9_load_stars(b9_ctx *ctx, const b9_stars *stars);
 int b9_set_priors(b9_ctx *ctx, const b9_priors *priors);
 int b9_set_options(b9_ctx *ctx, const b9_options *opt);
+/* tuning NULL = everything automatic again.  Not while a block is outstanding. */
+int b9_set_tuning(b9_ctx *ctx, const b9_tuning *tuning);
 
 /* ---- the hot path -------------------------------------------------------------------- */
 /*
@@ -286,6 +315,10 @@ int b9_max_eep(const b9_ctx *ctx);           /* longest isochrone in the loaded 
 int b9_device_id(const b9_ctx *ctx);
 /* Algorithmic bytes one star-eval moves in the loaded layout ("bytes per unit"). */
 int b9_bytes_per_star_eval(const b9_ctx *ctx);
+/* Star tiles per hot workgroup the fused sampler step would use for n_walkers local walkers with the loaded pack, stars
+ * and tuning (> 0), or a negative b9_status.  The summation grouping of a walker's log-posterior follows from it (see
+ * b9_tuning.tiles_per_block). */
+int b9_step_tiles_per_block(b9_ctx *ctx, int32_t n_walkers);
 /* Elapsed ms of the dominant (star-likelihood) kernel over the TIMED launches since the last
  * call with reset != 0, measured with HIP events on the launch stream; *n_launches receives
  * their count.  b9_enable_timing(ctx, n): n = 0 off, n > 0 opens an event bracket at every n-th

@@ -38,6 +38,15 @@ int b9h_exchange_barrier(void *exchange);
 int b9h_exchange_max(void *exchange, double value, double *max_over_ranks);
 int b9h_exchange_world(void *exchange);                 /* returns the number of ranks */
 const char *b9h_exchange_name(void *exchange);
+/* What the communicator itself reports: its rank count (ncclCommCount; 0 for an exchange without a communicator) ...  */
+int b9h_exchange_comm_ranks(void *exchange);
+/* ... and the PCI bus ids of the ranks' GPUs in rank order, comma-separated, all-gathered through the communicator
+ * ("" without one).  Returns 0, or -1 when `cap` is too small. */
+int b9h_exchange_devices(void *exchange, char *out, int cap);
+/* 1 when this process is a rank of a --forceRanks / --force-ranks launch (B9_FORCE_RANKS): one GPU, full multi-rank route */
+int b9h_forced_ranks(void);
+/* Test hook of the launchers' deadlines: parks the calling rank for ever when B9_TEST_STALL == "<where>:<rank>". */
+void b9h_test_stall(const char *where, int rank);
 
 /* ---- the sampler ------------------------------------------------------------------------------------------------ */
 typedef int (*b9h_block_fn)(void *user, const double *params_in, const double *logpost_in, const int32_t *walker_ids, int n_local,

@@ -35,7 +35,7 @@ def test_header_symbols_match_binding_table():
 def test_library_exports_every_declared_symbol(lib):
     for name in _declared_functions():
         assert hasattr(lib, name), f"{name} declared in base9_hip.h but not exported"
-    assert lib.b9_abi_version() == 2
+    assert lib.b9_abi_version() == 3
 
 
 def test_host_library_exports_every_declared_symbol():
@@ -65,7 +65,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(b9_pack), sizeof(b9_stars), sizeof(b9_priors), sizeof(b9_options));
   printf("%zu %zu %zu %d\n", sizeof(b9_mcmc_block), offsetof(b9_mcmc_block, row_origin), offsetof(b9_mcmc_block, rows_ready), B9_ROW_DOUBLES(4));
   printf("%zu %zu %zu %zu\n", offsetof(b9_pack, mass), offsetof(b9_pack, at_mags), offsetof(b9_pack, m_wd_up), offsetof(b9_stars, filter_prior_max));
-  printf("%d\n", B9_NPARAM);
+  printf("%d %zu %zu\n", B9_NPARAM, sizeof(b9_tuning), offsetof(b9_tuning, plan_debug));
   return 0; }''')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
@@ -76,7 +76,7 @@ int main(void) {
     got = got[:4] + got[8:]
     assert got[4:8] == [abi.b9_pack.mass.offset, abi.b9_pack.at_mags.offset, abi.b9_pack.m_wd_up.offset,
                         abi.b9_stars.filter_prior_max.offset]
-    assert got[8] == abi.B9_NPARAM
+    assert got[8:] == [abi.B9_NPARAM, C.sizeof(abi.b9_tuning), abi.b9_tuning.plan_debug.offset]
 
 
 def test_no_cpu_fallback(lib):

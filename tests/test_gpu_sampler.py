@@ -142,6 +142,123 @@ def test_two_ranks_on_one_gpu_match_one_rank():
         np.testing.assert_array_equal(st["all_logpost"], st1["all_logpost"])
 
 
+def _two_ranks_one_gpu(pack, stars, priors, options, start, tuning, **run_kw):
+    """World size 2 through the product block runner on ONE GPU (two threads, a context each, half of the walkers; the
+    all-gather bridged by a callback exchange).  Returns the two ranks' (state, samples, lps)."""
+    import threading
+    from base_amd import engine
+    slots, bar = [None, None], threading.Barrier(2, timeout=300)
+
+    def make_gather(rank):
+        def gather(rows):
+            slots[rank] = np.array(rows, copy=True)
+            bar.wait()
+            out = np.concatenate([slots[0], slots[1]])
+            bar.wait()
+            return out
+        return gather
+
+    results, errors = [None, None], []
+
+    def rank_main(rank):
+        try:
+            eng = engine.Engine(pack, stars, priors, options)
+            if tuning:
+                eng.set_tuning(**tuning)
+            ex = hostlib.Exchange.callback(make_gather(rank), rank, 2)
+            results[rank] = _device_run(eng, ex, start, **run_kw)
+            eng.close()
+        except BaseException as e:                       # noqa: BLE001  (reported by the main thread)
+            errors.append(e)
+            bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    return results
+
+
+def test_rank_count_invariance_at_50k_stars_needs_the_grouping_pinned():
+    """At 50 000 stars the automatic launch plan gives 8 walkers on one GPU 3 tiles per hot workgroup and 4 walkers (the
+    same 8 spread over two ranks) 2: the per-wave partial sums group different stars, so a walker's log-posterior rounds
+    differently -- the chains agree to the tolerance, not to the bit.  With b9_tuning.tiles_per_block pinned
+    on both sides they are the same bits."""
+    from base_amd import engine
+    cfg = synth.make_baseline_config("C2")
+    pack, stars, priors, options = cfg["pack"], cfg["stars"], cfg["priors"], cfg["options"]
+    start = synth.walker_params(cfg["truth"], 8, seed=42, scale=0.02)
+    kw = dict(burn=60, main=20, block=20)
+    eng1 = engine.Engine(pack, stars, priors, options)
+    t8, t4 = eng1.step_tiles_per_block(8), eng1.step_tiles_per_block(4)
+    assert t8 != t4, "the two plans no longer differ: pick another shape for this test"
+    st1, samples1, lps1 = _device_run(eng1, hostlib.Exchange.local(), start, **kw)
+    eng1.set_tuning(tiles_per_block=t8)
+    st1p, samples1p, lps1p = _device_run(eng1, hostlib.Exchange.local(), start, **kw)
+    np.testing.assert_array_equal(samples1p, samples1)             # (pinning the automatic value changes nothing)
+    eng1.close()
+    # automatic plans: equal to the tolerance
+    (sa, xa, la), (sb, xb, lb) = _two_ranks_one_gpu(pack, stars, priors, options, start, None, **kw)
+    lps2 = np.concatenate([la, lb], axis=1)
+    np.testing.assert_allclose(np.concatenate([xa, xb], axis=1), samples1, rtol=1e-9, atol=1e-12)
+    assert np.max(np.abs(lps2 - lps1) / np.maximum(1.0, np.abs(lps1))) <= 1e-9
+    # pinned grouping: the same bits
+    (sa, xa, la), (sb, xb, lb) = _two_ranks_one_gpu(pack, stars, priors, options, start, dict(tiles_per_block=t8), **kw)
+    np.testing.assert_array_equal(np.concatenate([xa, xb], axis=1), samples1)
+    np.testing.assert_array_equal(np.concatenate([la, lb], axis=1), lps1)
+    for st in (sa, sb):
+        np.testing.assert_array_equal(st["chol"], st1["chol"])
+        assert st["scale"] == st1["scale"]
+
+
+def _oracle_delta(orc, template_row, free, samples, lps):
+    """max relative |delta| between recorded chain log-posteriors and the oracle at the recorded positions; every
+    DISTINCT visited state is evaluated once (a rejected step repeats its predecessor's row)."""
+    flat = samples.reshape(-1, samples.shape[-1])
+    uniq, inverse = np.unique(flat, axis=0, return_inverse=True)
+    rows = np.repeat(np.asarray(template_row, dtype=np.float64)[None, :], len(uniq), axis=0)
+    rows[:, list(free)] = uniq
+    want = orc.logpost(rows)[inverse.ravel()]
+    got = lps.reshape(-1)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    fin = np.isfinite(want)
+    return float(np.max(np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin])))), len(uniq)
+
+
+@pytest.mark.parametrize("name", ["C0", "C1", "C2", "C3", "C4"])
+def test_sampler_logposts_match_oracle_full_size(name):
+    """The TIMED path -- k_mcmc_step driven by the C++ sampler (b9h::WalkerSampler: fused one-launch steps, pipelined
+    device-resident blocks) -- at the FULL size of every BASELINE.json configuration (one GPU's share): every
+    log-posterior the chain records over 60 steps (30 adapting, 30 frozen; two blocks each) equals the CPU oracle's at
+    the recorded position to 1e-9 relative.  This is the fused step's own reduction (per-wave partials of two parities,
+    heavy-star partials of two candidates, first-wave decision, published-decision shortcut) at benchmark size."""
+    from base_amd import engine
+    cfg = synth.make_baseline_config(name)
+    eng = engine.Engine(cfg["pack"], cfg["stars"], cfg["priors"], cfg["options"])
+    W, free = cfg["walkers"], cfg["free"]
+    start = synth.walker_params(cfg["truth"], W, seed=7, n_pops=cfg["n_pops"], scale=0.02)
+    s = hostlib.HostSampler(W, free, [mcmc.DEFAULT_STEP[k] for k in free], hostlib.Exchange.local(), seed=11, block=15, engine=eng)
+    s.initialise(start)
+    a = s.run(30, adapt=True, record=True)
+    b = s.run(30, adapt=False, record=True)
+    samples, lps = np.concatenate([a[0], b[0]]), np.concatenate([a[1], b[1]])
+    assert samples.shape == (60, W, len(free))
+    orc = oracle.Oracle(cfg["pack"], cfg["stars"], cfg["priors"], cfg["options"])
+    worst, n_states = 0.0, 0
+    for w in range(W):                       # parameters that are not sampled stay at the walker's starting values
+        err, n = _oracle_delta(orc, start[w], free, samples[:, w], lps[:, w])
+        worst, n_states = max(worst, err), n_states + n
+    assert n_states > W, "the chains never moved: nothing but the starting state was checked"
+    assert worst <= 1e-9, (name, worst)
+    # the ensemble state the sampler reports after the run (what bench.py checks after its timed region)
+    st = s.state()
+    want = orc.logpost(st["all_params"])
+    assert np.max(np.abs(st["all_logpost"] - want) / np.maximum(1.0, np.abs(want))) <= 1e-9
+    eng.close()
+
+
 def test_marginalised_mode_through_the_sampler():
     """Marginalised mode has no fused step: synchronous two-launch blocks, rows condensed on the host from the chain."""
     from base_amd import engine
@@ -169,6 +286,7 @@ def test_bench_self_launch_two_ranks_on_one_box():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and "RCCL" in line["config"]["collective"]
+    assert line["config"]["rccl_ranks"] == 2 and len(set(line["config"]["devices"])) == 2
     assert line["config"]["walkers_total"] == 16 and line["value"] > 0
 
 
@@ -191,4 +309,44 @@ def test_cli_two_gpus_chains_equal_one_gpu(tmp_path):
                             "--block", "30", "--seed", "5"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(open(base + ".res").read())
-    assert outs[0] == outs[1] and outs[0].count("\n") == 1 + 180 * 4
+    assert outs[0] == outs[1] and outs[0].count("\n") == 2 + 180 * 4
+
+
+def test_cli_forced_ranks_on_one_gpu_gives_the_same_res(tmp_path):
+    """The multi-rank route rehearsed on ONE GPU: `singlePopMcmc --gpus 1 --forceRanks` starts a child rank before any GPU
+    call, bootstraps RCCL through the id file (ncclCommInitRank, world 1), all-gathers the device rows through it,
+    writes .res.part0 and merges it -- and the .res is byte for byte the plain one-process run's."""
+    from base_amd import host_build
+    host_build.build_host()
+    pack_d, cl, *_ = build_problem("parsec", 8, n_stars=2000, small=False, seed=12)
+    root = synth.write_models_dir(pack_d, str(tmp_path / "models"))
+    phot = synth.write_phot(cl, pack_d["filters"], str(tmp_path / "c.phot"))
+    exe = os.path.join(ROOT, "base_amd", "host", "bin", "singlePopMcmc")
+    outs, errs = [], []
+    for tag, extra in (("plain", []), ("forced", ["--gpus", "1", "--forceRanks"])):
+        base = str(tmp_path / f"run_{tag}")
+        yml = synth.write_yaml(str(tmp_path / f"b_{tag}.yaml"), phot, root, base, cl["truth"])
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "B9_RANK")}
+        r = subprocess.run([exe, "--config", yml, "--walkers", "4", "--burnIter", "120", "--runIter", "60", "--block", "30", "--seed", "5"] + extra,
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(open(base + ".res").read())
+        errs.append(r.stderr)
+        assert not os.path.exists(base + ".res.part0")
+    assert outs[0] == outs[1] and outs[0].count("\n") == 2 + 180 * 4
+    assert outs[0].startswith("# base9_hip ABI ")
+    assert "RCCL" in errs[1] and "communicator of 1 rank(s)" in errs[1] and "RCCL" not in errs[0]
+
+
+def test_bench_forced_ranks_on_one_gpu():
+    """`bench.py --gpus 1 --force-ranks`: self-launched rank, RCCL communicator of one rank, device rows gathered by
+    ncclAllGather; the line names the collective and carries what the communicator itself reports."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "B9_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-ranks", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline", "--no-marginalised"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["ranks"] == 1 and cfg["forced_ranks"] is True
+    assert "RCCL" in cfg["collective"] and cfg["rccl_ranks"] == 1 and len(cfg["devices"]) == 1 and ":" in cfg["devices"][0]
+    assert line["value"] > 0 and line["roofline"]["useful_frac"] > 0

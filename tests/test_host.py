@@ -15,6 +15,14 @@ from conftest import build_problem
 HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "base_amd", "host")
 
 
+def _res_head(path):
+    """(the leading "# ..." comment, the column names) of a .res file."""
+    with open(path) as f:
+        lines = [f.readline(), f.readline()]
+    assert lines[0].startswith("# base9_hip ABI "), lines[0]
+    return lines[0], lines[1].split()
+
+
 @pytest.fixture(scope="module")
 def hostlib():
     from base_amd import build
@@ -160,8 +168,9 @@ def test_mcmc_cli_runs_and_recovers_truth(hostlib, tmp_path, prog, n_pops, n_y):
     r = _cli(prog, "--config", y, *extra)
     assert r.returncode == 0, r.stderr
     assert "star-likelihood evals/s" in r.stderr
-    head = open(str(tmp_path / "run.res")).readline().split()
-    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
+    note, head = _res_head(str(tmp_path / "run.res"))
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=2)
+    assert "mode=givenMass" in note and f"populations={n_pops}" in note and "walkers=4" in note
     assert head[0] == "logAge" and head[-2:] == ["logPost", "stage"] and res.shape == (5500 * 4, len(head))
     main = res[res[:, -1] == 3]
     assert len(main) == 1500 * 4 and np.all(np.isfinite(main[:, -2]))
@@ -216,8 +225,8 @@ def test_samplemass_cli_matches_oracle(hostlib, tmp_path):
     r = _cli("sampleMass", "--config", y, "--margIsoIncrem", "2", "--nMassRatios", "3", "--seed", "31")
     assert r.returncode == 0, r.stderr
     assert "star draws/s" in r.stderr
-    head = open(str(tmp_path / "run.res")).readline().split()
-    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
+    note, head = _res_head(str(tmp_path / "run.res"))
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=2)
     main = res[res[:, -1] == 3]
     ms = np.loadtxt(str(tmp_path / "run.massSamples"), skiprows=1)
     mb = np.loadtxt(str(tmp_path / "run.membership"), skiprows=1)
@@ -301,8 +310,9 @@ def test_mcmc_cli_marginalised_mode(hostlib, tmp_path):
     r = _cli("singlePopMcmc", "--config", y, "--marginalise", "--margIsoIncrem", "2", "--nMassRatios", "2", "--block", "10")
     assert r.returncode == 0, r.stderr
     assert "marginalised mode" in r.stderr
-    head = open(str(tmp_path / "run.res")).readline().split()
-    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
+    note, head = _res_head(str(tmp_path / "run.res"))
+    assert "mode=marginalised (margIsoIncrem=2, nMassRatios=2)" in note and "walkers=2" in note
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=2)
     assert res.shape == (30 * 2, len(head))
     cl2 = dict(cl0)
     lo, hi = np.where(np.asarray(cl["sigma"]) > 0, cl["obs"], np.inf).min(axis=0), np.where(np.asarray(cl["sigma"]) > 0, cl["obs"], -np.inf).max(axis=0)

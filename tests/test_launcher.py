@@ -1,0 +1,101 @@
+"""CPU tests of the two self-launchers (singlePopMcmc --gpus N in C++, bench.py --gpus N in Python): start-up deadline,
+exit code of a failed launch, clean-up -- and of bench.py's guard against stale profile counters.  No GPU is needed: the
+test hook B9_TEST_STALL parks a rank before it touches one."""
+import glob
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "base_amd", "host", "bin", "singlePopMcmc")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from base_amd import host_build
+    host_build.build_host()
+
+
+def _dist_dirs():
+    return set(glob.glob("/tmp/b9dist_*")) | set(glob.glob(os.path.join(os.environ.get("TMPDIR", "/tmp"), "b9dist_*")))
+
+
+def _run(cmd, env_extra, timeout=120):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "B9_RANK"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    return r, time.monotonic() - t0
+
+
+@pytest.mark.parametrize("which", ["cli", "bench"])
+def test_stalled_rank_ends_the_launch_at_the_deadline(which):
+    """A rank that never brings its communicator up (here: parked before anything) makes the launcher give up after
+    B9_LAUNCH_TIMEOUT_S, kill it and exit 124 -- instead of waiting for ever, as ncclCommInitRank would."""
+    before = _dist_dirs()
+    cmd = [EXE, "--gpus", "1", "--forceRanks"] if which == "cli" else [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-ranks"]
+    r, dt = _run(cmd, {"B9_TEST_STALL": "start:0", "B9_LAUNCH_TIMEOUT_S": "3"})
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert 2.5 <= dt < 60.0
+    assert "B9_LAUNCH_TIMEOUT_S" in r.stderr
+    assert _dist_dirs() == before, "the launcher left its bootstrap directory behind"
+
+
+def test_whole_run_deadline():
+    r, dt = _run([EXE, "--gpus", "1", "--forceRanks"], {"B9_TEST_STALL": "start:0", "B9_LAUNCH_TIMEOUT_S": "0", "B9_RUN_TIMEOUT_S": "2"})
+    assert r.returncode == 124 and "B9_RUN_TIMEOUT_S" in r.stderr and dt < 60.0
+
+
+@pytest.mark.parametrize("which", ["cli", "bench"])
+def test_exit_code_is_the_first_failure_not_the_sigterm_of_its_peers(which):
+    """Two ranks; rank 0 fails on its own (no model directory / no GPU here) while rank 1 is parked: the launcher ends rank 1
+    with SIGTERM and reports rank 0's exit code -- not 143 (or 15), the status of the rank it killed itself."""
+    before = _dist_dirs()
+    cmd = [EXE, "--gpus", "2"] if which == "cli" else [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"]
+    r, dt = _run(cmd, {"B9_TEST_STALL": "start:1", "B9_LAUNCH_TIMEOUT_S": "100"}, timeout=300)
+    assert r.returncode not in (0, 143, 15, 124), (r.returncode, r.stderr[-2000:])
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    assert dt < 100.0
+    assert _dist_dirs() == before
+
+
+def test_a_profile_of_other_sources_drops_the_counters(tmp_path, monkeypatch):
+    """bench.py divides the profile's per-launch counters by the LIVE launch time: when the kernel sources have changed
+    since the profile was taken, the counters are dropped (with the reason) instead of silently mixing two builds."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from base_amd import build
+    h = build.source_hash()
+    doc = {"commit": "abc1234", "csrc_sha256": h, "command": "x", "kernels": {"k_mcmc_step<8, 1>": {"avg_us": 15.0}},
+           "pmc": {"k_mcmc_step<8, 1>": {"hbm_bytes_per_launch": 1.0e7, "SQ_INSTS_VALU": 4.0e6, "SQ_ACTIVE_INST_VALU": 4.0e6,
+                                        "SQ_WAVE_CYCLES": 1.9e7, "SQ_WAVES": 2976}}}
+    os.makedirs(tmp_path / "profiles")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    pth = tmp_path / "profiles" / f"{bench.PROFILE_TAG}_summary.json"
+    pth.write_text(json.dumps(doc))
+    fresh = bench.profile_counters("k_mcmc_step", h)
+    assert "stale" not in fresh and fresh["valu_active_quad_cycles_per_launch"] == 4.0e6
+    roof = bench.valu_roofline(fresh, 15e-6, 1.0e8)
+    assert 0.4 < roof["frac"] < 0.5 and roof["traffic"] == 1.0e7 and 0.1 < roof["useful_frac"] < 0.3
+    # the same file against a tree whose sources differ
+    stale = bench.profile_counters("k_mcmc_step", "0" * 64)
+    assert "stale" in stale and "other kernel sources" in stale["stale"]
+    roof = bench.valu_roofline(stale, 15e-6, 1.0e8)
+    assert roof["frac"] is None and roof["achieved"] is None and roof["traffic"] is None and roof["hbm"]["frac"] is None
+    assert roof["useful_frac"] is not None            # needs no counter
+    pth.unlink()
+    assert "stale" in bench.profile_counters("k_mcmc_step", h)
+
+
+def test_useful_operation_model():
+    sys.path.insert(0, ROOT)
+    import bench
+    ops = bench.useful_lane_ops(8, 400, 0.3)
+    assert ops["search_rounds"] == 3 and ops["single"] < ops["binary"]
+    assert abs(ops["mean"] - (0.7 * ops["single"] + 0.3 * ops["binary"])) < 1e-9
+    assert bench.useful_lane_ops(8, 400, 0.3, n_pops=2)["single"] > ops["single"]

@@ -28,7 +28,7 @@ r = subprocess.run([exe, "--config", yml, "--verbose", "--priorDistMod", repr(fl
                    capture_output=True, text=True)
 lines = r.stderr.strip().split("\n")
 print("\n".join(lines[:12])); print("..."); print("\n".join(lines[-4:]))
-res = np.loadtxt(os.path.join(d, "run.res"), skiprows=1)
+res = np.loadtxt(os.path.join(d, "run.res"), skiprows=2)
 main = res[res[:, -1] == 3]
 print("truth ", truth[[0, 2, 3, 4]]); print("start ", start[[0, 2, 3, 4]])
 print("mean  ", main[:, :4].mean(axis=0)); print("std   ", main[:, :4].std(axis=0))

@@ -13,7 +13,7 @@ for args in (["--burnIter", "0", "--runIter", "10", "--thin", "7", "--walkers", 
              ["--burnIter", "33", "--runIter", "17", "--thin", "100", "--walkers", "2"]):
     yml = synth.write_yaml(os.path.join(d, "base9.yaml"), phot, root, os.path.join(d, "run"), truth, ms_model="dsed", burn=10, run=10, walkers=1)
     r = subprocess.run([exe + "singlePopMcmc", "--config", yml] + args, capture_output=True, text=True)
-    n = sum(1 for _ in open(os.path.join(d, "run.res"))) - 1
+    n = sum(1 for _ in open(os.path.join(d, "run.res"))) - 2
     print(args, "rc", r.returncode, "rows", n, r.stderr.strip().split("\n")[-1][:150])
     r2 = subprocess.run([exe + "sampleMass", "--config", yml] + args[:0], capture_output=True, text=True)
     print("   sampleMass rc", r2.returncode, r2.stderr.strip().split("\n")[-1][:160])
