@@ -58,6 +58,8 @@ struct b9_ctx {
     size_t partial_cap = 0;
     double *d_params = nullptr, *d_logpost = nullptr, *d_perstar = nullptr;
     size_t perstar_cap = 0;
+    double *d_marg_tab = nullptr;    // marginalised mode: the companions' flux table of the current call (k_marg_table)
+    size_t marg_tab_cap = 0;
     void *d_mcmc = nullptr;          // device state of b9_mcmc_run_block (two-launch step)
     struct McmcSlot {                // fused step: one enqueued block (device block, pinned mirror, completion event)
         void *d = nullptr, *h = nullptr, *h_dev = nullptr;   // h_dev: the pinned mirror as the device sees it (mapped)
@@ -265,6 +267,13 @@ int build_stars(b9_ctx *ctx)
     if ((rc = upload(ctx, ctx->star_allocs, hv_la.data(), hv_la.size(), &st.hv_la))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, hv_flags.data(), hv_flags.size(), &st.hv_flags))) return rc;
     if ((rc = upload(ctx, ctx->star_allocs, hv_perm.data(), hv_perm.size(), &st.hv_perm))) return rc;
+    {
+        std::vector<int> wd_slot;
+        for (int i = 0; i < n_pad; ++i) if (slot[i] >= 0 && h.stage[slot[i]] == B9_STAGE_WD) wd_slot.push_back(i);
+        st.n_wd = (int)wd_slot.size();
+        if (wd_slot.empty()) wd_slot.push_back(0);
+        if ((rc = upload(ctx, ctx->star_allocs, wd_slot.data(), wd_slot.size(), &st.wd_slot))) return rc;
+    }
     ctx->st = st;
     ctx->n_wd_stage = 0;
     for (int i = 0; i < n; ++i) ctx->n_wd_stage += h.stage[i] == B9_STAGE_WD;
@@ -313,6 +322,21 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
     return B9_OK;
 }
 
+
+// the marginalised mode's companion table for n_walkers rows (grown on demand)
+int ensure_marg_table(b9_ctx *ctx, int n_walkers, int n_pops, int K, int Q)
+{
+    if (Q < 2) return B9_OK;
+    const size_t need = (size_t)n_walkers * n_pops * (Q - 1) * ctx->pk.nfp * b9k_marg_table_npad(ctx->mass_cap, K);
+    if (need > ((size_t)8 << 30) / sizeof(double)) return fail(ctx, B9_ERR_CAPACITY, "marginalisation grid too fine: the companion table would exceed 8 GiB");
+    if (need > ctx->marg_tab_cap) {
+        if (ctx->d_marg_tab) (void)hipFree(ctx->d_marg_tab);
+        ctx->d_marg_tab = nullptr; ctx->marg_tab_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_marg_tab, need * sizeof(double)));
+        ctx->marg_tab_cap = need;
+    }
+    return B9_OK;
+}
 
 struct Plan { int tiles_per_block, n_groups; };
 
@@ -481,7 +505,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx->pack_allocs);
     free_all(ctx->star_allocs);
-    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_mcmc};
+    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_mcmc, ctx->d_marg_tab};
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (auto &sl : ctx->slot) {
         if (sl.d) (void)hipFree(sl.d);
@@ -735,8 +759,10 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
     if (ctx->opt.mode == B9_MODE_MARGINALISED) {
         const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
         const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
+        const int rc = ensure_marg_table(ctx, n_walkers, n_pops, K, Q);
+        if (rc) return rc;
         HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, nullptr, ctx->chunk_bounds, stream));
+                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, nullptr, ctx->chunk_bounds, ctx->n_cu, ctx->d_marg_tab, stream));
     } else {
         HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
                                   n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, ctx->st.n_pad, d_perstar,
@@ -1152,6 +1178,8 @@ int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t s
     const int chunk = std::min<int>(n_rows, 32);
     rc = ensure_capacity(ctx, chunk, n_pops, (size_t)ctx->st.n_pad * chunk, false);
     if (rc) return rc;
+    rc = ensure_marg_table(ctx, chunk, n_pops, K, Q);
+    if (rc) return rc;
     double *d_out = nullptr;
     int *d_pop = nullptr;
     const size_t per = (size_t)chunk * n;
@@ -1171,7 +1199,7 @@ int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t s
         B9MargSample smp{d_out, d_out + per, d_out + 2 * per, d_pop, (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), (long long)(row0 + r0)};
         // the kernel indexes its outputs [row][n_stars] with the launch's own row count: rows are contiguous for any m
         if (e == hipSuccess) e = b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params, m, n_pops,
-                                               ctx->d_partial, nullptr, K, Q, &smp, ctx->chunk_bounds, s);
+                                               ctx->d_partial, nullptr, K, Q, &smp, ctx->chunk_bounds, ctx->n_cu, ctx->d_marg_tab, s);
         const size_t cnt = (size_t)m * n, o = (size_t)r0 * n;
         if (e == hipSuccess) e = hipMemcpyAsync(out_mass + o, d_out, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(out_ratio + o, d_out + per, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);

@@ -66,6 +66,10 @@ struct DevStars {
     const double *hv_obs, *hv_w;     // [nfp][hv_pad]
     const double *hv_q, *hv_c0, *hv_la;   // [hv_pad]
     const int *hv_flags, *hv_perm;   // [hv_pad]  (hv_perm: original index of the star)
+    // the slots of the stars the catalogue marks as white dwarfs (stage WD), ascending: the marginalised mode evaluates
+    // them in a launch of their own (k_star_marg_wd)
+    int n_wd;
+    const int *wd_slot;              // [max(1, n_wd)]
 };
 
 // Header of one derived isochrone (one per walker x population).
