@@ -60,7 +60,6 @@ struct b9_ctx {
     size_t perstar_cap = 0;
     double *d_marg_tab = nullptr;    // marginalised mode: the companions' flux table of the current call (k_marg_table)
     size_t marg_tab_cap = 0;
-    void *d_mcmc = nullptr;          // device state of b9_mcmc_run_block (two-launch step)
     struct McmcSlot {                // fused step: one enqueued block (device block, pinned mirror, completion event)
         void *d = nullptr, *h = nullptr, *h_dev = nullptr;   // h_dev: the pinned mirror as the device sees it (mapped)
         size_t cap = 0, hcap = 0;
@@ -71,10 +70,11 @@ struct b9_ctx {
         size_t o_nacc = 0, o_st0 = 0, o_st1 = 0, o_samp = 0, o_lps = 0, o_rows = 0, n_samp = 0, n_lps = 0, n_rows = 0;
         bool host_samples = false; // the caller asked for the chain record (else it only exists on the device, for the rows)
         hipEvent_t rows_ready = nullptr;   // recorded right after the block's last kernel: the summary rows are in HBM
+        int kind = 0;                      // 0: fused one-launch steps; 1: two-launch steps (marginalised mode)
+        size_t o_cur = 0, o_lp = 0;        // two-launch blocks: where the final state half sits in the block
     } slot[2];
     int next_slot = 0, last_slot = -1;
     double *h_lp = nullptr, *h_lp_dev = nullptr;   // b9_logpost: 8 log-posteriors in mapped pinned host memory (host / device view)
-    size_t mcmc_cap = 0;
 
     // launch plan
     int n_cu = 256;            // compute units of the device (hipDeviceAttributeMultiprocessorCount)
@@ -505,7 +505,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx->pack_allocs);
     free_all(ctx->star_allocs);
-    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_mcmc, ctx->d_marg_tab};
+    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_marg_tab};
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (auto &sl : ctx->slot) {
         if (sl.d) (void)hipFree(sl.d);
@@ -862,6 +862,17 @@ static int collect_block(b9_ctx *ctx, b9_ctx::McmcSlot &sl, b9_mcmc_block *blk)
     HIPCHK(ctx, hipEventSynchronize(sl.done));
     sl.in_flight = false;
     const double *stage = static_cast<const double *>(sl.h);
+    if (sl.kind == 1) {             // two-launch block: [cur][lp] of the final half, n_acc as a 64-bit count
+        std::memcpy(blk->params, stage + sl.o_cur, sizeof(double) * (size_t)sl.W * B9_NPARAM);
+        std::memcpy(blk->logpost, stage + sl.o_lp, sizeof(double) * (size_t)sl.W);
+        if (sl.n_samp && sl.host_samples && blk->samples) std::memcpy(blk->samples, stage + sl.o_samp, sl.n_samp * 8);
+        if (sl.n_rows && blk->rows) std::memcpy(blk->rows, stage + sl.o_rows, sl.n_rows * 8);
+        if (sl.n_lps && blk->lps) std::memcpy(blk->lps, stage + sl.o_lps, sl.n_lps * 8);
+        unsigned long long n_acc = 0;
+        std::memcpy(&n_acc, stage + sl.o_nacc, sizeof n_acc);
+        blk->n_accept = (int64_t)n_acc;
+        return B9_OK;
+    }
     const double *fin = stage + (sl.final_parity ? sl.o_st1 : sl.o_st0);
     for (int w = 0; w < sl.W; ++w) {
         std::memcpy(blk->params + (size_t)w * B9_NPARAM, fin + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, sizeof(double) * B9_NPARAM);
@@ -887,8 +898,8 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     // predecessor is still running or waiting to be collected
     b9_ctx::McmcSlot &sl = ctx->slot[ctx->next_slot];
     if (sl.in_flight) return fail(ctx, B9_ERR_STATE, "two blocks are already outstanding: collect one with b9_mcmc_wait first");
-    if (cont && (ctx->last_slot < 0 || ctx->slot[ctx->last_slot].W != W))
-        return fail(ctx, B9_ERR_STATE, "B9_BLOCK_CONTINUE needs a previous block of this context with the same n_walkers");
+    if (cont && (ctx->last_slot < 0 || ctx->slot[ctx->last_slot].W != W || ctx->slot[ctx->last_slot].kind != 0))
+        return fail(ctx, B9_ERR_STATE, "B9_BLOCK_CONTINUE needs a previous block of this context with the same n_walkers and mode");
     const bool want_rows = blk->row_origin != nullptr;
     const size_t n_state = (size_t)W * B9_STATE_STRIDE, n_cur = (size_t)W * B9_NPARAM,
                  n_samp = (blk->samples || want_rows) ? (size_t)S * W * d : 0, n_lps = blk->lps ? (size_t)S * W : 0,
@@ -1017,9 +1028,126 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     blk->rows_ready = rows_event ? (void *)sl.rows_ready : nullptr;
     if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(stage + o_nacc, dev + o_nacc, down_words * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipEventRecord(sl.done, s));
+    sl.kind = 0;
     sl.W = W; sl.final_parity = (S + 1) & 1;
     sl.o_nacc = o_nacc; sl.o_st0 = o_st0; sl.o_st1 = o_st1; sl.o_samp = o_samp; sl.o_lps = o_lps; sl.n_samp = n_samp; sl.n_lps = n_lps;
     sl.o_rows = o_rows; sl.n_rows = n_rows; sl.host_samples = blk->samples != nullptr;
+    sl.in_flight = true; sl.owner = blk;
+    ctx->last_slot = ctx->next_slot;
+    ctx->next_slot ^= 1;
+    return async ? B9_OK : collect_block(ctx, sl, blk);
+}
+
+/* Device-resident Metropolis block with TWO launches per step (marginalised mode; b9_tuning.two_launch_steps):
+ *   D(0) L(0)  D(1) L(1)  ...  D(S-1) L(S-1)  F  [R]
+ *   D(t) = k_derive_iso: finishes step t-1 (sum + prior + accept; t > 0), proposes step t, derives its isochrones
+ *   L(t) = the star likelihood of step t's proposals;   F = k_finalize: finishes the last step;
+ *   R    = k_chain_rows: the block's per-walker summary rows, condensed from the chain record on the device.
+ * Same contract as the fused path: one pinned mirror per slot for the upload and the download, B9_BLOCK_ASYNC /
+ * B9_BLOCK_CONTINUE / summary rows in HBM behind rows_ready -- a star launch here takes milliseconds, so none of this is for
+ * speed; it gives a multi-GPU driver ONE way to run blocks and to read rows, whatever the evaluation mode. */
+static int run_block_two_launch(b9_ctx *ctx, b9_mcmc_block *blk, const Plan &plan)
+{
+    const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps, n_pops = ctx->opt.n_pops;
+    const bool cont = (blk->flags & B9_BLOCK_CONTINUE) != 0, async = (blk->flags & B9_BLOCK_ASYNC) != 0;
+    b9_ctx::McmcSlot &sl = ctx->slot[ctx->next_slot];
+    if (sl.in_flight) return fail(ctx, B9_ERR_STATE, "two blocks are already outstanding: collect one with b9_mcmc_wait first");
+    if (cont && (ctx->last_slot < 0 || ctx->slot[ctx->last_slot].W != W || ctx->slot[ctx->last_slot].kind != 1))
+        return fail(ctx, B9_ERR_STATE, "B9_BLOCK_CONTINUE needs a previous block of this context with the same n_walkers and mode");
+    const bool want_rows = blk->row_origin != nullptr;
+    const size_t n_cur = (size_t)W * B9_NPARAM, n_samp = (blk->samples || want_rows) ? (size_t)S * W * d : 0,
+                 n_lps = blk->lps ? (size_t)S * W : 0, n_rows = want_rows ? (size_t)W * B9_ROW_LEN(d) : 0;
+    // [chol][origin][free, ids][n_acc][cur: two halves][lp: two halves][rows][lps][samples]
+    //  upload = chol .. first half of lp's start state;  download = n_acc .. lps (.. samples when the caller wants the chain)
+    const size_t n_int = ((size_t)(d + W) + 1) / 2;
+    const size_t o_chol = 0, o_org = o_chol + (size_t)d * d, o_int = o_org + d, o_nacc = o_int + n_int, o_cur = o_nacc + 1,
+                 o_lp = o_cur + 2 * n_cur, o_rows = o_lp + 2 * (size_t)W, o_lps = o_rows + n_rows, o_samp = o_lps + n_lps,
+                 n_total = o_samp + n_samp;
+    if (n_total * 8 > sl.cap) {
+        if (sl.d) (void)hipFree(sl.d);
+        sl.d = nullptr; sl.cap = 0;
+        HIPCHK(ctx, hipMalloc(&sl.d, n_total * 8));
+        sl.cap = n_total * 8;
+    }
+    if (n_total * 8 > sl.hcap) {
+        if (sl.h) (void)hipHostFree(sl.h);
+        sl.h = nullptr; sl.hcap = 0;
+        HIPCHK(ctx, hipHostMalloc(&sl.h, n_total * 8, hipHostMallocMapped));
+        HIPCHK(ctx, hipHostGetDevicePointer(&sl.h_dev, sl.h, 0));
+        sl.hcap = n_total * 8;
+    }
+    if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.rows_ready) HIPCHK(ctx, hipEventCreateWithFlags(&sl.rows_ready, hipEventDisableTiming));
+    double *const dev = static_cast<double *>(sl.d), *const stage = static_cast<double *>(sl.h);
+    hipStream_t s = ctx->stream;
+    // upload: proposal factor, moment origin, RNG streams, cleared counter and (unless continuing) the starting state
+    std::memcpy(stage + o_chol, blk->chol, (size_t)d * d * 8);
+    if (want_rows) std::memcpy(stage + o_org, blk->row_origin, (size_t)d * 8); else std::memset(stage + o_org, 0, (size_t)d * 8);
+    int *hi = reinterpret_cast<int *>(stage + o_int);
+    std::memcpy(hi, blk->free_idx, d * sizeof(int));
+    std::memcpy(hi + d, blk->walker_ids, W * sizeof(int));
+    std::memset(stage + o_nacc, 0, 8);
+    HIPCHK(ctx, hipMemcpyAsync(dev + o_chol, stage + o_chol, (o_cur - o_chol) * 8, hipMemcpyHostToDevice, s));
+    if (!cont) {
+        std::memcpy(stage + o_cur, blk->params, n_cur * 8);
+        std::memcpy(stage + o_lp, blk->logpost, (size_t)W * 8);
+        HIPCHK(ctx, hipMemcpyAsync(dev + o_cur, stage + o_cur, n_cur * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(dev + o_lp, stage + o_lp, (size_t)W * 8, hipMemcpyHostToDevice, s));
+    } else {      // the previous block's final half (stream-ordered behind its last launch) -> this block's half 0
+        const b9_ctx::McmcSlot &pv = ctx->slot[ctx->last_slot];
+        const double *pd = static_cast<const double *>(pv.d);
+        HIPCHK(ctx, hipMemcpyAsync(dev + o_cur, pd + pv.o_cur, n_cur * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(dev + o_lp, pd + pv.o_lp, (size_t)W * 8, hipMemcpyDeviceToDevice, s));
+    }
+    McmcDev mc{};
+    mc.enabled = 1; mc.d = d; mc.n_walkers = W;
+    mc.cur = dev + o_cur; mc.lp_cur = dev + o_lp;
+    mc.chol = dev + o_chol;
+    mc.free_idx = reinterpret_cast<int *>(dev + o_int); mc.walker_ids = mc.free_idx + d;
+    mc.samples = n_samp ? dev + o_samp : nullptr; mc.lps = n_lps ? dev + o_lps : nullptr;
+    mc.n_acc = reinterpret_cast<unsigned long long *>(dev + o_nacc);
+    mc.k0 = (unsigned)(blk->seed & 0xFFFFFFFFull); mc.k1 = (unsigned)(blk->seed >> 32);
+    const int n_part = partial_count(ctx, plan);
+    for (int t = 0; t < S; ++t) {
+        const Bufs bf = buffer_set(ctx, t & 1), bp = buffer_set(ctx, (t & 1) ^ 1);
+        mc.step = (unsigned long long)(blk->step0 + t);     // the step being proposed
+        mc.has_prev = t > 0;
+        mc.pin = t > 0 ? (t - 1) & 1 : 0;                   // state half on entry
+        mc.row = t - 1;                                     // chain row of the step being finished
+        const B9Prev prev{ctx->d_partial, n_part, (long long)ctx->st.n_pad, bp.hdr, bp.params};
+        HIPCHK(ctx, b9k_derive_iso(ctx->pk, bf.params, W, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap,
+                                   mc, ctx->pr, prev, s));
+        const int rc = launch_stars(ctx, bf, W, nullptr, plan, s);
+        if (rc) return rc;
+    }
+    {   // finish the last step
+        const Bufs bf = buffer_set(ctx, (S - 1) & 1);
+        mc.step = (unsigned long long)(blk->step0 + S - 1);
+        mc.has_prev = 0;
+        mc.pin = S > 1 ? (S - 2) & 1 : 0;                   // the half D(S-1) wrote (or the initial half)
+        if (S > 1) mc.pin ^= 1;
+        mc.row = S - 1;
+        HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, n_part, ctx->st.n_pad, n_pops, bf.params, ctx->pr, W,
+                                 ctx->d_logpost, nullptr, ctx->st.n, mc, s));
+    }
+    const int fin = mc.pin ^ 1;                             // half that holds the final state
+    const size_t o_cur_fin = o_cur + (size_t)fin * n_cur, o_lp_fin = o_lp + (size_t)fin * W;
+    if (want_rows) {
+        StepDev sd{};
+        sd.d = d; sd.n_walkers = W; sd.n_steps = S; sd.samples = mc.samples; sd.free_idx = mc.free_idx;
+        sd.row_origin = dev + o_org; sd.rows = dev + o_rows; sd.host_rows = nullptr;
+        HIPCHK(ctx, b9k_chain_rows(sd, dev + o_cur_fin, dev + o_lp_fin, s));
+    }
+    const bool rows_event = want_rows && (blk->flags & B9_BLOCK_ROWS_EVENT) != 0;
+    if (rows_event) HIPCHK(ctx, hipEventRecord(sl.rows_ready, s));
+    blk->d_rows = want_rows ? (void *)(dev + o_rows) : nullptr;
+    blk->rows_ready = rows_event ? (void *)sl.rows_ready : nullptr;
+    const size_t down_end = blk->samples ? n_total : o_samp;
+    HIPCHK(ctx, hipMemcpyAsync(stage + o_nacc, dev + o_nacc, (down_end - o_nacc) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipEventRecord(sl.done, s));
+    sl.kind = 1; sl.W = W; sl.final_parity = fin;
+    sl.o_nacc = o_nacc; sl.o_cur = o_cur_fin; sl.o_lp = o_lp_fin; sl.o_samp = o_samp; sl.o_lps = o_lps; sl.o_rows = o_rows;
+    sl.n_samp = n_samp; sl.n_lps = n_lps; sl.n_rows = n_rows; sl.host_samples = blk->samples != nullptr;
     sl.in_flight = true; sl.owner = blk;
     ctx->last_slot = ctx->next_slot;
     ctx->next_slot ^= 1;
@@ -1048,72 +1176,7 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     rc = ensure_capacity(ctx, W, n_pops, (size_t)ctx->st.n_pad * W, false);
     if (rc) return rc;
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) return run_block_fused(ctx, blk);
-    if (blk->flags) return fail(ctx, B9_ERR_INVALID, "B9_BLOCK_CONTINUE / B9_BLOCK_ASYNC need the fused step (given-mass mode)");
-    if (blk->row_origin) return fail(ctx, B9_ERR_INVALID, "device summary rows (row_origin) need the fused step (given-mass mode): condense the samples on the host");
-    // marginalised mode (and B9_TWO_LAUNCH_STEPS=1): two launches per step
-    // one device allocation for the block's state
-    const size_t n_cur = (size_t)W * B9_NPARAM, n_samp = blk->samples ? (size_t)S * W * d : 0,
-                 n_lps = blk->lps ? (size_t)S * W : 0;
-    const size_t doubles = 2 * n_cur + 2 * (size_t)W + (size_t)d * d + n_samp + n_lps + 1;
-    const size_t bytes = doubles * sizeof(double) + (size_t)(d + W) * sizeof(int);
-    if (bytes > ctx->mcmc_cap) {
-        if (ctx->d_mcmc) (void)hipFree(ctx->d_mcmc);
-        ctx->d_mcmc = nullptr; ctx->mcmc_cap = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_mcmc, bytes));
-        ctx->mcmc_cap = bytes;
-    }
-    double *p = static_cast<double *>(ctx->d_mcmc);
-    McmcDev mc{};
-    mc.enabled = 1; mc.d = d; mc.n_walkers = W;
-    mc.cur = p; p += 2 * n_cur;
-    mc.lp_cur = p; p += 2 * (size_t)W;
-    double *d_chol = p; p += (size_t)d * d;
-    mc.samples = n_samp ? p : nullptr; p += n_samp;
-    mc.lps = n_lps ? p : nullptr; p += n_lps;
-    mc.n_acc = reinterpret_cast<unsigned long long *>(p); p += 1;
-    int *d_free = reinterpret_cast<int *>(p), *d_ids = d_free + d;
-    mc.chol = d_chol; mc.free_idx = d_free; mc.walker_ids = d_ids;
-    mc.k0 = (unsigned)(blk->seed & 0xFFFFFFFFull); mc.k1 = (unsigned)(blk->seed >> 32);
-    hipStream_t s = ctx->stream;
-    HIPCHK(ctx, hipMemcpyAsync(mc.cur, blk->params, n_cur * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(mc.lp_cur, blk->logpost, W * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(d_chol, blk->chol, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(d_free, blk->free_idx, d * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(d_ids, blk->walker_ids, W * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemsetAsync(mc.n_acc, 0, sizeof(unsigned long long), s));
-    const int n_part = partial_count(ctx, plan);
-    for (int t = 0; t < S; ++t) {
-        const Bufs bf = buffer_set(ctx, t & 1), bp = buffer_set(ctx, (t & 1) ^ 1);
-        mc.step = (unsigned long long)(blk->step0 + t);     // the step being proposed
-        mc.has_prev = t > 0;
-        mc.pin = t > 0 ? (t - 1) & 1 : 0;                   // state half on entry
-        mc.row = t - 1;                                     // chain row of the step being finished
-        const B9Prev prev{ctx->d_partial, n_part, (long long)ctx->st.n_pad, bp.hdr, bp.params};
-        HIPCHK(ctx, b9k_derive_iso(ctx->pk, bf.params, W, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap,
-                                   mc, ctx->pr, prev, s));
-        rc = launch_stars(ctx, bf, W, nullptr, plan, s);
-        if (rc) return rc;
-    }
-    {   // finish the last step
-        const Bufs bf = buffer_set(ctx, (S - 1) & 1);
-        mc.step = (unsigned long long)(blk->step0 + S - 1);
-        mc.has_prev = 0;
-        mc.pin = S > 1 ? (S - 2) & 1 : 0;                   // the half D(S-1) wrote (or the initial half)
-        if (S > 1) mc.pin ^= 1;
-        mc.row = S - 1;
-        HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, n_part, ctx->st.n_pad, n_pops, bf.params, ctx->pr, W,
-                                 ctx->d_logpost, nullptr, ctx->st.n, mc, s));
-    }
-    const int fin = mc.pin ^ 1;                             // half that holds the final state
-    unsigned long long n_acc = 0;
-    HIPCHK(ctx, hipMemcpyAsync(blk->params, mc.cur + (size_t)fin * n_cur, n_cur * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipMemcpyAsync(blk->logpost, mc.lp_cur + (size_t)fin * W, W * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (n_samp) HIPCHK(ctx, hipMemcpyAsync(blk->samples, mc.samples, n_samp * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (n_lps) HIPCHK(ctx, hipMemcpyAsync(blk->lps, mc.lps, n_lps * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipMemcpyAsync(&n_acc, mc.n_acc, sizeof n_acc, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    blk->n_accept = (int64_t)n_acc;
-    return B9_OK;
+    return run_block_two_launch(ctx, blk, plan);
 }
 
 int b9_mcmc_wait(b9_ctx *ctx, b9_mcmc_block *blk)

@@ -323,6 +323,12 @@ hipError_t b9k_mcmc_finish(const DevPack &pk, const StepDev &sd, const DevPriors
     return hipGetLastError();
 }
 
+hipError_t b9k_chain_rows(const StepDev &sd, const double *cur_fin, const double *lp_fin, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_chain_rows, dim3(sd.n_walkers), dim3(256), 0, stream, sd, cur_fin, lp_fin);
+    return hipGetLastError();
+}
+
 // An empty kernel: bracketing it with HIP events measures what an event bracket adds to a kernel's
 // own duration (dispatch boundary + event processing); b9_calibrate_timing subtracts nothing by
 // itself, it only reports the figure.

@@ -59,5 +59,8 @@ hipError_t b9k_mcmc_continue(const double *prev_final, double *cur0, double *lp0
 // the block's last decision only (one workgroup per walker)
 hipError_t b9k_mcmc_finish(const DevPack &pk, const StepDev &sd, const DevPriors &pr, hipStream_t stream);
 
+// summary rows of a two-launch block from its chain record on the device (sd: d, n_walkers, n_steps, samples, free_idx, row_origin, rows)
+hipError_t b9k_chain_rows(const StepDev &sd, const double *cur_fin, const double *lp_fin, hipStream_t stream);
+
 hipError_t b9k_noop(hipStream_t stream);
 hipError_t b9k_spin(double microseconds, hipStream_t stream);

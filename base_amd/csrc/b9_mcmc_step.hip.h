@@ -530,6 +530,18 @@ __global__ __launch_bounds__(256) void k_mcmc_finish(DevPack pk, StepDev sd, Dev
     }
 }
 
+// Summary rows of a block whose steps were two launches each (marginalised mode): the chain record is on the device,
+// the walker's final state in `cur_fin` / `lp_fin`; same sums, same order, same bits as k_mcmc_finish's rows.
+__global__ __launch_bounds__(256) void k_chain_rows(StepDev sd, const double *__restrict__ cur_fin, const double *__restrict__ lp_fin)
+{
+    __shared__ double s_last[B9_NPARAM + 2];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (tid < B9_NPARAM) s_last[tid] = cur_fin[(size_t)w * B9_NPARAM + tid];
+    if (tid == B9_NPARAM) { s_last[B9_NPARAM] = lp_fin[w]; s_last[B9_NPARAM + 1] = 0.0; }
+    __syncthreads();
+    block_summary_row(sd, w, s_last);
+}
+
 // The block's opening: ONE small launch copies the block's upload (starting state, proposal factor, moment origin,
 // RNG streams, cleared counters) from the pinned host mirror, mapped into the device, into the device block -- and, for a
 // block that continues its predecessor (B9_BLOCK_CONTINUE), takes the starting state from that block's final state

@@ -40,8 +40,8 @@ bool cholesky(std::vector<double> &a, int d)      // in place, lower; false if n
 // ---- the GPU runner ------------------------------------------------------------------------------------------
 class DeviceRunner final : public BlockRunner {
   public:
-    DeviceRunner(b9_ctx *ctx, int n_local, const std::vector<int32_t> &ids, const std::vector<int32_t> &free_idx, uint64_t seed, bool fused)
-        : ctx_(ctx), W_(n_local), d_((int)free_idx.size()), ids_(ids), free_(free_idx), seed_(seed), fused_(fused)
+    DeviceRunner(b9_ctx *ctx, int n_local, const std::vector<int32_t> &ids, const std::vector<int32_t> &free_idx, uint64_t seed)
+        : ctx_(ctx), W_(n_local), d_((int)free_idx.size()), ids_(ids), free_(free_idx), seed_(seed)
     {
         params_.assign((size_t)W_ * B9_NPARAM, 0.0);
         logpost_.assign(W_, 0.0);
@@ -61,7 +61,7 @@ class DeviceRunner final : public BlockRunner {
         s.params = params_; s.logpost = logpost_;           // inputs of the first block; outputs of every block
         s.chol.assign(job.chol, job.chol + (size_t)d_ * d_);
         s.origin.assign(job.origin, job.origin + d_);
-        if (job.want_samples || !fused_) { s.samples.resize(n * W_ * d_); s.lps.resize(n * W_); }
+        if (job.want_samples) { s.samples.resize(n * W_ * d_); s.lps.resize(n * W_); }
         s.rows.resize((size_t)W_ * B9_ROW_DOUBLES(d_));
         s.want_samples = job.want_samples;
         b9_mcmc_block &b = s.blk;
@@ -69,21 +69,19 @@ class DeviceRunner final : public BlockRunner {
         b.n_walkers = W_; b.n_free = d_; b.free_idx = free_.data(); b.chol = s.chol.data(); b.walker_ids = ids_.data();
         b.seed = seed_; b.step0 = job.step0; b.n_steps = job.n_steps;
         b.params = s.params.data(); b.logpost = s.logpost.data();
-        const bool host_chain = job.want_samples || !fused_;
-        b.samples = host_chain ? s.samples.data() : nullptr;
-        b.lps = host_chain ? s.lps.data() : nullptr;
-        if (fused_) {
-            b.flags = B9_BLOCK_ASYNC | (first_ ? 0 : B9_BLOCK_CONTINUE) | (job.want_device_rows ? B9_BLOCK_ROWS_EVENT : 0);
-            b.row_origin = s.origin.data();
-            b.rows = s.rows.data();
-        }
+        b.samples = job.want_samples ? s.samples.data() : nullptr;
+        b.lps = job.want_samples ? s.lps.data() : nullptr;
+        // both evaluation modes: enqueued without waiting, continuing from the state the previous block leaves on the
+        // device, summary rows condensed by the block's last launch (in HBM for an exchange that reads them there)
+        b.flags = B9_BLOCK_ASYNC | (first_ ? 0 : B9_BLOCK_CONTINUE) | (job.want_device_rows ? B9_BLOCK_ROWS_EVENT : 0);
+        b.row_origin = s.origin.data();
+        b.rows = s.rows.data();
         const int rc = b9_mcmc_run_block(ctx_, &b);
         if (rc != B9_OK) fail(b9_last_error(ctx_));
-        s.pending = fused_;
-        if (!fused_) { params_ = s.params; logpost_ = s.logpost; }     // synchronous: the state is back already
+        s.pending = true;
         first_ = false;
         Submitted r;
-        if (fused_ && job.want_device_rows) { r.d_rows = static_cast<const double *>(b.d_rows); r.rows_ready = b.rows_ready; }
+        if (job.want_device_rows) { r.d_rows = static_cast<const double *>(b.d_rows); r.rows_ready = b.rows_ready; }
         return r;
     }
 
@@ -123,8 +121,6 @@ class DeviceRunner final : public BlockRunner {
     std::vector<double> params_, logpost_;
     Slot slot_[2];
     bool first_ = true;
-    const bool fused_;      // given-mass mode: one launch per step, pipelined blocks, rows condensed on the device;
-                            // marginalised mode: two launches per step, synchronous blocks, rows condensed here from the chain
 };
 
 // ---- the test seam: blocks and evaluations through caller-supplied callbacks -----------------------------------
@@ -203,7 +199,8 @@ class CallbackExchange final : public Exchange {
 std::unique_ptr<BlockRunner> make_device_runner(b9_ctx *ctx, int n_local, const std::vector<int32_t> &walker_ids,
                                                 const std::vector<int32_t> &free_idx, uint64_t seed, int mode)
 {
-    return std::unique_ptr<BlockRunner>(new DeviceRunner(ctx, n_local, walker_ids, free_idx, seed, mode == B9_MODE_GIVEN_MASS));
+    (void)mode;      // (since ABI 3 both modes run pipelined blocks with device rows; kept in the signature for callers)
+    return std::unique_ptr<BlockRunner>(new DeviceRunner(ctx, n_local, walker_ids, free_idx, seed));
 }
 std::unique_ptr<BlockRunner> make_callback_runner(b9h_block_fn run, b9h_logpost_fn eval, void *user, int n_local,
                                                   const std::vector<int32_t> &walker_ids, const std::vector<int32_t> &free_idx, uint64_t seed)

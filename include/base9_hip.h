@@ -247,7 +247,7 @@ typedef struct b9_mcmc_block {
     double *samples;             /* out, nullable                                             */
     double *lps;                 /* out, nullable                                             */
     int64_t n_accept;            /* out                                                       */
-    /* ---- block summary rows (ABI 2; given-mass mode).  row_origin != NULL: the block's last launch also condenses
+    /* ---- block summary rows (ABI 2; both evaluation modes since ABI 3).  row_origin != NULL: the block's last launch also condenses
      * every walker's chain into ONE row of B9_ROW_DOUBLES(n_free) doubles on the device,
      *     [0] log-posterior after the block   [1..12] position after the block
      *     [13] steps after the block's first on which the walker moved   [14] n_steps
@@ -266,7 +266,7 @@ typedef struct b9_mcmc_block {
 int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk);
 
 /*
- * Pipelining blocks (given-mass mode).  B9_BLOCK_ASYNC: b9_mcmc_run_block returns as soon as the block is
+ * Pipelining blocks (both evaluation modes; a block may only continue a block of the same mode).  B9_BLOCK_ASYNC: b9_mcmc_run_block returns as soon as the block is
  * enqueued on the context's stream; b9_mcmc_wait(ctx, blk) -- same blk, whose host arrays must stay valid --
  * blocks until it has run and fills params / logpost / samples / lps / n_accept.  B9_BLOCK_CONTINUE: the block
  * starts from the state the PREVIOUS block of this context left on the device (its params / logpost inputs are

@@ -262,7 +262,10 @@ def test_sampler_logposts_match_oracle_full_size(name):
 
 
 def test_marginalised_mode_through_the_sampler():
-    """Marginalised mode has no fused step: synchronous two-launch blocks, rows condensed on the host from the chain."""
+    """Marginalised mode runs the same pipelined blocks as given-mass mode (two launches per step instead of one):
+    B9_BLOCK_ASYNC | CONTINUE, summary rows condensed on the device (k_chain_rows) and read from HBM by a one-rank RCCL
+    all-gather.  Chain log-posteriors equal the oracle's marginalised ones; the device rows equal the host statement;
+    two continued blocks equal one block of twice the length; the RCCL exchange changes nothing."""
     from base_amd import engine
     pack_d, cl, pack, stars, priors, _ = build_problem("dsed", 8, n_stars=200, seed=4)
     options = abi.make_options(abi.MODE_MARGINALISED, 1, 2, 2)
@@ -277,6 +280,38 @@ def test_marginalised_mode_through_the_sampler():
     want = orc.logpost(rows)
     assert np.max(np.abs(lps[[3, 17, 29], 1] - want) / np.maximum(1.0, np.abs(want))) <= 1e-9
     assert s.state()["steps"] == 30
+    # one-rank RCCL exchange reading the rows in HBM: the same chain
+    ex = hostlib.Exchange.rccl(0, 1, eng.device_id(), directory=None)
+    s2 = hostlib.HostSampler(4, FREE, STEP, ex, seed=5, block=10, engine=eng)
+    s2.initialise(start)
+    samples2, lps2 = s2.run(30, adapt=True, record=True)
+    np.testing.assert_array_equal(samples2, samples)
+    np.testing.assert_array_equal(lps2, lps)
+    # block level: device rows == host statement; async + continue == one long block
+    free = np.array(FREE, dtype=np.int32)
+    chol = np.diag(STEP) * 2.0
+    lp0 = eng.logpost(start)
+    origin = start[:, free].mean(axis=0)
+    one = eng.mcmc_submit(start, lp0, np.arange(4), free, chol, 9, 0, 16, record=True, asynchronous=False, row_origin=origin)
+    p1, l1, x1, y1, a1 = eng.mcmc_collect(one)
+    np.testing.assert_array_equal(one["rows"], hostlib.summary_rows(x1, p1, l1, origin))
+    ha = eng.mcmc_submit(start, lp0, np.arange(4), free, chol, 9, 0, 8, record=True, asynchronous=True, row_origin=origin)
+    hb = eng.mcmc_submit(start, lp0, np.arange(4), free, chol, 9, 8, 8, record=True, cont=True, asynchronous=True, row_origin=origin)
+    pa, la, xa, ya, aa = eng.mcmc_collect(ha)
+    pb, lb, xb, yb, ab = eng.mcmc_collect(hb)
+    np.testing.assert_array_equal(np.concatenate([xa, xb]), x1)
+    np.testing.assert_array_equal(np.concatenate([ya, yb]), y1)
+    np.testing.assert_array_equal(pb, p1)
+    assert aa + ab == a1
+    np.testing.assert_array_equal(hb["rows"], hostlib.summary_rows(xb, pb, lb, origin))
+    # a marginalised block cannot continue a given-mass block
+    eng.set_options(abi.make_options(abi.MODE_GIVEN_MASS, 1, 2, 2))
+    hg = eng.mcmc_submit(start, eng.logpost(start), np.arange(4), free, chol, 9, 0, 4, record=False, asynchronous=False)
+    eng.mcmc_collect(hg)
+    eng.set_options(options)
+    with pytest.raises(engine.B9Error):
+        eng.mcmc_submit(start, lp0, np.arange(4), free, chol, 9, 4, 4, record=False, cont=True, asynchronous=False)
+    eng.close()
 
 
 def test_bench_self_launch_two_ranks_on_one_box():
