@@ -70,8 +70,8 @@ class b9_options(C.Structure):
 class b9_tuning(C.Structure):
     """Launch-plan tuning (include/base9_hip.h); all zeros = automatic."""
     _fields_ = [(n, C.c_int32) for n in ("tiles_per_block", "derive_parts", "derive_order", "heavy_parts", "walkers_per_lane",
-                                         "contiguous_tiles", "two_launch_steps", "no_chunk_bounds", "timing_group", "plan_debug")] + \
-               [("reserved", C.c_int32 * 6)]
+                                         "contiguous_tiles", "two_launch_steps", "no_chunk_bounds", "timing_group", "plan_debug", "tree_depth")] + \
+               [("reserved", C.c_int32 * 5)]
 
 
 class b9_mcmc_block(C.Structure):
@@ -192,7 +192,7 @@ ABI_SYMBOLS = [
     "b9_abi_version", "b9_ctx_create", "b9_ctx_destroy", "b9_last_error",
     "b9_load_pack", "b9_load_stars", "b9_set_priors", "b9_set_options", "b9_set_tuning",
     "b9_logpost", "b9_logpost_device", "b9_mcmc_run_block", "b9_mcmc_wait", "b9_sample_mass", "b9_derive_isochrone",
-    "b9_max_eep", "b9_device_id", "b9_bytes_per_star_eval", "b9_step_tiles_per_block",
+    "b9_max_eep", "b9_device_id", "b9_bytes_per_star_eval", "b9_step_tiles_per_block", "b9_step_depth",
     "b9_enable_timing", "b9_kernel_time_ms", "b9_calibrate_timing",
 ]
 
@@ -227,6 +227,7 @@ def load_hip_library(path: Optional[str] = None) -> C.CDLL:
     lib.b9_device_id.argtypes = [vp]
     lib.b9_bytes_per_star_eval.argtypes = [vp]
     lib.b9_step_tiles_per_block.argtypes = [vp, C.c_int32]
+    lib.b9_step_depth.argtypes = [vp, C.c_int32]
     lib.b9_enable_timing.argtypes = [vp, C.c_int]
     lib.b9_kernel_time_ms.argtypes = [vp, C.c_int, _dp, _ip]
     lib.b9_calibrate_timing.argtypes = [vp, _dp]

@@ -92,6 +92,13 @@ struct b9_ctx {
     bool plan_debug = false;         // b9_tuning.plan_debug: print the fused step's launch plan to stderr when it changes
     bool chunk_bounds = true;        // marginalised kernel: chunk-level pruning table (b9_tuning.no_chunk_bounds turns it off)
     int heavy_parts_fixed = 0;       // b9_tuning.heavy_parts: 0 = sized from the catalogue (check_ready)
+    int tree_depth = 0;              // b9_tuning.tree_depth: 0 = automatic
+    int tree_blocks_per_cu = 0, tree_occ_key = -1;   // k_mcmc_tree workgroups per CU, and the key it was queried for
+    // candidate buffers of the tree-speculative step (grown on demand): [2 parities][W][outcomes][nodes]([pops])
+    IsoHdr *d_tree_hdr = nullptr;
+    double *d_tree_iso = nullptr, *d_tree_par = nullptr, *d_tree_partial = nullptr;
+    size_t tree_cand_cap = 0, tree_partial_cap = 0;
+    long long tree_iso_stride = 0;
 
     // timing of the dominant kernel
     int timing = 0;            // 0 off, n > 0: bracket every n-th launch of the dominant kernel with events
@@ -424,7 +431,8 @@ void apply_tuning(b9_ctx *ctx, const b9_tuning &t)
     ctx->chunk_bounds = t.no_chunk_bounds == 0;
     ctx->timing_group = t.timing_group > 0 ? t.timing_group : 8;
     ctx->plan_debug = t.plan_debug != 0;
-    ctx->step_occ_key = -1; ctx->plan_debug_key = -1;
+    ctx->tree_depth = std::max(0, std::min(B9_TREE_MAX_DEPTH, t.tree_depth));
+    ctx->step_occ_key = -1; ctx->plan_debug_key = -1; ctx->tree_occ_key = -1;
 }
 
 // The B9_* environment overrides of the same fields (true when any is set).  Parsed once per context, at creation.
@@ -448,7 +456,81 @@ bool tuning_from_env(b9_tuning *t)
     num("B9_NO_CHUNK_BOUNDS", &t->no_chunk_bounds);
     num("B9_TIMING_GROUP", &t->timing_group);
     num("B9_PLAN_DEBUG", &t->plan_debug);
+    num("B9_TREE_DEPTH", &t->tree_depth);
     return any;
+}
+
+// Launch plan of the tree-speculative step: the deepest tree (b9_tuning.tree_depth caps or pins it) whose workgroups --
+// per walker one writer, 2^d (2^d - 1) candidate derivations in `parts` pieces, (2^d - 1) x heavy_parts heavy-star and
+// (2^d - 1) x n_groups hot workgroups -- are ALL resident in one occupancy round, with at most B9_TREE_MAX_GROUPS tile
+// groups per node (what one round trip of the walk reads).  depth 1 = none fits: the one-step fused launch runs instead.
+struct TreePlan { int depth, tiles_per_block, n_groups, derive_parts; bool strided; };
+
+TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
+{
+    TreePlan tp{1, 1, 1, 1, true};
+    if (ctx->tree_depth == 1) return tp;
+    const int key = (ctx->pk.nfp * 4 + n_pops) * 65536 + ctx->mass_cap;
+    if (ctx->tree_occ_key != key) {
+        int per_cu = 0;
+        if (b9k_mcmc_tree_occupancy(ctx->pk, n_pops, ctx->mass_cap, &per_cu) != hipSuccess || per_cu < 1) per_cu = 1;
+        ctx->tree_blocks_per_cu = per_cu;
+        ctx->tree_occ_key = key;
+    }
+    const long long slots = (long long)ctx->n_cu * ctx->tree_blocks_per_cu;
+    const int n_tiles = ctx->st.n_pad / 256;
+    const int full_parts = (ctx->mass_cap * (ctx->pk.nfp + 1) + 255) / 256;
+    for (int d = B9_TREE_MAX_DEPTH; d >= 2; --d) {
+        if (ctx->tree_depth >= 2 && d != ctx->tree_depth) continue;          // pinned
+        const long long NN = (1 << d) - 1, NO = 1 << d;
+        int tpb = ctx->tiles_per_block > 0 ? ctx->tiles_per_block : 1;
+        if (ctx->tiles_per_block <= 0) while ((n_tiles + tpb - 1) / tpb > B9_TREE_MAX_GROUPS) ++tpb;
+        const int n_groups = (n_tiles + tpb - 1) / tpb;
+        if (n_groups > B9_TREE_MAX_GROUPS) continue;         // (a PINNED grouping -- it fixes the summation order -- is never overridden: no tree then)
+        const long long fixed = n_walkers * (1 + NN * ctx->heavy_parts + NN * 8 * ((n_groups + 7) / 8));
+        const long long per_part = (long long)n_walkers * NO * NN * n_pops;
+        const long long room = (long long)(0.95 * slots) - fixed;
+        // (the derivation is the launch's longest chain -- decision, parameters, three dependent table round trips -- and more
+        //  workgroups per isochrone shorten its last leg: C1 at depth 3, us per chain step: 1 part 7.1, 2: 5.3, 4: 4.7, 6: 4.6)
+        int parts = (int)std::min<long long>(std::min(12, full_parts), room / per_part);
+        if (ctx->derive_parts > 0) parts = std::min(ctx->derive_parts, full_parts);
+        const bool fits = parts >= (d == 2 ? 2 : 1) && fixed + per_part * parts <= slots;
+        if (!fits && ctx->tree_depth < 2) continue;          // (a pinned depth runs even when it takes several rounds)
+        tp.depth = d; tp.tiles_per_block = tpb; tp.n_groups = n_groups; tp.derive_parts = std::max(1, parts);
+        tp.strided = !ctx->contiguous_tiles;
+        break;
+    }
+    if (ctx->plan_debug && ctx->plan_debug_key != key * 64 + n_walkers + 1000000 * tp.depth) {
+        ctx->plan_debug_key = key * 64 + n_walkers + 1000000 * tp.depth;
+        std::fprintf(stderr, "b9 tree plan: %lld slots; depth %d: %d walkers x %d nodes x %d tile groups (%d tiles each), %d derivation parts, %d heavy parts\n",
+                     slots, tp.depth, n_walkers, (1 << tp.depth) - 1, tp.n_groups, tp.tiles_per_block, tp.derive_parts, ctx->heavy_parts);
+    }
+    return tp;
+}
+
+int ensure_tree_buffers(b9_ctx *ctx, int n_walkers, int n_pops, const TreePlan &tp)
+{
+    const size_t NN = (1u << tp.depth) - 1, NO = 1u << tp.depth;
+    const size_t n_cand = (size_t)2 * n_walkers * NO * NN;
+    if (n_cand * n_pops > ctx->tree_cand_cap || ctx->tree_iso_stride != ctx->iso_stride) {
+        for (void *p : {(void *)ctx->d_tree_hdr, (void *)ctx->d_tree_iso, (void *)ctx->d_tree_par}) if (p) (void)hipFree(p);
+        ctx->d_tree_hdr = nullptr; ctx->d_tree_iso = nullptr; ctx->d_tree_par = nullptr; ctx->tree_cand_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tree_hdr, sizeof(IsoHdr) * n_cand * n_pops));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tree_iso, sizeof(double) * (size_t)ctx->iso_stride * n_cand * n_pops));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tree_par, sizeof(double) * B9_NPARAM * n_cand));
+        HIPCHK(ctx, hipMemset(ctx->d_tree_hdr, 0, sizeof(IsoHdr) * n_cand * n_pops));
+        ctx->tree_cand_cap = n_cand * n_pops; ctx->tree_iso_stride = ctx->iso_stride;
+    }
+    const size_t part_stride = ((size_t)tp.n_groups * 4 + ctx->heavy_parts + 1) & ~(size_t)1;
+    const size_t n_part = (size_t)2 * n_walkers * NN * part_stride;
+    if (n_part > ctx->tree_partial_cap) {
+        if (ctx->d_tree_partial) (void)hipFree(ctx->d_tree_partial);
+        ctx->d_tree_partial = nullptr; ctx->tree_partial_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tree_partial, sizeof(double) * n_part));
+        HIPCHK(ctx, hipMemset(ctx->d_tree_partial, 0, sizeof(double) * n_part));
+        ctx->tree_partial_cap = n_part;
+    }
+    return B9_OK;
 }
 
 }  // namespace
@@ -505,7 +587,8 @@ void b9_ctx_destroy(b9_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx->pack_allocs);
     free_all(ctx->star_allocs);
-    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_marg_tab};
+    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_marg_tab,
+                    ctx->d_tree_hdr, ctx->d_tree_iso, ctx->d_tree_par, ctx->d_tree_partial};
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (auto &sl : ctx->slot) {
         if (sl.d) (void)hipFree(sl.d);
@@ -874,6 +957,20 @@ static int collect_block(b9_ctx *ctx, b9_ctx::McmcSlot &sl, b9_mcmc_block *blk)
         return B9_OK;
     }
     const double *fin = stage + (sl.final_parity ? sl.o_st1 : sl.o_st0);
+    if (sl.kind == 2) {             // tree-speculative block: tree state rows
+        double n_acc = 0.0;
+        for (int w = 0; w < sl.W; ++w) {
+            const double *row = fin + (size_t)w * B9_TREE_STATE_STRIDE;
+            std::memcpy(blk->params + (size_t)w * B9_NPARAM, row + B9_TS_CUR, sizeof(double) * B9_NPARAM);
+            blk->logpost[w] = row[B9_TS_LP];
+            n_acc += row[B9_TS_NACC];
+        }
+        if (sl.n_samp && sl.host_samples && blk->samples) std::memcpy(blk->samples, stage + sl.o_samp, sl.n_samp * 8);
+        if (sl.n_rows && blk->rows) std::memcpy(blk->rows, stage + sl.o_rows, sl.n_rows * 8);
+        if (sl.n_lps && blk->lps) std::memcpy(blk->lps, stage + sl.o_lps, sl.n_lps * 8);
+        blk->n_accept = (int64_t)n_acc;
+        return B9_OK;
+    }
     for (int w = 0; w < sl.W; ++w) {
         std::memcpy(blk->params + (size_t)w * B9_NPARAM, fin + (size_t)w * B9_STATE_STRIDE + B9_ST_CUR, sizeof(double) * B9_NPARAM);
         blk->logpost[w] = fin[(size_t)w * B9_STATE_STRIDE + B9_ST_LP];
@@ -1038,6 +1135,140 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     return async ? B9_OK : collect_block(ctx, sl, blk);
 }
 
+/* Device-resident Metropolis block, given-mass mode, tree-speculative launches (TreeDev in b9_device.h): `depth` steps per launch.
+ * Launch sequence for S steps, M = ceil(S / depth):   B  P  K(0) K(1) ... K(M-1)  F
+ *   B    = k_tree_begin: the upload from the mapped mirror; the starting state into both parities' state rows
+ *   P    = k_mcmc_tree, prologue: derives the first tree (2^depth - 1 candidates) from the starting state
+ *   K(m) = k_mcmc_tree: walks the tree K(m-1) evaluated (the sequential accept tests of its `depth` steps), evaluates the tree
+ *          rooted at the resulting state, derives K(m+1)'s tree for every possible outcome of its own
+ *   F    = k_tree_finish: the last walk, final state, summary rows.
+ * Same block contract as run_block_fused (slots, mapped mirror, B9_BLOCK_ASYNC / CONTINUE, rows in HBM behind rows_ready). */
+static int run_block_tree(b9_ctx *ctx, b9_mcmc_block *blk, const TreePlan &tp)
+{
+    const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps, n_pops = ctx->opt.n_pops, depth = tp.depth;
+    const bool cont = (blk->flags & B9_BLOCK_CONTINUE) != 0, async = (blk->flags & B9_BLOCK_ASYNC) != 0;
+    int rc = ensure_tree_buffers(ctx, W, n_pops, tp);
+    if (rc) return rc;
+    b9_ctx::McmcSlot &sl = ctx->slot[ctx->next_slot];
+    if (sl.in_flight) return fail(ctx, B9_ERR_STATE, "two blocks are already outstanding: collect one with b9_mcmc_wait first");
+    if (cont && (ctx->last_slot < 0 || ctx->slot[ctx->last_slot].W != W || ctx->slot[ctx->last_slot].kind != 2))
+        return fail(ctx, B9_ERR_STATE, "B9_BLOCK_CONTINUE needs a previous block of this context with the same n_walkers and mode");
+    const bool want_rows = blk->row_origin != nullptr;
+    const size_t n_state = (size_t)W * B9_TREE_STATE_STRIDE,
+                 n_samp = (blk->samples || want_rows) ? (size_t)S * W * d : 0, n_lps = blk->lps ? (size_t)S * W : 0,
+                 n_rows = want_rows ? (size_t)W * B9_ROW_LEN(d) : 0;
+    //   [chol][origin][free, ids][state 0][state 1] | [rows][lps][samples]        upload = chol .. state 1
+    const size_t n_int = ((size_t)(d + W) + 1) / 2;
+    const size_t o_chol = 0, o_org = o_chol + (size_t)d * d, o_int = o_org + d, o_st0 = o_int + n_int, o_st1 = o_st0 + n_state,
+                 o_rows = o_st1 + n_state, o_lps = o_rows + n_rows, o_samp = o_lps + n_lps, n_total = o_samp + n_samp;
+    const size_t up_words = o_rows;
+    if (n_total * 8 > sl.cap) {
+        if (sl.d) (void)hipFree(sl.d);
+        sl.d = nullptr; sl.cap = 0;
+        HIPCHK(ctx, hipMalloc(&sl.d, n_total * 8));
+        sl.cap = n_total * 8;
+    }
+    if (n_total * 8 > sl.hcap) {
+        if (sl.h) (void)hipHostFree(sl.h);
+        sl.h = nullptr; sl.hcap = 0;
+        HIPCHK(ctx, hipHostMalloc(&sl.h, n_total * 8, hipHostMallocMapped));
+        HIPCHK(ctx, hipHostGetDevicePointer(&sl.h_dev, sl.h, 0));
+        sl.hcap = n_total * 8;
+    }
+    if (!sl.done) HIPCHK(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.rows_ready) HIPCHK(ctx, hipEventCreateWithFlags(&sl.rows_ready, hipEventDisableTiming));
+    double *const dev = static_cast<double *>(sl.d), *const stage = static_cast<double *>(sl.h);
+    hipStream_t s = ctx->stream;
+    {
+        std::memcpy(stage + o_chol, blk->chol, (size_t)d * d * 8);
+        if (want_rows) std::memcpy(stage + o_org, blk->row_origin, (size_t)d * 8); else std::memset(stage + o_org, 0, (size_t)d * 8);
+        int *hi = reinterpret_cast<int *>(stage + o_int);
+        std::memcpy(hi, blk->free_idx, d * sizeof(int));
+        std::memcpy(hi + d, blk->walker_ids, W * sizeof(int));
+        std::memset(stage + o_st0, 0, 2 * n_state * 8);
+        if (!cont)
+            for (int p = 0; p < 2; ++p)
+                for (int w = 0; w < W; ++w) {
+                    double *row = stage + (p ? o_st1 : o_st0) + (size_t)w * B9_TREE_STATE_STRIDE;
+                    std::memcpy(row + B9_TS_CUR, blk->params + (size_t)w * B9_NPARAM, sizeof(double) * B9_NPARAM);
+                    row[B9_TS_LP] = blk->logpost[w];
+                }
+        const double *prev_final = nullptr;
+        if (cont) {
+            const b9_ctx::McmcSlot &pv = ctx->slot[ctx->last_slot];
+            prev_final = static_cast<const double *>(pv.d) + (pv.final_parity ? pv.o_st1 : pv.o_st0);
+        }
+        HIPCHK(ctx, b9k_tree_begin(static_cast<const double *>(sl.h_dev), dev, (int)up_words, prev_final, dev + o_st0, W, s));
+    }
+    TreeDev td{};
+    td.d = d; td.n_walkers = W; td.n_pops = n_pops; td.depth = depth;
+    td.n_groups = tp.n_groups; td.heavy_parts = ctx->heavy_parts; td.mass_cap = ctx->mass_cap;
+    td.part_stride = (int)(((size_t)tp.n_groups * 4 + ctx->heavy_parts + 1) & ~(size_t)1);
+    td.k0 = (unsigned)(blk->seed & 0xFFFFFFFFull); td.k1 = (unsigned)(blk->seed >> 32);
+    td.iso_stride = ctx->iso_stride;
+    td.state = dev + o_st0; td.partial = ctx->d_tree_partial;
+    td.cand_par = ctx->d_tree_par; td.cand_hdr = ctx->d_tree_hdr; td.cand_iso = ctx->d_tree_iso;
+    td.chol = dev + o_chol; td.free_idx = reinterpret_cast<int *>(dev + o_int); td.walker_ids = td.free_idx + d;
+    td.samples = n_samp ? dev + o_samp : nullptr; td.lps = n_lps ? dev + o_lps : nullptr;
+    td.row_origin = dev + o_org; td.n_steps = S;
+    const int tiles_arg = tp.strided ? -tp.tiles_per_block : tp.tiles_per_block;
+    const int M = (S + depth - 1) / depth;
+    {   // P: the block's first tree from the starting state -> candidates of parity 0, outcome slot 0
+        td.set = 1; td.levels_prev = 0; td.levels = 0; td.derive_mode = 2; td.row = 0;
+        td.step = (unsigned long long)blk->step0; td.next_step = (unsigned long long)blk->step0;
+        HIPCHK(ctx, b9k_mcmc_tree(ctx->pk, ctx->st, td, ctx->pr, tiles_arg, tp.derive_parts, s));
+    }
+    long t_slot = -1;
+    int t_covered = 0;
+    for (int m = 0; m < M; ++m) {
+        td.set = m & 1;
+        td.levels_prev = m > 0 ? depth : 0;
+        td.levels = std::min(depth, S - m * depth);
+        td.derive_mode = (m + 1 < M) ? 1 : 0;
+        td.row = (m - 1) * depth;
+        td.step = (unsigned long long)(blk->step0 + (long long)m * depth);
+        td.next_step = td.step + (unsigned)depth;
+        if (t_slot < 0) {
+            rc = timing_begin(ctx, s, &t_slot);
+            if (rc) return rc;
+            t_covered = 0;
+        } else if (ctx->timing > 0) ctx->launch_no++;
+        HIPCHK(ctx, b9k_mcmc_tree(ctx->pk, ctx->st, td, ctx->pr, tiles_arg, tp.derive_parts, s));
+        if (t_slot >= 0 && (++t_covered >= ctx->timing_group || m == M - 1)) {
+            ctx->ev_count[t_slot] = t_covered;
+            rc = timing_end(ctx, s, t_slot);
+            if (rc) return rc;
+            t_slot = -1;
+        }
+    }
+    {   // F
+        td.set = M & 1;
+        td.levels_prev = std::min(depth, S - (M - 1) * depth);
+        td.levels = 0; td.derive_mode = 0;
+        td.row = (M - 1) * depth;
+        td.step = (unsigned long long)(blk->step0 + S); td.next_step = td.step;
+        td.rows = want_rows ? dev + o_rows : nullptr;
+        const bool zero_copy = !blk->samples && !blk->lps;
+        double *const mirror = static_cast<double *>(sl.h_dev);
+        td.host_state = zero_copy ? mirror + ((M & 1) ? o_st1 : o_st0) : nullptr;
+        td.host_rows = (zero_copy && want_rows) ? mirror + o_rows : nullptr;
+        HIPCHK(ctx, b9k_tree_finish(ctx->pk, td, ctx->pr, s));
+        const bool rows_event = want_rows && (blk->flags & B9_BLOCK_ROWS_EVENT) != 0;
+        if (rows_event) HIPCHK(ctx, hipEventRecord(sl.rows_ready, s));
+        blk->d_rows = want_rows ? (void *)(dev + o_rows) : nullptr;
+        blk->rows_ready = rows_event ? (void *)sl.rows_ready : nullptr;
+        if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(stage + o_st0, dev + o_st0, ((blk->samples ? n_total : o_samp) - o_st0) * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(ctx, hipEventRecord(sl.done, s));
+    sl.kind = 2; sl.W = W; sl.final_parity = M & 1;
+    sl.o_st0 = o_st0; sl.o_st1 = o_st1; sl.o_samp = o_samp; sl.o_lps = o_lps; sl.n_samp = n_samp; sl.n_lps = n_lps;
+    sl.o_rows = o_rows; sl.n_rows = n_rows; sl.host_samples = blk->samples != nullptr;
+    sl.in_flight = true; sl.owner = blk;
+    ctx->last_slot = ctx->next_slot;
+    ctx->next_slot ^= 1;
+    return async ? B9_OK : collect_block(ctx, sl, blk);
+}
+
 /* Device-resident Metropolis block with TWO launches per step (marginalised mode; b9_tuning.two_launch_steps):
  *   D(0) L(0)  D(1) L(1)  ...  D(S-1) L(S-1)  F  [R]
  *   D(t) = k_derive_iso: finishes step t-1 (sum + prior + accept; t > 0), proposes step t, derives its isochrones
@@ -1175,7 +1406,10 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     const Plan plan = make_plan(ctx, W, n_pops);
     rc = ensure_capacity(ctx, W, n_pops, (size_t)ctx->st.n_pad * W, false);
     if (rc) return rc;
-    if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) return run_block_fused(ctx, blk);
+    if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) {
+        const TreePlan tp = make_tree_plan(ctx, W, n_pops);
+        return tp.depth >= 2 ? run_block_tree(ctx, blk, tp) : run_block_fused(ctx, blk);
+    }
     return run_block_two_launch(ctx, blk, plan);
 }
 
@@ -1321,7 +1555,22 @@ int b9_step_tiles_per_block(b9_ctx *ctx, int32_t n_walkers)
     if (rc) return rc;
     rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)ctx->st.n_pad * n_walkers, false);   // (the plan keys on mass_cap)
     if (rc) return rc;
+    if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) {
+        const TreePlan tp = make_tree_plan(ctx, n_walkers, ctx->opt.n_pops);
+        if (tp.depth >= 2) return tp.tiles_per_block;
+    }
     return make_step_plan(ctx, n_walkers, ctx->opt.n_pops).plan.tiles_per_block;
+}
+
+int b9_step_depth(b9_ctx *ctx, int32_t n_walkers)
+{
+    if (!ctx || n_walkers < 1) return B9_ERR_INVALID;
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)ctx->st.n_pad * n_walkers, false);
+    if (rc) return rc;
+    if (ctx->opt.mode != B9_MODE_GIVEN_MASS || ctx->two_launch_steps) return 1;
+    return make_tree_plan(ctx, n_walkers, ctx->opt.n_pops).depth;
 }
 
 int b9_enable_timing(b9_ctx *ctx, int on)

@@ -178,3 +178,69 @@ struct StepDev {
 #define B9_ROW_N 14                  // steps of the block
 #define B9_ROW_SUM 15                // [15 .. 15+d) sum of x,  then [15+d .. 15+d+d*d) sum of x x^T;  x = sample - origin
 #define B9_ROW_LEN(d) (15 + (d) + (d) * (d))
+
+// ------------------------------------------------------------------------------------------
+// Tree-speculative sampler step (given-mass mode, few walkers per GPU): ONE launch advances every chain by `depth` steps.
+//
+// A chain's next `depth` steps form a binary tree of proposals: the proposal of step T+j depends only on which of the
+// steps T+1 .. T+j-1 were accepted (its base is the latest accepted proposal, or the state x after step T) and on the
+// step's own normals, which are counter-based -- so all 2^depth - 1 proposals of the tree are known before any of them
+// is evaluated.  Launch K(m) evaluates the WHOLE tree rooted at the chain's state (one set of star workgroups per node,
+// on the workgroup slots a one-walker launch leaves idle); the next launch walks it -- level 1's accept test, then the
+// level-2 node that outcome selects, ... -- which is exactly the sequential algorithm's sequence of tests on exactly its
+// proposals: same draws, same sums, same comparisons, same chain.  As in the one-step fused launch, K(m) also derives the
+// candidate isochrones of K(m+1) speculatively: one tree per possible outcome of its own tree (2^depth outcomes x
+// 2^depth - 1 nodes; depth 1 is the one-step scheme's two candidates).
+//
+// Node n of a tree: level j = floor(log2(n + 1)) + 1, prefix p = n + 1 - 2^(j-1) = the accept bits of levels 1 .. j-1
+// (level 1 most significant).  Outcome o of a launch = the accept bits of its levels (level 1 most significant).
+// Everything ping-pongs on the launch's parity `set`:
+//   state[set]   written by K(m): x (state after the decision K(m) took), its log-posterior, and -- for the tree K(m)
+//                evaluates -- every node's proposal, its log-prior, every level's log u
+//   partial[set] written by K(m): per node, the per-wave partial sums of its star likelihoods
+//   cand[set]    read by K(m): per outcome of K(m-1), the tree's (params, headers, isochrones); K(m) writes cand[set ^ 1]
+// ------------------------------------------------------------------------------------------
+#define B9_TREE_MAX_DEPTH 3
+#define B9_TREE_MAX_NODES 7
+#define B9_TREE_KD 3                 // partials per lane and node the walk reads in its one round trip: a node has at most 64 KD hot
+#define B9_TREE_MAX_GROUPS (16 * B9_TREE_KD)      // partials = this many tile groups (the launch plan raises the tiles per workgroup to stay under it)
+#define B9_TS_CUR 0              // [0..11]  state after the decision this launch took
+#define B9_TS_LP 12              // its log-posterior
+#define B9_TS_NACC 13            // proposals accepted so far in the block
+#define B9_TS_LOGU 14            // [14..16] log u of levels 1..3 of the tree this launch evaluates
+#define B9_TS_LPRIOR 17          // [17..23] log-prior of node n's proposal (-inf: outside the grid or the prior's support)
+#define B9_TS_PROP 24            // [24 + 12 n ..] node n's proposal
+#define B9_TREE_STATE_STRIDE (24 + 12 * B9_TREE_MAX_NODES + 4)      // 112 doubles
+
+struct TreeDev {
+    int d, n_walkers, n_pops;
+    int depth;                       // levels of a full tree (1..3)
+    int levels_prev;                 // levels of the tree the PREVIOUS launch evaluated (0: none -- first launch of a block, prologue)
+    int levels;                      // levels this launch evaluates (< depth only for a block's last launch)
+    int derive_mode;                 // 0: derive nothing (finish), 1: next trees for every outcome of this launch's tree,
+                                     // 2: prologue -- the block's first tree from the starting state (outcome slot 0 only)
+    int set;                         // parity of this launch
+    int row;                         // chain row of the first step the decision of this launch appends
+    int n_groups, part_stride;       // tile groups per node; doubles per (walker, node) partial row = 4 n_groups + heavy_parts (padded)
+    int mass_cap, heavy_parts;
+    unsigned k0, k1;                 // Philox key
+    unsigned long long step;         // global index of the step at level 1 of the tree this launch evaluates
+    unsigned long long next_step;    // ... of the tree(s) this launch derives
+    long long iso_stride;
+    double *state;                   // [2][W][B9_TREE_STATE_STRIDE]
+    double *partial;                 // [2][W][nodes][part_stride]
+    double *cand_par;                // [2][W][outcomes][nodes][12]
+    IsoHdr *cand_hdr;                // [2][W][outcomes][nodes][pops]
+    double *cand_iso;                // [2][W][outcomes][nodes][pops][iso_stride]
+    const double *chol;              // [d][d]
+    const int *free_idx;             // [d]
+    const int *walker_ids;           // [W]
+    double *samples;                 // [n_steps][W][d] or null
+    double *lps;                     // [n_steps][W] or null
+    // the finish launch only (as StepDev's)
+    double *rows;
+    const double *row_origin;
+    int n_steps;
+    double *host_state;              // [W][B9_TREE_STATE_STRIDE]
+    double *host_rows;
+};

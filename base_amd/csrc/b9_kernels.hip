@@ -47,6 +47,7 @@
 #include "b9_star.hip.h"
 #include "b9_star_like.hip.h"
 #include "b9_mcmc_step.hip.h"
+#include "b9_mcmc_tree.hip.h"
 #include "b9_star_marg.hip.h"
 
 // ------------------------------------------------------------------------------------------
@@ -302,6 +303,79 @@ hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &s
 #undef MS1
 #undef MS2
 #undef MS_ARGS
+}
+
+// ---- tree-speculative step (k_mcmc_tree) -------------------------------------------------------------------------
+template <int NFP, int NPOPS>
+static size_t mcmc_tree_lds(const DevPack &pk, int mass_cap)
+{
+    return sizeof(double) * std::max((size_t)NPOPS * mass_cap + 8, heavy_lds_doubles(pk, NPOPS, 1, mass_cap));
+}
+
+template <int NFP, int NPOPS>
+static hipError_t mcmc_tree_occupancy(const DevPack &pk, int mass_cap, int *blocks_per_cu)
+{
+    const size_t lds = mcmc_tree_lds<NFP, NPOPS>(pk, mass_cap);
+    auto kern = k_mcmc_tree<NFP, NPOPS>;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(kern), 256, lds);
+}
+
+hipError_t b9k_mcmc_tree_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu)
+{
+#define OC2(NFP) mcmc_tree_occupancy<NFP, 2>(pk, mass_cap, blocks_per_cu)
+#define OC1(NFP) mcmc_tree_occupancy<NFP, 1>(pk, mass_cap, blocks_per_cu)
+    B9_SWITCH_NFP(OC2, OC1)
+#undef OC1
+#undef OC2
+}
+
+template <int NFP, int NPOPS>
+static hipError_t launch_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int tiles_per_block,
+                                   int derive_parts, hipStream_t stream)
+{
+    const size_t lds = mcmc_tree_lds<NFP, NPOPS>(pk, td.mass_cap);
+    auto kern = k_mcmc_tree<NFP, NPOPS>;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int W = td.n_walkers, NN = (1 << td.depth) - 1, NO = td.derive_mode == 2 ? 1 : (1 << td.depth);
+    const int writers = td.derive_mode == 2 ? 0 : W;
+    const int n_derive = td.derive_mode == 0 ? 0 : W * NO * NN * NPOPS * derive_parts;
+    const int heavy = td.levels > 0 ? W * NN * td.heavy_parts : 0;
+    const int front = (writers + n_derive + heavy + 7) / 8 * 8;
+    const int hot = td.levels > 0 ? 8 * ((td.n_groups + 7) / 8) * W * NN : 0;
+    hipLaunchKernelGGL(kern, dim3(front + hot), dim3(256), lds, stream, pk, st, td, pr, tiles_per_block, front, derive_parts);
+    return hipGetLastError();
+}
+
+hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int tiles_per_block,
+                         int derive_parts, hipStream_t stream)
+{
+    const int n_pops = td.n_pops;
+#define MT2(NFP) launch_mcmc_tree<NFP, 2>(pk, st, td, pr, tiles_per_block, derive_parts, stream)
+#define MT1(NFP) launch_mcmc_tree<NFP, 1>(pk, st, td, pr, tiles_per_block, derive_parts, stream)
+    B9_SWITCH_NFP(MT2, MT1)
+#undef MT1
+#undef MT2
+}
+
+hipError_t b9k_tree_finish(const DevPack &pk, const TreeDev &td, const DevPriors &pr, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_tree_finish, dim3(td.n_walkers), dim3(256), 0, stream, pk, td, pr);
+    return hipGetLastError();
+}
+
+hipError_t b9k_tree_begin(const double *host_up, double *dev, int up_words, const double *prev_final, double *state, int n_walkers, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_tree_begin, dim3(1), dim3(256), 0, stream, host_up, dev, up_words, prev_final, state, n_walkers);
+    return hipGetLastError();
 }
 
 hipError_t b9k_mcmc_begin(const double *host_up, double *dev, int up_words, const double *prev_final, double *cur0, double *lp0,

@@ -1,0 +1,445 @@
+// b9_mcmc_tree.hip.h -- k_mcmc_tree: the tree-speculative sampler step (TreeDev in b9_device.h): one launch advances
+// every chain by `depth` Metropolis steps.  For launches with few walkers, where the one-step fused launch
+// (k_mcmc_step) leaves most of the GPU idle and a chain's rate is set by the launch's latency chain, not by its work.
+// Part of the single translation unit b9_kernels.hip (included there, in this order); gfx950 only.
+#pragma once
+
+
+__device__ __forceinline__ int tree_level(int n) { return 32 - __clz(n + 1); }          // floor(log2(n + 1)) + 1
+
+// Everything a wave's walk of the previous launch's tree reads, requested before any of it is looked at (clamped
+// indices instead of branches: one memory round trip).
+struct TreeLoads {
+    double lp, logu[B9_TREE_MAX_DEPTH], lpr[B9_TREE_MAX_NODES], hv[B9_TREE_MAX_NODES], v[B9_TREE_MAX_NODES][B9_TREE_KD];
+};
+
+struct TreeWalk {
+    int outcome;                     // accept bits of the levels walked (level 1 most significant)
+    int last;                        // the last accepted node, -1 if none: the state after the walk is its proposal (or the old state)
+    int n_acc;
+    double lp;                       // log-posterior of the state after the walk
+    int node[B9_TREE_MAX_DEPTH];     // per level: the node tested ...
+    int last_at[B9_TREE_MAX_DEPTH];  // ... and the last accepted node after that level's test (-1: none yet)
+    double lp_at[B9_TREE_MAX_DEPTH]; // ... and the log-posterior of the state after it
+};
+
+__device__ __forceinline__ const double *tree_state_in(const TreeDev &td, int w)
+{
+    return td.state + ((size_t)(td.set ^ 1) * td.n_walkers + w) * B9_TREE_STATE_STRIDE;
+}
+__device__ __forceinline__ const double *tree_partial_in(const TreeDev &td, int w)
+{
+    const int NN = (1 << td.depth) - 1;
+    return td.partial + ((size_t)(td.set ^ 1) * td.n_walkers + w) * NN * td.part_stride;
+}
+
+__device__ __forceinline__ void tree_issue(const TreeDev &td, int w, TreeLoads &tl)
+{
+    const int lane = threadIdx.x & 63, NN = (1 << td.depth) - 1, n_hot = 4 * td.n_groups;
+    const double *in = tree_state_in(td, w), *part = tree_partial_in(td, w);
+    tl.lp = in[B9_TS_LP];
+#pragma unroll
+    for (int j = 0; j < B9_TREE_MAX_DEPTH; ++j) tl.logu[j] = in[B9_TS_LOGU + j];
+    const int hl = lane < td.heavy_parts ? lane : td.heavy_parts - 1;
+#pragma unroll
+    for (int n = 0; n < B9_TREE_MAX_NODES; ++n) {
+        tl.lpr[n] = in[B9_TS_LPRIOR + n];
+        const double *row = part + (size_t)(n < NN ? n : 0) * td.part_stride;
+#pragma unroll
+        for (int k = 0; k < B9_TREE_KD; ++k) { const int j = lane + 64 * k; tl.v[n][k] = row[j < n_hot ? j : n_hot - 1]; }
+        tl.hv[n] = row[n_hot + hl];
+    }
+}
+
+// one accept test: prior + sum, as k_finalize forms it
+__device__ __forceinline__ bool tree_test(double lpr, double t, double logu, double lp_base, double &lp_prop)
+{
+    lp_prop = (lpr != NEG_INF) ? lpr + t : NEG_INF;
+    return isfinite(lp_prop) && (logu < lp_prop - lp_base);
+}
+
+// The walk: per node, lane l adds the hot waves' partials l, l + 64, ... in order, then heavy-star partial l, then the
+// shuffle tree -- the same bits in every workgroup; then the sequential algorithm's tests, level by level.
+__device__ __forceinline__ TreeWalk tree_walk(const TreeDev &td, int w, const TreeLoads &tl)
+{
+    const int lane = threadIdx.x & 63, n_hot = 4 * td.n_groups;      // (the launch plan keeps n_hot <= 64 B9_TREE_KD)
+    double T[B9_TREE_MAX_NODES];
+#pragma unroll
+    for (int n = 0; n < B9_TREE_MAX_NODES; ++n) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < B9_TREE_KD; ++k) acc = (lane + 64 * k < n_hot) ? acc + tl.v[n][k] : acc;
+        acc = (lane < td.heavy_parts) ? acc + tl.hv[n] : acc;
+        T[n] = __shfl(wave_sum(acc), 0, 64);
+    }
+    TreeWalk tw;
+    tw.outcome = 0; tw.last = -1; tw.n_acc = 0; tw.lp = tl.lp;
+#pragma unroll
+    for (int j = 0; j < B9_TREE_MAX_DEPTH; ++j) { tw.node[j] = 0; tw.last_at[j] = -1; tw.lp_at[j] = tl.lp; }
+    // level 1: node 0
+    if (td.levels_prev >= 1) {
+        double lpp;
+        const bool ok = tree_test(tl.lpr[0], T[0], tl.logu[0], tw.lp, lpp);
+        tw.node[0] = 0;
+        if (ok) { tw.lp = lpp; tw.last = 0; ++tw.n_acc; }
+        tw.outcome = ok ? 1 : 0;
+        tw.last_at[0] = tw.last; tw.lp_at[0] = tw.lp;
+    }
+    // level 2: node 1 + b1
+    if (td.levels_prev >= 2) {
+        const int b1 = tw.outcome & 1, n = 1 + b1;
+        double lpp;
+        // (unary plus: a conditional on two array ELEMENTS is an lvalue -- a select of addresses, which keeps the whole
+        //  array out of registers; on two VALUES it is a register select)
+        double l1 = tl.lpr[1], l2 = tl.lpr[2];
+        asm volatile("" : "+v"(l1), "+v"(l2));
+        const bool ok = tree_test(b1 ? l2 : l1, b1 ? +T[2] : +T[1], tl.logu[1], tw.lp, lpp);
+        tw.node[1] = n;
+        if (ok) { tw.lp = lpp; tw.last = n; ++tw.n_acc; }
+        tw.outcome = tw.outcome * 2 + (ok ? 1 : 0);
+        tw.last_at[1] = tw.last; tw.lp_at[1] = tw.lp;
+    }
+    // level 3: node 3 + (b1 b2)
+    if (td.levels_prev >= 3) {
+        const int p = tw.outcome & 3, n = 3 + p;
+        // (the four candidates pass through an empty asm: left alone, the compiler turns the select chain over array elements
+        //  into ONE load at a selected offset -- which pins the whole array in scratch memory)
+        double l3 = tl.lpr[3], l4 = tl.lpr[4], l5 = tl.lpr[5], l6 = tl.lpr[6];
+        asm volatile("" : "+v"(l3), "+v"(l4), "+v"(l5), "+v"(l6));
+        const double lpr = p == 0 ? l3 : (p == 1 ? l4 : (p == 2 ? l5 : l6));
+        const double t = p == 0 ? +T[3] : (p == 1 ? +T[4] : (p == 2 ? +T[5] : +T[6]));
+        double lpp;
+        const bool ok = tree_test(lpr, t, tl.logu[2], tw.lp, lpp);
+        tw.node[2] = n;
+        if (ok) { tw.lp = lpp; tw.last = n; ++tw.n_acc; }
+        tw.outcome = tw.outcome * 2 + (ok ? 1 : 0);
+        tw.last_at[2] = tw.last; tw.lp_at[2] = tw.lp;
+    }
+    return tw;
+}
+
+// issue + walk by one wave (the loads of everything else the caller needs first should precede the call in program order)
+__device__ __forceinline__ TreeWalk tree_decide(const TreeDev &td, int w)
+{
+    TreeLoads tl;
+    tree_issue(td, w, tl);
+    return tree_walk(td, w, tl);
+}
+
+// index of candidate (walker w, outcome o of the previous launch, node n) in cand_par / cand_hdr / cand_iso of parity `set`
+__device__ __forceinline__ size_t tree_cand(const TreeDev &td, int set, int w, int o, int n)
+{
+    const int NN = (1 << td.depth) - 1, NO = 1 << td.depth;
+    return (((size_t)set * td.n_walkers + w) * NO + o) * NN + n;
+}
+
+// ---- hot role: one node's star likelihood (k_star_like's hot body on the candidate the walk selects) --------------------
+template <int NFP, int NPOPS>
+__device__ __forceinline__ void tree_hot(const DevPack &pk, const DevStars &st, const TreeDev &td, int L, int tiles_per_block, double *smem)
+{
+    const int tid = threadIdx.x, W = td.n_walkers, mass_cap = td.mass_cap, NN = (1 << td.depth) - 1, V = W * NN;
+    const int xcd = L & 7, s = L >> 3;
+    const int v = s % V, group = (s / V) * 8 + xcd;          // every node of every walker re-reads a star tile from one XCD's L2
+    if (group >= td.n_groups) return;
+    const int w = v / NN, n = v - w * NN;
+    if (tree_level(n) > td.levels) return;                   // (a block's last launch may evaluate fewer levels)
+    const bool strided = tiles_per_block < 0;
+    if (strided) tiles_per_block = -tiles_per_block;
+    const int tile0 = strided ? group : group * tiles_per_block, tile_step = strided ? td.n_groups : 1;
+    __shared__ int s_o;
+    const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    int i = tile0 * 256 + tid;
+    int il = i < st.n_pad ? i : st.n_pad - 1;
+    double m1 = st.mass1[il], q = st.q[il], ea = st.ea[il];
+    if (first_wave) {
+        const int o = tree_decide(td, w).outcome;
+        if (tid == 0) s_o = o;
+    }
+    __syncthreads();
+    const size_t cb = tree_cand(td, td.set, w, s_o, n);
+    double *const lds_mass = smem;
+    {
+        const int half = mass_cap / 2;
+        double2 *const lds2 = reinterpret_cast<double2 *>(lds_mass);
+        for (int f = tid; f < NPOPS * half; f += 256) {
+            const int c = f / half, j = f - c * half;
+            lds2[f] = reinterpret_cast<const double2 *>(td.cand_iso + (cb * NPOPS + c) * td.iso_stride)[j];
+        }
+    }
+    IsoView<NFP> iso[NPOPS];
+    bool valid = true;
+    double tip_min = __builtin_inf();
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        const IsoHdr hh = td.cand_hdr[cb * NPOPS + kp];
+        valid = valid && hh.valid;
+        iso[kp].n = hh.n; iso[kp].tip = hh.agb_tip;
+        iso[kp].i_feh = hh.i_feh; iso[kp].i_y = hh.i_y; iso[kp].t_feh = hh.t_feh; iso[kp].t_y = hh.t_y;
+        iso[kp].mass = lds_mass + (size_t)kp * mass_cap;
+        iso[kp].mags = td.cand_iso + (cb * NPOPS + kp) * td.iso_stride + mass_cap;
+        tip_min = hh.agb_tip < tip_min ? hh.agb_tip : tip_min;
+    }
+    const double *par = td.cand_par + cb * B9_NPARAM;
+    const double mod = par[B9_P_MOD], av = par[B9_P_ABS], lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+    __syncthreads();                                         // the LDS mass columns
+    MixAcc acc;
+    acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;             // = 1.0
+    for (int t = 0; t < tiles_per_block; ++t) {
+        if ((tile0 + t * tile_step) * 256 >= st.n_pad) break;
+        const int i_n = (tile0 + (t + 1) * tile_step) * 256 + tid;
+        const int il_n = i_n < st.n_pad ? i_n : st.n_pad - 1;
+        const double m1_n = st.mass1[il_n], q_n = st.q[il_n], ea_n = st.ea[il_n];     // the next tile's star scalars: one round trip less per tile
+        if (valid && i < st.n_pad && !(m1 > tip_min)) {      // empty slots hold m1 = +inf
+            const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, il, nullptr, log_lam, log_1ml);
+            mix_add(acc, ea, l);
+        }
+        i = i_n; il = il_n; m1 = m1_n; q = q_n; ea = ea_n;
+    }
+    const double tot = mix_wave_total(acc);
+    if ((tid & 63) == 0)
+        td.partial[(((size_t)td.set * W + w) * NN + n) * td.part_stride + group * 4 + (tid >> 6)] = valid ? tot : 0.0;
+}
+
+// ---- heavy role: the stars above a node's AGB tip (k_star_like's heavy role on the selected candidate) -----------------
+template <int NFP, int NPOPS>
+__device__ __forceinline__ void tree_heavy(const DevPack &pk, const DevStars &st, const TreeDev &td, int b, double *smem)
+{
+    const int W = td.n_walkers, NN = (1 << td.depth) - 1;
+    const int part = b % td.heavy_parts, v = b / td.heavy_parts, w = v / NN, n = v - w * NN;
+    if (tree_level(n) > td.levels) return;
+    __shared__ int s_ho;
+    const bool first_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+    if (first_wave) {
+        const int o = tree_decide(td, w).outcome;
+        if (threadIdx.x == 0) s_ho = o;
+    }
+    __syncthreads();
+    const size_t cb = tree_cand(td, td.set, w, s_ho, n);
+    const IsoHdr *const h1[1] = {td.cand_hdr + cb * NPOPS};
+    const double *const i1[1] = {td.cand_iso + cb * NPOPS * td.iso_stride}, *const p1[1] = {td.cand_par + cb * B9_NPARAM};
+    double *const o1[1] = {td.partial + (((size_t)td.set * W + w) * NN + n) * td.part_stride + (size_t)td.n_groups * 4 + part};
+    heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, td.iso_stride, td.mass_cap, p1, [] { return 0; }, false, 0, part, td.heavy_parts, o1, nullptr, smem);
+}
+
+// ---- proposal bookkeeping shared by the writer and the derivation role ---------------------------------------------------
+// Normals of `n_steps` consecutive steps starting at global step `step0` into s_z[step][12], by the lanes of wave 3
+// (Philox + Box-Muller: they depend on (seed, step, walker) only).
+__device__ __forceinline__ void tree_draw_z(const TreeDev &td, int w, unsigned long long step0, int n_steps, double (*s_z)[12])
+{
+    const int j = (int)threadIdx.x - 192, n_pairs = (td.d + 1) >> 1;
+    if (j >= 0 && j < n_steps * n_pairs) {
+        const int si = j / n_pairs, pj = j - si * n_pairs;
+        const unsigned long long sn = step0 + si;
+        unsigned r[4];
+        philox4x32((unsigned)sn, (unsigned)(sn >> 32), (unsigned)td.walker_ids[w], (unsigned)pj, td.k0, td.k1, r);
+        const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+        const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+        s_z[si][2 * pj] = rad * cos(ang);
+        s_z[si][2 * pj + 1] = rad * sin(ang);
+    }
+}
+
+// ---- derivation role: candidate (outcome o2 of THIS launch's tree, node n2 of the next tree) -------------------------------
+// The state x after the previous launch's walk; the end state of outcome o2 = x plus the steps of this launch's tree that
+// o2 accepts (each an `s_par[free[i]] += sum_j chol[i][j] z_j`, j ascending, plain multiply-add -- the sequential
+// algorithm's own update, so the same bits); node n2's proposal = that plus the next tree's accepted ancestors' steps and
+// its own.  Nothing here waits for memory after the first round trip until the isochrone tables.
+__device__ __forceinline__ void tree_derive(const DevPack &pk, const TreeDev &td, int w, int o2, int n2, int pop, int part, int parts)
+{
+    const int tid = threadIdx.x, d = td.d, W = td.n_walkers, n_pops = td.n_pops, depth = td.depth;
+    __shared__ double s_par[B9_NPARAM], s_z[2 * B9_TREE_MAX_DEPTH][12], s_delta[2 * B9_TREE_MAX_DEPTH][12];
+    __shared__ int s_last;
+    const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    const AxisRegs axr = preload_axis(pk);                 // first round trip, needs no parameter
+    const double *in = tree_state_in(td, w);
+    // the old state and every node's proposal of the previous launch's tree: which of them is x, the walk says
+    double cand_v[B9_TREE_MAX_NODES + 1];
+    {
+        const int NN = (1 << depth) - 1;
+        cand_v[0] = tid < B9_NPARAM ? in[B9_TS_CUR + tid] : 0.0;
+#pragma unroll
+        for (int n = 0; n < B9_TREE_MAX_NODES; ++n) cand_v[n + 1] = (tid < B9_NPARAM && n < NN) ? in[B9_TS_PROP + 12 * n + tid] : 0.0;
+    }
+    double crow[11];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) crow[j] = (tid < d && j < d) ? td.chol[tid * d + j] : 0.0;
+    const int fidx = tid < d ? td.free_idx[tid] : 0;
+    // wave 3: the normals of this launch's tree (steps td.step ..) and of the next (td.next_step ..)
+    const bool prologue = td.derive_mode == 2;
+    if (!prologue) tree_draw_z(td, w, td.step, depth, s_z);
+    tree_draw_z(td, w, td.next_step, depth, s_z + B9_TREE_MAX_DEPTH);
+    if (first_wave) {
+        const int last = tree_decide(td, w).last;
+        if (tid == 0) s_last = last;
+    }
+    __syncthreads();
+    {
+        const int last = s_last;
+        double x = cand_v[0];
+#pragma unroll
+        for (int n = 0; n < B9_TREE_MAX_NODES; ++n) x = (last == n) ? +cand_v[n + 1] : x;
+        if (tid < B9_NPARAM) s_par[tid] = x;
+    }
+    // delta of every step: sum_j chol[i][j] z_j
+#pragma unroll
+    for (int si = 0; si < 2 * B9_TREE_MAX_DEPTH; ++si) {
+        const bool have = (si < B9_TREE_MAX_DEPTH) ? (!prologue && si < depth) : (si - B9_TREE_MAX_DEPTH < depth);
+        double delta = 0.0;
+        if (have) {
+#pragma unroll
+            for (int j = 0; j < 11; ++j) if (j < d) delta = delta + crow[j] * s_z[si][j];
+        }
+        if (tid < d) s_delta[si][tid] = delta;
+    }
+    __syncthreads();
+    if (tid < d) {
+        double v = s_par[fidx];                              // (each thread owns one sampled parameter: sequential adds, no hazard)
+        if (!prologue)
+            for (int i = 1; i <= depth; ++i) if ((o2 >> (depth - i)) & 1) v += s_delta[i - 1][tid];
+        const int lv = tree_level(n2), p2 = n2 + 1 - (1 << (lv - 1));
+        for (int i = 1; i < lv; ++i) if ((p2 >> (lv - 1 - i)) & 1) v += s_delta[B9_TREE_MAX_DEPTH + i - 1][tid];
+        v += s_delta[B9_TREE_MAX_DEPTH + lv - 1][tid];
+        s_par[fidx] = v;
+    }
+    __syncthreads();
+    const size_t cb = tree_cand(td, td.set ^ 1, w, o2, n2);
+    if (pop == 0 && part == 0 && tid < B9_NPARAM) td.cand_par[cb * B9_NPARAM + tid] = s_par[tid];
+    derive_iso_block(pk, s_par, pop, (int)(cb * n_pops + pop), td.cand_hdr, td.cand_iso, td.iso_stride, td.mass_cap, part, parts, axr);
+}
+
+// ---- writer: the walk's result -- new state, chain rows of the previous launch's steps, and what the NEXT launch's walk
+// needs about the tree this launch evaluates (every node's proposal and log-prior, every level's log u) -----------------
+__device__ __forceinline__ void tree_writer(const DevPack &pk, const TreeDev &td, const DevPriors &pr, int w, double *s_state_out /* LDS [14] or null */)
+{
+    const int tid = threadIdx.x, d = td.d, W = td.n_walkers, n_pops = td.n_pops, depth = td.depth, NN = (1 << depth) - 1;
+    __shared__ double s_lvl[B9_TREE_MAX_DEPTH + 1][B9_NPARAM];       // state after level j (0: before the walk)
+    __shared__ double s_prop[B9_TREE_MAX_NODES][B9_NPARAM];
+    __shared__ TreeWalk s_tw;
+    const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    const double *in = tree_state_in(td, w);
+    double cand_v[B9_TREE_MAX_NODES + 1];
+    cand_v[0] = tid < B9_NPARAM ? in[B9_TS_CUR + tid] : 0.0;
+#pragma unroll
+    for (int n = 0; n < B9_TREE_MAX_NODES; ++n) cand_v[n + 1] = (tid < B9_NPARAM && n < NN) ? in[B9_TS_PROP + 12 * n + tid] : 0.0;
+    const double nacc_in = in[B9_TS_NACC];
+    const int fidx = tid < d ? td.free_idx[tid] : 0;
+    if (first_wave) {
+        const TreeWalk tw0 = tree_decide(td, w);
+        if (tid == 0) s_tw = tw0;
+    }
+    __syncthreads();
+    const int tw_outcome = s_tw.outcome, tw_n_acc = s_tw.n_acc;
+    const double tw_lp = s_tw.lp;
+    if (tid < B9_NPARAM) {
+        s_lvl[0][tid] = cand_v[0];
+#pragma unroll
+        for (int j = 0; j < B9_TREE_MAX_DEPTH; ++j) {
+            const int la = s_tw.last_at[j];
+            double x = cand_v[0];
+#pragma unroll
+            for (int n = 0; n < B9_TREE_MAX_NODES; ++n) x = (la == n) ? +cand_v[n + 1] : x;
+            s_lvl[j + 1][tid] = x;
+        }
+    }
+    // the tree this launch evaluates: candidate set of the walk's outcome (full-depth launches precede every launch but a
+    // block's first, whose set is outcome slot 0)
+    const int o = td.levels_prev > 0 ? tw_outcome : 0;
+    const size_t cb = tree_cand(td, td.set, w, o, 0);
+    if (td.derive_mode != 0 || td.levels > 0) {
+        for (int e = tid; e < NN * B9_NPARAM; e += 256) s_prop[e / B9_NPARAM][e % B9_NPARAM] = td.cand_par[cb * B9_NPARAM + e];
+    }
+    __syncthreads();
+    const int lv = td.levels_prev;
+    double *out = td.state + ((size_t)td.set * W + w) * B9_TREE_STATE_STRIDE;
+    if (tid < B9_NPARAM) out[B9_TS_CUR + tid] = s_lvl[lv][tid];
+    if (td.levels > 0)
+        for (int e = tid; e < NN * B9_NPARAM; e += 256) out[B9_TS_PROP + e] = s_prop[e / B9_NPARAM][e % B9_NPARAM];
+    if (tid == 0) { out[B9_TS_LP] = tw_lp; out[B9_TS_NACC] = nacc_in + (double)tw_n_acc; }
+    if (td.levels > 0) {
+        if (tid >= 64 && tid < 64 + NN) {                    // log-prior of every node's proposal
+            const int n = tid - 64;
+            bool pv = true;
+            for (int k = 0; k < n_pops; ++k) pv = pv && td.cand_hdr[(cb + n) * n_pops + k].valid;
+            out[B9_TS_LPRIOR + n] = pv ? log_prior_cluster(pr, s_prop[n], n_pops) : NEG_INF;
+        }
+        if (tid >= 128 && tid < 128 + depth) {               // log u of level j's accept test (draw index n_pairs of its step)
+            const unsigned long long sn = td.step + (unsigned)(tid - 128);
+            unsigned r[4];
+            philox4x32((unsigned)sn, (unsigned)(sn >> 32), (unsigned)td.walker_ids[w], (unsigned)((d + 1) >> 1), td.k0, td.k1, r);
+            out[B9_TS_LOGU + (tid - 128)] = log(u01(r[0], r[1]));
+        }
+    }
+    // chain rows of the previous launch's steps: the state after each of its levels
+    for (int j = 1; j <= lv; ++j) {
+        if (td.samples && tid < d) td.samples[((size_t)(td.row + j - 1) * W + w) * d + tid] = s_lvl[j][fidx];
+        if (td.lps && tid == 0) td.lps[(size_t)(td.row + j - 1) * W + w] = s_tw.lp_at[j - 1];
+    }
+    if (s_state_out) {
+        if (tid < B9_NPARAM) s_state_out[tid] = s_lvl[lv][tid];
+        if (tid == 0) { s_state_out[B9_NPARAM] = tw_lp; s_state_out[B9_NPARAM + 1] = nacc_in + (double)tw_n_acc; }
+    }
+}
+
+// Grid: [writers W][derivation][heavy][pad to 8][hot].  n_front = first hot workgroup id.
+template <int NFP, int NPOPS>
+__global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS))
+void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int tiles_per_block, int n_front, int derive_parts)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int W = td.n_walkers, NN = (1 << td.depth) - 1, NO = td.derive_mode == 2 ? 1 : (1 << td.depth);
+    int b = blockIdx.x;
+    if (b >= n_front) { tree_hot<NFP, NPOPS>(pk, st, td, b - n_front, tiles_per_block, smem); return; }
+    const int n_writers = td.derive_mode == 2 ? 0 : W;       // (the prologue has no tree to take a decision on)
+    if (b < n_writers) { tree_writer(pk, td, pr, b, nullptr); return; }
+    b -= n_writers;
+    const int n_derive = td.derive_mode == 0 ? 0 : W * NO * NN * NPOPS * derive_parts;
+    if (b < n_derive) {          // b = (((w * NO + o2) * NN + n2) * NPOPS + pop) * parts + part
+        const int part = b % derive_parts; b /= derive_parts;
+        const int pop = b % NPOPS; b /= NPOPS;
+        const int n2 = b % NN; b /= NN;
+        const int o2 = b % NO; b /= NO;
+        tree_derive(pk, td, b, o2, n2, pop, part, derive_parts);
+        return;
+    }
+    b -= n_derive;
+    if (td.levels > 0 && b < W * NN * td.heavy_parts) tree_heavy<NFP, NPOPS>(pk, st, td, b, smem);
+}
+
+// the block's last walk: one workgroup per walker, writer role only (+ the block's summary rows, the host mirror)
+__global__ __launch_bounds__(256) void k_tree_finish(DevPack pk, TreeDev td, DevPriors pr)
+{
+    __shared__ double s_last[B9_NPARAM + 2];
+    tree_writer(pk, td, pr, blockIdx.x, s_last);
+    __syncthreads();
+    if (td.rows) {
+        StepDev sd{};
+        sd.d = td.d; sd.n_walkers = td.n_walkers; sd.n_steps = td.n_steps; sd.samples = td.samples; sd.free_idx = td.free_idx;
+        sd.row_origin = td.row_origin; sd.rows = td.rows; sd.host_rows = td.host_rows;
+        block_summary_row(sd, blockIdx.x, s_last);
+    }
+    if (td.host_state) {
+        double *h = td.host_state + (size_t)blockIdx.x * B9_TREE_STATE_STRIDE;
+        if (threadIdx.x < B9_NPARAM) h[B9_TS_CUR + threadIdx.x] = s_last[threadIdx.x];
+        if (threadIdx.x == B9_NPARAM) { h[B9_TS_LP] = s_last[B9_NPARAM]; h[B9_TS_NACC] = s_last[B9_NPARAM + 1]; }
+    }
+}
+
+// The block's opening (as k_mcmc_begin): the upload from the mapped host mirror, and the starting state -- the caller's,
+// or the previous block's final state rows -- into BOTH parities' state rows (the prologue launch reads one, K(0) the other).
+__global__ __launch_bounds__(256) void k_tree_begin(const double *__restrict__ host_up, double *__restrict__ dev, int up_words,
+                                                    const double *__restrict__ prev_final, double *__restrict__ state, int n_walkers)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < up_words; i += 256) dev[i] = host_up[i];
+    if (!prev_final) return;
+    __syncthreads();
+    for (int w = 0; w < n_walkers; ++w) {
+        const double *src = prev_final + (size_t)w * B9_TREE_STATE_STRIDE;
+        for (int p = 0; p < 2; ++p) {
+            double *dst = state + ((size_t)p * n_walkers + w) * B9_TREE_STATE_STRIDE;
+            if (tid < B9_NPARAM) dst[B9_TS_CUR + tid] = src[B9_TS_CUR + tid];
+            if (tid == B9_NPARAM) { dst[B9_TS_LP] = src[B9_TS_LP]; dst[B9_TS_NACC] = 0.0; }
+        }
+    }
+}

@@ -182,6 +182,12 @@ class Engine:
             self._check(r)
         return r
 
+    def step_depth(self, n_walkers: int) -> int:
+        r = int(self.lib.b9_step_depth(self._ctx, int(n_walkers)))
+        if r < 0:
+            self._check(r)
+        return r
+
     def device_id(self) -> int:
         return int(self.lib.b9_device_id(self._ctx))
 

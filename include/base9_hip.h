@@ -166,7 +166,7 @@ typedef struct b9_options {
  * number of GPUs the walkers are spread over must pin it (singlePopMcmc --tilesPerBlock n does).
  * The same fields can be set through the environment, read ONCE when the context is created: B9_TILES_PER_BLOCK,
  * B9_DERIVE_PARTS, B9_DERIVE_ORDER (historical coding: 1 default, 0 heavy first, < 0 derivation trails), B9_HEAVY_PARTS,
- * B9_WALKERS_PER_LANE, B9_CONTIGUOUS_TILES, B9_TWO_LAUNCH_STEPS, B9_NO_CHUNK_BOUNDS, B9_TIMING_GROUP, B9_PLAN_DEBUG;
+ * B9_WALKERS_PER_LANE, B9_CONTIGUOUS_TILES, B9_TWO_LAUNCH_STEPS, B9_NO_CHUNK_BOUNDS, B9_TIMING_GROUP, B9_PLAN_DEBUG, B9_TREE_DEPTH;
  * B9_STREAM_PRIORITY=default gives the context's stream the default priority instead of the lowest.
  */
 typedef struct b9_tuning {
@@ -181,7 +181,11 @@ typedef struct b9_tuning {
     int32_t no_chunk_bounds;   /* 1: marginalised kernel without its chunk-level pruning table                           */
     int32_t timing_group;      /* launches per HIP-event bracket of b9_enable_timing in the fused step (default 8)        */
     int32_t plan_debug;        /* 1: print the fused step's launch plan to stderr whenever it changes                    */
-    int32_t reserved[6];
+    int32_t tree_depth;        /* given-mass sampler blocks: Metropolis steps per launch.  1 = the one-step fused launch;   */
+                               /* 2 / 3 = the tree-speculative launch (every proposal of the chain's next 2 / 3 steps --   */
+                               /* 3 / 7 of them -- evaluated at once, same chain); default: the deepest tree whose          */
+                               /* workgroups are all resident at once (few walkers per GPU), else 1.  Env: B9_TREE_DEPTH    */
+    int32_t reserved[5];
 } b9_tuning;
 
 typedef struct b9_ctx b9_ctx;
@@ -319,6 +323,8 @@ int b9_bytes_per_star_eval(const b9_ctx *ctx);
  * and tuning (> 0), or a negative b9_status.  The summation grouping of a walker's log-posterior follows from it (see
  * b9_tuning.tiles_per_block). */
 int b9_step_tiles_per_block(b9_ctx *ctx, int32_t n_walkers);
+/* Metropolis steps one launch of a given-mass sampler block advances n_walkers local chains by (b9_tuning.tree_depth). */
+int b9_step_depth(b9_ctx *ctx, int32_t n_walkers);
 /* Elapsed ms of the dominant (star-likelihood) kernel over the TIMED launches since the last
  * call with reset != 0, measured with HIP events on the launch stream; *n_launches receives
  * their count.  b9_enable_timing(ctx, n): n = 0 off, n > 0 opens an event bracket at every n-th

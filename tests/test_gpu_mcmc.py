@@ -55,15 +55,22 @@ def test_walker_sampler_on_device_recovers_truth():
 
 
 @pytest.mark.parametrize("env", [
-    {"B9_TILES_PER_BLOCK": "1", "B9_DERIVE_PARTS": "1"},                          # many workgroups, several occupancy rounds' worth of prologues
-    {"B9_TILES_PER_BLOCK": "2", "B9_DERIVE_PARTS": "3", "B9_DERIVE_ORDER": "-1"},  # derivation workgroups trail the grid
-    {"B9_TILES_PER_BLOCK": "5", "B9_CONTIGUOUS_TILES": "1"},                      # consecutive tiles, ragged last group
-    {"B9_TILES_PER_BLOCK": "7"},                                                  # strided tiles, groups without a last tile
+    # the one-step fused launch (k_mcmc_step; B9_TREE_DEPTH=1 pins it: this small shape would otherwise take the tree launch)
+    {"B9_TREE_DEPTH": "1", "B9_TILES_PER_BLOCK": "1", "B9_DERIVE_PARTS": "1"},                          # many workgroups, several occupancy rounds' worth of prologues
+    {"B9_TREE_DEPTH": "1", "B9_TILES_PER_BLOCK": "2", "B9_DERIVE_PARTS": "3", "B9_DERIVE_ORDER": "-1"},  # derivation workgroups trail the grid
+    {"B9_TREE_DEPTH": "1", "B9_TILES_PER_BLOCK": "5", "B9_CONTIGUOUS_TILES": "1"},                      # consecutive tiles, ragged last group
+    {"B9_TREE_DEPTH": "1", "B9_TILES_PER_BLOCK": "7"},                                                  # strided tiles, groups without a last tile
     {"B9_TWO_LAUNCH_STEPS": "1"},                                                 # the two-launch step (what marginalised mode runs)
-    {"B9_DERIVE_ORDER": "0", "B9_HEAVY_PARTS": "3"},                               # heavy-star workgroups lead the grid; few, long heavy lists
-    {"B9_DERIVE_ORDER": "1", "B9_HEAVY_PARTS": "16", "B9_DERIVE_PARTS": "2"},      # (default order) many heavy parts, most of them idle
+    {"B9_TREE_DEPTH": "1", "B9_DERIVE_ORDER": "0", "B9_HEAVY_PARTS": "3"},                               # heavy-star workgroups lead the grid; few, long heavy lists
+    {"B9_TREE_DEPTH": "1", "B9_DERIVE_ORDER": "1", "B9_HEAVY_PARTS": "16", "B9_DERIVE_PARTS": "2"},      # (default order) many heavy parts, most of them idle
+    # the tree-speculative launch (k_mcmc_tree): 2 / 3 steps per launch, blocks that are not a multiple of the depth
+    {"B9_TREE_DEPTH": "2"},
+    {"B9_TREE_DEPTH": "3"},                                                       # (more workgroups than one occupancy round at 5 walkers: still the same chain)
+    {"B9_TREE_DEPTH": "3", "B9_TILES_PER_BLOCK": "5", "B9_DERIVE_PARTS": "1", "B9_HEAVY_PARTS": "2"},
+    {"B9_TREE_DEPTH": "2", "B9_TILES_PER_BLOCK": "2", "B9_CONTIGUOUS_TILES": "1", "B9_DERIVE_PARTS": "3"},
+    {},                                                                           # the automatic plan
 ])
-@pytest.mark.parametrize("n_steps", [1, 2, 9])
+@pytest.mark.parametrize("n_steps", [1, 2, 9, 10])
 def test_fused_step_plans_all_give_the_same_chain(monkeypatch, env, n_steps):
     """The launch plan of the fused sampler step (tiles per workgroup, derivation parts, their place in the grid,
     strided or consecutive tiles) and the block length (1 step: no K(t) ever takes a decision; 2: one does)
