@@ -330,12 +330,11 @@ int ensure_capacity(b9_ctx *ctx, int n_walkers, int n_pops, size_t n_partial, bo
 }
 
 
-// the marginalised mode's companion table for n_walkers rows (grown on demand)
+// the marginalised mode's per-call node table for n_walkers rows (grown on demand)
 int ensure_marg_table(b9_ctx *ctx, int n_walkers, int n_pops, int K, int Q)
 {
-    if (Q < 2) return B9_OK;
-    const size_t need = (size_t)n_walkers * n_pops * (Q - 1) * ctx->pk.nfp * b9k_marg_table_npad(ctx->mass_cap, K);
-    if (need > ((size_t)8 << 30) / sizeof(double)) return fail(ctx, B9_ERR_CAPACITY, "marginalisation grid too fine: the companion table would exceed 8 GiB");
+    const size_t need = (size_t)n_walkers * n_pops * (size_t)b9k_marg_table_doubles(ctx->pk.nfp, ctx->mass_cap, K, Q);
+    if (need > ((size_t)8 << 30) / sizeof(double)) return fail(ctx, B9_ERR_CAPACITY, "marginalisation grid too fine: the node table would exceed 8 GiB");
     if (need > ctx->marg_tab_cap) {
         if (ctx->d_marg_tab) (void)hipFree(ctx->d_marg_tab);
         ctx->d_marg_tab = nullptr; ctx->marg_tab_cap = 0;

@@ -171,6 +171,11 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
 
 // nodes of the companion table per (walker, population, mass ratio, filter): whole 64-node chunks of the longest isochrone
 int b9k_marg_table_npad(int mass_cap, int K) { return (((mass_cap - 1) * K + 63) / 64) * 64; }
+// doubles of one (walker, population)'s table: (Q - 1) NFP companion planes + NFP magnitude + NFP flux planes + the log weights
+long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q)
+{
+    return ((long long)(Q - 1) * nfp + 2LL * nfp + 1) * b9k_marg_table_npad(mass_cap, K);
+}
 
 template <int NFP, int NPOPS, bool SAMPLE>
 static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
@@ -178,9 +183,8 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
                                      double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool chunk_bounds, int n_cu,
                                      double *tab, hipStream_t stream)
 {
-    constexpr int RS = NFP + B9_MARG_ROW_PAD;
-    // [isochrones: mass column + padded rows][chunk-bound table: three planes][per wave: star constants + lane list][per wave: chunk list]
-    size_t lds = sizeof(double) * ((size_t)NPOPS * mass_cap * (RS + 1) + (size_t)4 * B9_MARG_WAVE_SCRATCH(NFP));
+    // [mass columns][chunk-bound table: three planes][per wave: star constants][per wave: chunk list]
+    size_t lds = sizeof(double) * ((size_t)NPOPS * (mass_cap + 8) + (size_t)4 * B9_MARG_WAVE_SCRATCH(NFP));
     int chunk_cap = ((mass_cap - 1) * K + 63) / 64 + 1;                     // chunk-bound table, when LDS has room for it
     const size_t with_table = lds + sizeof(double) * ((size_t)NPOPS * chunk_cap * NFP * 3) + sizeof(int) * 4 * ((size_t)chunk_cap + 1);
     if (with_table <= 160 * 1024 && chunk_bounds) lds = with_table; else chunk_cap = 0;
@@ -200,12 +204,12 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     const int gx = std::max(1, std::min(n_quads, (per_cu * std::max(1, n_cu)) / std::max(1, n_walkers)));
     // the companions' flux table of this call (per walker and population; nothing to build for a single mass ratio)
     const int npad = b9k_marg_table_npad(mass_cap, K);
-    const long long tab_stride = (long long)(Q - 1) * NFP * npad;
-    if (Q > 1) {
+    const long long tab_stride = b9k_marg_table_doubles(NFP, mass_cap, K, Q);
+    {
         if (!tab) return hipErrorInvalidValue;
-        const int parts = std::max(1, std::min(64, (npad * (Q - 1) + 1023) / 1024));
+        const int parts = std::max(1, std::min(64, (npad * Q + 1023) / 1024));
         hipLaunchKernelGGL((k_marg_table<NFP>), dim3(n_walkers * NPOPS, parts), dim3(256), sizeof(double) * (mass_cap + 8), stream, hdr, iso_data,
-                           iso_stride, mass_cap, K, Q, tab, tab_stride, npad);
+                           iso_stride, mass_cap, K, Q, tab, tab_stride, npad, pk.log_mass_norm);
     }
     hipLaunchKernelGGL(kern, dim3(gx * n_walkers), dim3(256), lds, stream, pk, st, hdr, iso_data, iso_stride,
                        mass_cap, d_params, vals, perstar, K, Q, ms, chunk_cap, tab, tab_stride, npad, n_walkers, gx);

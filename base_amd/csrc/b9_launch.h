@@ -41,8 +41,9 @@ struct B9MargSample {
 hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
                          double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool chunk_bounds, int n_cu,
-                         double *tab /* companions' flux table: n_walkers * n_pops * (Q - 1) * nfp * b9k_marg_table_npad doubles (Q > 1) */, hipStream_t stream);
+                         double *tab /* the call's node table: n_walkers * n_pops * b9k_marg_table_doubles(nfp, mass_cap, K, Q) doubles */, hipStream_t stream);
 int b9k_marg_table_npad(int mass_cap, int K);
+long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q);
 
 // fused sampler step (given-mass mode): decision of step t-1 + stars of step t + candidates of step t+1
 // (tiles_per_block < 0: a workgroup's |tiles_per_block| tiles are strided n_groups apart instead of consecutive)

@@ -14,11 +14,13 @@
 // Round 3 layout.  WORKGROUPS ARE PERSISTENT over a walker's stars: the walker's isochrone (mass column +
 // magnitude rows) and the chunk-bound table are staged in LDS ONCE per workgroup; its four waves then walk
 // the star slots in strides of the launch's wave count (each wave on its own: no workgroup barrier after
-// the staging).  Lane = primary-mass node of a 64-node chunk: the primary is interpolated from the LDS rows;
-// the COMPANION of node n at mass ratio j / n_q depends on the walker only, not on the star, so its flux per
-// filter comes from a table built once per call (k_marg_table, [j - 1][filter][node], L2-resident: the
-// workgroups of a walker share an XCD) -- no secondary bracket search, no second interpolation, and the flux
-// combine is -2.5 log10(F1 + F2): one logarithm per (node, j, filter) instead of an exponential and a logarithm.
+// the staging).  Lane = primary-mass node of a 64-node chunk.  NOTHING about a node depends on the star: its primary
+// magnitudes and fluxes, its log(prior dM / n_q), and -- per mass ratio j / n_q -- its companion's fluxes are tabulated
+// once per call (k_marg_table; L2-resident: the workgroups of a walker share an XCD).  A star's work is then, per node,
+// the chi^2 of the single star (j = 0) and, per companion, one add and one logarithm per filter: -2.5 log10(F1 + F2).
+// (Round 2's kernel re-derived all of that per star: bracket searches, interpolations, an exponential and a logarithm per
+// flux combine -- 9090 VALU wave-instructions per star-eval against 4.5k now; its LDS rows at a 64-byte stride were 4-way
+// bank-conflicted, a padded stride removed the conflicts without moving the time, and the rows then left LDS altogether.)
 // A star of stage WD integrates over (AGB tip, M_wd_up] in 8 iso_increm steps through the WD branch: those stars (a few
 // per cent of a cluster, listed at load time: DevStars::wd_slot) have a kernel of their own, k_star_marg_wd, so that
 // the WD branch's registers (it alone wants > 200 VGPRs) do not set the occupancy of every other star's evaluation.
@@ -27,10 +29,6 @@ struct Lse { double mx, sm; };      // online log-sum-exp:  value = mx + log(sm)
 #ifndef B9_MARG_CUT
 #define B9_MARG_CUT 40.0             // nodes more than this many e-folds below the running maximum are dropped
 #endif
-#ifndef B9_MARG_ROW_PAD
-#define B9_MARG_ROW_PAD 1            // LDS magnitude rows are NFP + 1 doubles apart: with 64-byte rows the 8 rows a half-wave's primary
-#endif                               // nodes touch fall on 4 bank groups (SQ_LDS_BANK_CONFLICT ~ SQ_ACTIVE_INST_LDS in round 2's profile)
-
 __device__ __forceinline__ void lse_add(Lse &a, double x)
 {
     if (x == NEG_INF) return;
@@ -106,7 +104,7 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // Waves per SIMD the instances are built for (tools/kernel_resources.py; every instance at <= 16 B of scratch per lane).
 #ifndef B9_MARG_WAVES
-#define B9_MARG_WAVES(NFP, NPOPS, SAMPLE) (((NFP) >= 16 || (SAMPLE) || ((NPOPS) == 2 && (NFP) >= 8)) ? 2 : 3)
+#define B9_MARG_WAVES(NFP, NPOPS, SAMPLE) (((NFP) >= 16 && (NPOPS) == 2 && (SAMPLE)) ? 1 : (((NFP) >= 16 || (SAMPLE) || ((NPOPS) == 2 && (NFP) >= 8)) ? 2 : 3))
 #endif
 
 // doubles of per-wave LDS scratch: the star's shift / obs / weight per filter
@@ -121,7 +119,6 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                                                     const double *__restrict__ tab, long long tab_stride, int npad,
                                                     int n_walkers, int wg_per_walker)
 {
-    constexpr int RS = NFP + B9_MARG_ROW_PAD;            // LDS row stride of the magnitude rows, doubles
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid of n_walkers * wg_per_walker workgroups.  Workgroup ids are dealt round-robin over the 8 XCDs: with a
@@ -145,18 +142,17 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
             }
         return;
     }
-    // ---- once per workgroup: stage the isochrone(s): [pop][ mass[cap] | mags[cap][RS] ] -------------------------------
-    const double *lds_mass[NPOPS], *lds_mags[NPOPS];
+    // ---- once per workgroup: the mass column(s) in LDS (the seed's bracket search; SAMPLE's node masses).  The magnitude
+    // rows are not staged: every per-node quantity the star loop needs comes from the call's table (k_marg_table).
+    const double *lds_mass[NPOPS];
 #pragma unroll
     for (int kp = 0; kp < NPOPS; ++kp) {
-        double *dst = smem + (size_t)kp * mass_cap * (RS + 1);
+        double *dst = smem + (size_t)kp * (mass_cap + 8);
         const double2 *src2 = reinterpret_cast<const double2 *>(iso_g[kp].mass);
         double2 *d2 = reinterpret_cast<double2 *>(dst);
         for (int j = tid; j < mass_cap / 2; j += 256) d2[j] = src2[j];                       // (mass_cap is even)
-        double *rows = dst + mass_cap;
-        const int total = iso_g[kp].n * NFP;
-        for (int idx = tid; idx < total; idx += 256) rows[(idx / NFP) * RS + (idx & (NFP - 1))] = iso_g[kp].mags[idx];
-        lds_mass[kp] = dst; lds_mags[kp] = rows;
+        if (tid < 8) dst[mass_cap + tid] = __builtin_inf();                                  // find_bracket's masked over-read
+        lds_mass[kp] = dst;
     }
     __syncthreads();
     // Chunk-level pruning table, per 64-node chunk c of the primary-mass loop and per filter f (three planes):
@@ -168,7 +164,7 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
     //                  two bracketing rows lie at or below the chunk's last row).  Where even that is fainter
     //                  than observed, every node and every mass ratio pays the deficit.
     //   (third plane: the chunk's own brightest row, an intermediate of the prefix minimum.)
-    double *const chunk_tab = smem + (size_t)NPOPS * mass_cap * (RS + 1);
+    double *const chunk_tab = smem + (size_t)NPOPS * (mass_cap + 8);
     const size_t plane = (size_t)NPOPS * chunk_cap * NFP;
     if (chunk_cap > 0) {
 #pragma unroll
@@ -179,8 +175,9 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                 const int r0 = (64 * c) / K;
                 int r1 = (64 * c + 63) / K + 1;
                 r1 = r1 > n - 1 ? n - 1 : r1;
-                double mx = lds_mags[kp][(size_t)r0 * RS + f], mn = mx;
-                for (int r = r0 + 1; r <= r1; ++r) { const double v = lds_mags[kp][(size_t)r * RS + f]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+                const double *col = iso_g[kp].mags + f;                          // (global, L2: once per workgroup)
+                double mx = col[(size_t)r0 * NFP], mn = mx;
+                for (int r = r0 + 1; r <= r1; ++r) { const double v = col[(size_t)r * NFP]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
                 chunk_tab[((size_t)kp * chunk_cap + c) * NFP + f] = mx;
                 chunk_tab[2 * plane + ((size_t)kp * chunk_cap + c) * NFP + f] = mn;
             }
@@ -255,7 +252,12 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
         }
 #pragma unroll
         for (int kp = 0; kp < NPOPS; ++kp) {
-            const double *const mass = lds_mass[kp], *const mags = lds_mags[kp];
+            const double *const mass = lds_mass[kp];
+            // this (walker, population)'s table: companions [(j - 1) NFP + f][npad], then per node the primary's magnitudes
+            // [f][npad], fluxes [f][npad] and log(prior dM / Q) [npad]
+            const double *const tab_wp = tab + (size_t)(w * NPOPS + kp) * tab_stride;
+            const double *const tab_p1 = tab_wp + (size_t)(Q - 1) * NFP * npad, *const tab_f1 = tab_p1 + (size_t)NFP * npad,
+                         *const tab_base = tab_f1 + (size_t)NFP * npad;
             const int n_eep = iso_g[kp].n;
             const double tip = iso_g[kp].tip;
             Lse acc; acc.mx = NEG_INF; acc.sm = 0.0;
@@ -280,12 +282,12 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                             const double dMs = d / K;
                             int s = (int)((ms_ - a) / dMs);
                             s = s < 0 ? 0 : (s > K - 1 ? K - 1 : s);
-                            const double mn = fma((double)s, dMs, a), tn = (mn - a) / d;
-                            const double *r = mags + (size_t)lo * RS;
+                            const int ns = __builtin_amdgcn_readfirstlane(lo * K + s);       // the node: wave-uniform (scalar loads)
                             double c = 0.0;
 #pragma unroll
-                            for (int f = 0; f < NFP; ++f) { const double dd = (lerp(r[f], r[RS + f], tn) + s_shift[f]) - s_obs[f]; c = fma(s_wgt[f] * dd, dd, c); }
-                            if (isfinite(c)) seed = (log_prior_mass_dev(pk.log_mass_norm, mn) + log_pos(dMs / Q)) - 0.5 * c;
+                            for (int f = 0; f < NFP; ++f) { const double dd = (tab_p1[(size_t)f * npad + ns] + s_shift[f]) - s_obs[f]; c = fma(s_wgt[f] * dd, dd, c); }
+                            const double bs = tab_base[ns];
+                            if (isfinite(c) && bs != NEG_INF) seed = bs - 0.5 * c;
                         }
                     }
                 }
@@ -338,18 +340,18 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                         if (cb > 2.0 * ((bmax[kp] - wmx) + B9_MARG_CUT)) continue;
                     }
                     MSTAT(1, 1);
-                    // ---- primary pass: lane = node ------------------------------------------------------------------
-                    bool live = pnode < n_nodes;
-                    int e = 0, s = 0;
-                    double a = 0.0, d = 1.0;
-                    if (live) { e = pnode / K; s = pnode - e * K; a = mass[e]; d = mass[e + 1] - a; live = d > 0.0; }
-                    const double dM = d / K;
-                    const double m1 = fma((double)s, dM, a);
-                    const double t1 = (m1 - a) / d;
-                    const double *r0 = mags + (size_t)e * RS;
+                    // ---- primary pass: lane = node.  Magnitudes, fluxes and log(prior dM / Q) of the node: table words ------
                     double p1[NFP];
 #pragma unroll
-                    for (int f = 0; f < NFP; ++f) p1[f] = lerp(r0[f], r0[RS + f], t1);
+                    for (int f = 0; f < NFP; ++f) p1[f] = tab_p1[(size_t)f * npad + pnode];
+                    const double base_n = tab_base[pnode];                       // -inf: past the last node, or an empty EEP interval
+                    bool live = base_n != NEG_INF;
+                    double m1 = 0.0;
+                    if (SAMPLE) {                                                // (only the draws report the node's mass)
+                        const int pn = pnode < n_nodes ? pnode : 0, e = pn / K, sb = pn - e * K;
+                        const double a = mass[e];
+                        m1 = fma((double)sb, (mass[e + 1] - a) / K, a);
+                    }
                     // j = 0 (single star) and the too-bright lower bound for j >= 1
                     double chi0 = 0.0, chi_lb = 0.0;
 #pragma unroll
@@ -359,12 +361,17 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                         chi0 = fma(wdd, dd, chi0);
                         chi_lb = dd < 0.0 ? fma(wdd, dd, chi_lb) : chi_lb;
                     }
+                    // the primary's fluxes (for the companions below): requested now that the magnitudes' registers are free,
+                    // in flight across the tests and the single-star term
+                    double F1[NFP];
+#pragma unroll
+                    for (int f = 0; f < NFP; ++f) F1[f] = tab_f1[(size_t)f * npad + pnode];
                     // with the bound bmax on this node's (prior + weight) nothing of it can matter: skip
                     const double cut_ub = 2.0 * ((bmax[kp] - wmx) + B9_MARG_CUT);
                     live = live && !(chi_lb > cut_ub);                           // chi0 >= chi_lb
                     if (__ballot(live) == 0ull) continue;
                     MSTAT(2, 1);
-                    const double base = live ? log_prior_mass_dev(pk.log_mass_norm, m1) + log_pos(dM / Q) : NEG_INF;
+                    const double base = live ? base_n : NEG_INF;
                     if (live && isfinite(chi0)) {
                         lse_add(acc, base - 0.5 * chi0);
                         B9_SAMPLE_NODE(base - 0.5 * chi0, (long long)pnode * Q, m1, 0.0)
@@ -374,14 +381,9 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                     const unsigned long long wmask = __ballot(want);
                     if (wmask == 0ull || Q < 2) continue;                        // (A) for the whole wave
                     MSTAT(3, 1); MSTAT(6, __popcll(wmask));
-                    // ---- companions: the node's secondary for mass ratio j does not depend on the star -- its FLUX in every
-                    // filter comes from the walker's table (k_marg_table: [j - 1][f][node], built once per call), so a
-                    // (node, j, filter) costs one add and one logarithm: -2.5 log10(F1 + F2).  The 8 table words of a
-                    // mass ratio are requested together, one mass ratio ahead of their use.
-                    double F1[NFP];
-#pragma unroll
-                    for (int f = 0; f < NFP; ++f) F1[f] = exp_fast((-0.4 * LN10) * p1[f]);
-                    const double *tp = tab + (size_t)(w * NPOPS + kp) * tab_stride + pnode;
+                    // ---- companions: a (node, j, filter) costs one add and one logarithm: -2.5 log10(F1 + F2), both fluxes table
+                    // words.  The NFP words of a mass ratio are requested together, one mass ratio ahead of their use.
+                    const double *tp = tab_wp + pnode;
                     double F2[NFP];
 #pragma unroll
                     for (int f = 0; f < NFP; ++f) F2[f] = tp[(size_t)f * npad];
@@ -412,13 +414,15 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                     }
                 }
             }
-            // wavefront shuffle reduction of the 64 partial log-sum-exps
+            // wavefront combine of the 64 partial log-sum-exps: the wave's maximum first, then every lane's sum rescaled to it
+            // ONCE and a plain shuffle sum (one exponential per lane instead of one per lane and shuffle step)
+            double wm = acc.mx;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                Lse b; b.mx = __shfl_down(acc.mx, o, 64); b.sm = __shfl_down(acc.sm, o, 64);
-                acc = lse_merge(acc, b);
-            }
-            ll[kp] = (acc.mx == NEG_INF) ? NEG_INF : c0m + (acc.mx + log(acc.sm));
+            for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(wm, o, 64); wm = t > wm ? t : wm; }
+            double ssum = (acc.mx == NEG_INF) ? 0.0 : acc.sm * exp_fast(acc.mx - wm);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
+            ll[kp] = (wm == NEG_INF) ? NEG_INF : c0m + (wm + log(ssum));
         }
 #undef B9_SAMPLE_NODE
         if (SAMPLE) {      // wave argmax of the keys (ties keep the lower lane)
@@ -452,12 +456,14 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
 // sub-step n % K: the primary mass the main kernel forms, same operations) and mass ratio j / Q, j = 1 .. Q-1:
 // secondary mass m2 = (j / Q) m1, bracket + linear interpolation of the derived isochrone's rows (below the
 // isochrone's first point: no flux, magnitude 99.999), and F2 = 10^(-0.4 magnitude) per filter.
-// Layout tab[wp][(j - 1) * NFP + f][npad] (npad = whole 64-node chunks; nodes past the end hold 0).
+// And per node the primary itself: magnitudes, fluxes F1 = 10^(-0.4 magnitude), log(prior(m1) dM / Q) (-inf: no such node).
+// Layout tab[wp]: [(j - 1) * NFP + f][npad] companions, [f][npad] magnitudes, [f][npad] fluxes, [npad] log weights
+// (npad = whole 64-node chunks; nodes past the end hold 0 / -inf).
 // Grid: (walkers * pops, parts).
 // ------------------------------------------------------------------------------------------
 template <int NFP>
 __global__ __launch_bounds__(256) void k_marg_table(const IsoHdr *__restrict__ hdr, const double *__restrict__ iso_data, long long iso_stride,
-                                                    int mass_cap, int K, int Q, double *__restrict__ tab, long long tab_stride, int npad)
+                                                    int mass_cap, int K, int Q, double *__restrict__ tab, long long tab_stride, int npad, double lmn)
 {
     extern __shared__ __attribute__((aligned(16))) double s_mass[];
     const int wp = blockIdx.x, tid = threadIdx.x;
@@ -495,6 +501,27 @@ __global__ __launch_bounds__(256) void k_marg_table(const IsoHdr *__restrict__ h
         }
 #pragma unroll
         for (int f = 0; f < NFP; ++f) out[((size_t)jm1 * NFP + f) * npad + node] = F[f];
+    }
+    // the primaries: magnitudes, fluxes, log(prior(m1) dM / Q) of every node (the operations the star kernel used to repeat per star)
+    double *p1 = out + (size_t)(Q - 1) * NFP * npad, *f1 = p1 + (size_t)NFP * npad, *bs = f1 + (size_t)NFP * npad;
+    for (int node = blockIdx.y * 256 + tid; node < npad; node += gridDim.y * 256) {
+        double P[NFP], base = NEG_INF;
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) P[f] = 0.0;
+        if (node < n_nodes) {
+            const int e = node / K, s = node - e * K;
+            const double a = s_mass[e], d = s_mass[e + 1] - a;
+            const double *r0 = g_mags + (size_t)e * NFP;
+            const double dM = d / K;
+            const double m1 = fma((double)s, dM, a);
+            const double t1 = (d > 0.0) ? (m1 - a) / d : 0.0;
+#pragma unroll
+            for (int f = 0; f < NFP; ++f) P[f] = lerp(r0[f], r0[NFP + f], t1);
+            if (d > 0.0) base = log_prior_mass_dev(lmn, m1) + log_pos(dM / Q);
+        }
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) { p1[(size_t)f * npad + node] = P[f]; f1[(size_t)f * npad + node] = exp_fast((-0.4 * LN10) * P[f]); }
+        bs[node] = base;
     }
 }
 

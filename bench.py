@@ -452,7 +452,11 @@ def main():
                        "collective": (exchange.name + "; one all-gather of [logpost, position, moments] rows per block") if use_rccl else "none",
                        "wd_tracks": "rectangular cooling table (wc_uniform path); the bench cluster has no WD-stage stars -- the ragged-track "
                                     "path of real cooling models is timed in profiles/ (config sweep, row C3r)",
-                       "prewarm_steps_untimed": prewarm, "steps_per_launch": 1},
+                       "prewarm_steps_untimed": prewarm,
+                       "steps_per_launch": eng.step_depth(WALKERS_PER_GPU),
+                       "steps_per_launch_note": "Metropolis steps of every chain per k_mcmc_step / k_mcmc_tree launch: 1 at 8 walkers x 50k stars (the "
+                                                "launch is full); the single-chain BASELINE shapes run the tree-speculative launch, 3 steps each "
+                                                "(profiles/ config sweep)"},
             "roofline": roof,
             "timed_region_breakdown": {"kernel_ms": kernel_ms, "host_and_block_fixed_ms": (1e3 * dt - kernel_ms) if kernel_ms else None,
                                        "wall_ms": 1e3 * dt, "ms_per_step_over_launch_period": (1e3 * dt / args.steps) / (1e3 * k_avg_s) if k_n else None},

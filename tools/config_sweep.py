@@ -7,18 +7,14 @@ import numpy as np
 import oracle
 from base_amd import abi, engine, hostlib, mcmc, synth
 
-CONFIGS = [
-    # name, pack, n_filt, n_stars, wd_frac, n_y, n_pops, walkers on this GPU, note
-    ("C0", "girardi", 3, 200, 0.0, 1, 1, 1, "200-star, Girardi-shaped, 3 filters, 1 chain (the reference's CPU plumbing case)"),
-    ("C1", "dsed", 8, 10000, 0.0, 1, 1, 1, "10k-star, DSED-shaped, 8 filters, 1 chain, 1 GPU"),
-    ("C2", "parsec", 8, 50000, 0.0, 1, 1, 8, "50k-star, PARSEC-shaped, 8 filters, 64 walkers / 8 GPUs -> 8 per GPU (bench.py workload)"),
-    ("C3", "parsec", 8, 20000, 0.05, 1, 1, 1, "20k-star mixed MS+WD (5% WD: Bergeron-like atmospheres + IFMR), 8 filters, 1 GPU"),
-    ("C4", "parsec", 8, 30000, 0.0, 3, 2, 8, "two-population 30k-star, 8 filters, 32 walkers / 4 GPUs -> 8 per GPU"),
-]
+CONFIGS = [(k,) + v + (False,) for k, v in synth.BASELINE_CONFIGS.items()]
+# C3 again with RAGGED WD cooling tracks (every track its own age axis, as real cooling models have: the ABI-2 search path
+# instead of the rectangular table's shared-axis fast path)
+CONFIGS.append(("C3r",) + synth.BASELINE_CONFIGS["C3"][:-1] + ("C3 with ragged WD cooling tracks (per-track age axes)", True))
 SUBKEYS = ("obs", "sigma", "mass1", "mass_ratio", "clust_prior", "stage", "wd_type")
 rows = []
-for name, pk, nf, ns, wd, ny, npops, W, note in CONFIGS:
-    pack_d = synth.make_pack(pk, nf, n_y=ny)
+for name, pk, nf, ns, wd, ny, npops, W, note, ragged in CONFIGS:
+    pack_d = synth.make_pack(pk, nf, n_y=ny, wd_ragged=ragged)
     truth = synth.default_params(pack_d)
     cl = synth.make_cluster(pack_d, ns, seed=9001 + int(name[1]), truth=truth, wd_frac=wd, n_pops=npops)
     pack, stars = abi.make_pack(pack_d), abi.make_stars(cl)
@@ -40,15 +36,16 @@ for name, pk, nf, ns, wd, ny, npops, W, note in CONFIGS:
     a0 = s.state()["accepted_local"]
     t0 = time.perf_counter(); s.run(2000); dt = time.perf_counter() - t0
     accepted = s.state()["accepted_local"] - a0
-    r = dict(config=name, note=note, n_stars=ns, n_filt=nf, walkers=W, n_pops=npops, wd_stars=int((cl["stage"] == 3).sum()),
+    r = dict(config=name, note=note, steps_per_launch=eng.step_depth(W), n_stars=ns, n_filt=nf, walkers=W, n_pops=npops, wd_stars=int((cl["stage"] == 3).sum()),
              max_rel_err_vs_oracle=err, oracle_subset=len(idx), mcmc_steps_per_s=2000 / dt, us_per_step=1e6 * dt / 2000,
              star_evals_per_s=2000 * W * ns / dt, accept_rate=accepted / (2000.0 * W))
     rows.append(r)
     print(json.dumps(r), flush=True)
     eng.close()
-print("Five BASELINE.json configurations at one GPU's share (tools/config_sweep.py; C++ driver, fused one-launch sampler step, 100-step blocks)\n")
-print("| config | stars x filters | walkers | us/step | star-evals/s | max rel err vs oracle (all stars) | accept |")
-print("|---|---|---|---|---|---|---|")
+print("Five BASELINE.json configurations at one GPU's share (tools/config_sweep.py; C++ driver b9h::WalkerSampler, device-resident 100-step blocks;\n"
+      "steps/launch 1 = the one-step fused launch k_mcmc_step, 2-3 = the tree-speculative launch k_mcmc_tree)\n")
+print("| config | stars x filters | walkers | steps/launch | us/step | star-evals/s | max rel err vs oracle (all stars) | accept |")
+print("|---|---|---|---|---|---|---|---|")
 for r in rows:
-    print(f"| {r['config']} | {r['n_stars']} x {r['n_filt']}{' (2 pops)' if r['n_pops']==2 else ''}{' (%d WD)' % r['wd_stars'] if r['wd_stars'] else ''} | {r['walkers']} | "
+    print(f"| {r['config']} | {r['n_stars']} x {r['n_filt']}{' (2 pops)' if r['n_pops']==2 else ''}{' (%d WD)' % r['wd_stars'] if r['wd_stars'] else ''} | {r['walkers']} | {r['steps_per_launch']} | "
           f"{r['us_per_step']:.1f} | {r['star_evals_per_s']:.3e} | {r['max_rel_err_vs_oracle']:.1e} | {r['accept_rate']:.2f} |")

@@ -3,7 +3,7 @@
 # a trace domain: MI355X_MICROARCH.md "rocprofv3 PMC slots"), then tools/profile_summary.py.
 # usage: tools/profile_round.sh <tag> <commit>     -> gpurun_out/<tag>_*   (copy the summaries to profiles/)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out

@@ -4,7 +4,10 @@ csv): per-kernel times, raw PMC means per dispatch, and -- for the dominant kern
 bench.py reports (fp64 VALU issue, HBM traffic, algorithmic bytes), each reproduced here from the raw counters."""
 import csv, glob, json, collections, shutil, sys
 tag, commit, command = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "unknown"), (sys.argv[3] if len(sys.argv) > 3 else "")
-out = {"tag": tag, "commit": commit, "command": command + " (under rocprofv3: --kernel-trace --stats, and separate --pmc passes)", "kernels": {}, "pmc": {}}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from base_amd import build as _build
+out = {"tag": tag, "commit": commit, "csrc_sha256": _build.source_hash(), "command": command + " (under rocprofv3: --kernel-trace --stats, and separate --pmc passes)", "kernels": {}, "pmc": {}}
 for f in glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, f"gpurun_out/{tag}_kernel_stats.csv")
     for r in csv.DictReader(open(f)):
@@ -46,9 +49,22 @@ for k, c in out["pmc"].items():
             "wave_cycles_busy_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0)),
             "wave_cycles_waiting_frac": c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0))}
 out["roofline_k_mcmc_step"] = roof
+mroof = {}
+for k, c in out["pmc"].items():
+    if not k.startswith("k_star_marg<") or k not in out["kernels"]:
+        continue
+    t = out["kernels"][k]["avg_us"] * 1e-6
+    mroof = {"kernel": k, "avg_launch_us": out["kernels"][k]["avg_us"],
+             "valu_issue_frac": 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (N_SIMD * CLOCK * t),
+             "valu_insts_per_star_eval": c.get("SQ_INSTS_VALU", 0.0) / 400000.0,
+             "hbm_bytes_per_launch": c.get("hbm_bytes_per_launch"), "hbm_frac": c.get("hbm_bytes_per_launch", 0.0) / t / HBM_PEAK,
+             "lds_bank_conflict_over_lds_active": c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, c.get("SQ_ACTIVE_INST_LDS", 1.0)),
+             "wave_cycles_busy_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0)),
+             "wave_cycles_waiting_frac": c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0))}
+out["roofline_k_star_marg"] = mroof
 json.dump(out, open(f"gpurun_out/{tag}_summary.json", "w"), indent=1)
 with open(f"gpurun_out/{tag}_summary.md", "w") as md:
-    md.write(f"# rocprofv3 summary {tag} (commit {commit})\n\ncommand: `{command}` under `rocprofv3 --kernel-trace --stats` and separate `--pmc` passes\n\n")
+    md.write(f"# rocprofv3 summary {tag} (commit {commit}, kernel sources sha256 {out['csrc_sha256'][:16]})\n\ncommand: `{command}` under `rocprofv3 --kernel-trace --stats` and separate `--pmc` passes\n\n")
     md.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["pct"]):
         md.write(f"| `{k}` | {v['calls']} | {v['avg_us']:.2f} | {v['min_us']:.2f} | {v['max_us']:.2f} | {v['pct']:.1f} |\n")
@@ -59,6 +75,11 @@ with open(f"gpurun_out/{tag}_summary.md", "w") as md:
         md.write(f"* **HBM side**: (2 x FETCH_SIZE + WRITE_SIZE) = {roof['hbm_bytes_per_launch'] / 1e6:.2f} MB per launch -> {roof['hbm_GBps']:.0f} GB/s = **{roof['hbm_frac']:.3f}** of the 8 TB/s peak (L2 hit rate {roof['l2_hit_rate']:.2f})\n")
         md.write(f"* **algorithmic bytes** (SURVEY 8d: 152 B per star-eval): {roof['algorithmic_GBps_152B']:.0f} GB/s = {roof['algorithmic_frac_of_hbm_peak_152B']:.3f} of the HBM peak -- an L2-served rate (the walkers of a GPU share a star tile through the XCD-local L2), NOT an HBM fraction\n")
         md.write(f"* wave cycles: {roof['wave_cycles_busy_frac']:.2f} issuing, {roof['wave_cycles_waiting_frac']:.2f} waiting (s_waitcnt / barrier)\n")
+    if mroof:
+        md.write(f"\n## Marginalised mode: `{mroof['kernel']}` (50k stars x 8 walkers, 6384 nodes per star-eval)\n\n")
+        md.write(f"* launch: {mroof['avg_launch_us'] / 1e3:.2f} ms; fp64 VALU issue **{mroof['valu_issue_frac']:.3f}**; {mroof['valu_insts_per_star_eval']:.0f} VALU wave-instructions per star-eval\n")
+        md.write(f"* HBM: {mroof['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch = {mroof['hbm_frac']:.4f} of peak; LDS bank-conflict cycles / LDS active cycles = {mroof['lds_bank_conflict_over_lds_active']:.2f}\n")
+        md.write(f"* wave cycles: {mroof['wave_cycles_busy_frac']:.2f} issuing, {mroof['wave_cycles_waiting_frac']:.2f} waiting\n")
     md.write("\n## PMC (mean per dispatch)\n\n")
     for k, c in out["pmc"].items():
         if "copyBuffer" in k: continue
