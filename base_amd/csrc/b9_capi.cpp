@@ -1156,10 +1156,11 @@ static int run_block_tree(b9_ctx *ctx, b9_mcmc_block *blk, const TreePlan &tp)
     const size_t n_state = (size_t)W * B9_TREE_STATE_STRIDE,
                  n_samp = (blk->samples || want_rows) ? (size_t)S * W * d : 0, n_lps = blk->lps ? (size_t)S * W : 0,
                  n_rows = want_rows ? (size_t)W * B9_ROW_LEN(d) : 0;
-    //   [chol][origin][free, ids][state 0][state 1] | [rows][lps][samples]        upload = chol .. state 1
+    //   [chol][origin][free, ids][state 0][state 1] | [rows][lps][samples][step table]        upload = chol .. state 1
     const size_t n_int = ((size_t)(d + W) + 1) / 2;
+    const size_t tab_steps = (size_t)S + B9_TREE_MAX_DEPTH, n_tab = (size_t)W * tab_steps * B9_TREE_TAB_ROW;
     const size_t o_chol = 0, o_org = o_chol + (size_t)d * d, o_int = o_org + d, o_st0 = o_int + n_int, o_st1 = o_st0 + n_state,
-                 o_rows = o_st1 + n_state, o_lps = o_rows + n_rows, o_samp = o_lps + n_lps, n_total = o_samp + n_samp;
+                 o_rows = o_st1 + n_state, o_lps = o_rows + n_rows, o_samp = o_lps + n_lps, o_tab = o_samp + n_samp, n_total = o_tab + n_tab;
     const size_t up_words = o_rows;
     if (n_total * 8 > sl.cap) {
         if (sl.d) (void)hipFree(sl.d);
@@ -1210,6 +1211,7 @@ static int run_block_tree(b9_ctx *ctx, b9_mcmc_block *blk, const TreePlan &tp)
     td.chol = dev + o_chol; td.free_idx = reinterpret_cast<int *>(dev + o_int); td.walker_ids = td.free_idx + d;
     td.samples = n_samp ? dev + o_samp : nullptr; td.lps = n_lps ? dev + o_lps : nullptr;
     td.row_origin = dev + o_org; td.n_steps = S;
+    td.step_tab = dev + o_tab; td.tab_steps = (int)tab_steps; td.block_step0 = (unsigned long long)blk->step0;
     const int tiles_arg = tp.strided ? -tp.tiles_per_block : tp.tiles_per_block;
     const int M = (S + depth - 1) / depth;
     {   // P: the block's first tree from the starting state -> candidates of parity 0, outcome slot 0
@@ -1256,7 +1258,7 @@ static int run_block_tree(b9_ctx *ctx, b9_mcmc_block *blk, const TreePlan &tp)
         if (rows_event) HIPCHK(ctx, hipEventRecord(sl.rows_ready, s));
         blk->d_rows = want_rows ? (void *)(dev + o_rows) : nullptr;
         blk->rows_ready = rows_event ? (void *)sl.rows_ready : nullptr;
-        if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(stage + o_st0, dev + o_st0, ((blk->samples ? n_total : o_samp) - o_st0) * 8, hipMemcpyDeviceToHost, s));
+        if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(stage + o_st0, dev + o_st0, ((blk->samples ? o_tab : o_samp) - o_st0) * 8, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(ctx, hipEventRecord(sl.done, s));
     sl.kind = 2; sl.W = W; sl.final_parity = M & 1;

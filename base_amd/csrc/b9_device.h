@@ -211,6 +211,7 @@ struct StepDev {
 #define B9_TS_LPRIOR 17          // [17..23] log-prior of node n's proposal (-inf: outside the grid or the prior's support)
 #define B9_TS_PROP 24            // [24 + 12 n ..] node n's proposal
 #define B9_TREE_STATE_STRIDE (24 + 12 * B9_TREE_MAX_NODES + 4)      // 112 doubles
+#define B9_TREE_TAB_ROW 12       // step table row: [0..10] delta of sampled parameter t, [11] log u
 
 struct TreeDev {
     int d, n_walkers, n_pops;
@@ -237,6 +238,13 @@ struct TreeDev {
     const int *walker_ids;           // [W]
     double *samples;                 // [n_steps][W][d] or null
     double *lps;                     // [n_steps][W] or null
+    // Per-block table of everything about a STEP that does not depend on the chain: [W][tab_steps][B9_TREE_TAB_ROW] --
+    // per walker and step s (0 = the block's first): delta[t] = sum_j chol[t][j] z_j of sampled parameter t (the proposal's
+    // increment) and the accept test's log u.  Written once per block by the prologue launch; the K launches' derivation
+    // workgroups and writers READ it (the Philox + Box-Muller of six steps on one wave was 1.6 us of every derivation's chain).
+    double *step_tab;
+    int tab_steps;                   // n_steps + B9_TREE_MAX_DEPTH (a tree may reach past the block's end; those rows are never used for a decision)
+    unsigned long long block_step0;  // global index of the block's first step
     // the finish launch only (as StepDev's)
     double *rows;
     const double *row_origin;

@@ -350,7 +350,7 @@ static hipError_t launch_mcmc_tree(const DevPack &pk, const DevStars &st, const 
         if (e != hipSuccess) return e;
     }
     const int W = td.n_walkers, NN = (1 << td.depth) - 1, NO = td.derive_mode == 2 ? 1 : (1 << td.depth);
-    const int writers = td.derive_mode == 2 ? 0 : W;
+    const int writers = W;                                   // (prologue: the step-table workgroups)
     const int n_derive = td.derive_mode == 0 ? 0 : W * NO * NN * NPOPS * derive_parts;
     const int heavy = td.levels > 0 ? W * NN * td.heavy_parts : 0;
     const int front = (writers + n_derive + heavy + 7) / 8 * 8;

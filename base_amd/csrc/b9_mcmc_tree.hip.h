@@ -240,6 +240,38 @@ __device__ __forceinline__ void tree_draw_z(const TreeDev &td, int w, unsigned l
     }
 }
 
+// ---- table role (prologue launch, one workgroup per walker): the block's step table (TreeDev::step_tab) ---------------------
+__device__ __forceinline__ void tree_table(const TreeDev &td, int w)
+{
+    const int tid = threadIdx.x, d = td.d, n_pairs = (d + 1) >> 1;
+    __shared__ double s_zc[64][12];
+    double *tab = td.step_tab + (size_t)w * td.tab_steps * B9_TREE_TAB_ROW;
+    const int wid = td.walker_ids[w];
+    for (int s0 = 0; s0 < td.tab_steps; s0 += 64) {
+        const int ns = td.tab_steps - s0 < 64 ? td.tab_steps - s0 : 64;
+        __syncthreads();
+        for (int e = tid; e < ns * (n_pairs + 1); e += 256) {
+            const int si = e / (n_pairs + 1), pj = e - si * (n_pairs + 1);
+            const unsigned long long sn = td.block_step0 + (unsigned)(s0 + si);
+            unsigned r[4];
+            philox4x32((unsigned)sn, (unsigned)(sn >> 32), (unsigned)wid, (unsigned)pj, td.k0, td.k1, r);
+            if (pj < n_pairs) {
+                const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+                const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+                s_zc[si][2 * pj] = rad * cos(ang);
+                s_zc[si][2 * pj + 1] = rad * sin(ang);
+            } else tab[(size_t)(s0 + si) * B9_TREE_TAB_ROW + 11] = log(u01(r[0], r[1]));     // draw index n_pairs: the accept test's u
+        }
+        __syncthreads();
+        for (int e = tid; e < ns * d; e += 256) {
+            const int si = e / d, t = e - si * d;
+            double delta = 0.0;
+            for (int j = 0; j < d; ++j) delta = delta + td.chol[t * d + j] * s_zc[si][j];      // j ascending, plain multiply-add
+            tab[(size_t)(s0 + si) * B9_TREE_TAB_ROW + t] = delta;
+        }
+    }
+}
+
 // ---- derivation role: candidate (outcome o2 of THIS launch's tree, node n2 of the next tree) -------------------------------
 // The state x after the previous launch's walk; the end state of outcome o2 = x plus the steps of this launch's tree that
 // o2 accepts (each an `s_par[free[i]] += sum_j chol[i][j] z_j`, j ascending, plain multiply-add -- the sequential
@@ -261,14 +293,24 @@ __device__ __forceinline__ void tree_derive(const DevPack &pk, const TreeDev &td
 #pragma unroll
         for (int n = 0; n < B9_TREE_MAX_NODES; ++n) cand_v[n + 1] = (tid < B9_NPARAM && n < NN) ? in[B9_TS_PROP + 12 * n + tid] : 0.0;
     }
+    const bool prologue = td.derive_mode == 2;
     double crow[11];
 #pragma unroll
-    for (int j = 0; j < 11; ++j) crow[j] = (tid < d && j < d) ? td.chol[tid * d + j] : 0.0;
+    for (int j = 0; j < 11; ++j) crow[j] = (prologue && tid < d && j < d) ? td.chol[tid * d + j] : 0.0;
     const int fidx = tid < d ? td.free_idx[tid] : 0;
-    // wave 3: the normals of this launch's tree (steps td.step ..) and of the next (td.next_step ..)
-    const bool prologue = td.derive_mode == 2;
-    if (!prologue) tree_draw_z(td, w, td.step, depth, s_z);
-    tree_draw_z(td, w, td.next_step, depth, s_z + B9_TREE_MAX_DEPTH);
+    // the steps' increments: table words (K launches; requested with everything else of the first round trip)
+    double dtab[2 * B9_TREE_MAX_DEPTH];
+    {
+        const double *tab = td.step_tab + (size_t)w * td.tab_steps * B9_TREE_TAB_ROW;
+        const long long r_cur = (long long)(td.step - td.block_step0), r_next = (long long)(td.next_step - td.block_step0);
+#pragma unroll
+        for (int i = 0; i < B9_TREE_MAX_DEPTH; ++i) {
+            dtab[i] = (!prologue && tid < d && i < depth) ? tab[(size_t)(r_cur + i) * B9_TREE_TAB_ROW + tid] : 0.0;
+            dtab[B9_TREE_MAX_DEPTH + i] = (!prologue && tid < d && i < depth) ? tab[(size_t)(r_next + i) * B9_TREE_TAB_ROW + tid] : 0.0;
+        }
+    }
+    // the prologue alone draws its tree's normals itself (wave 3): the block's table is being written by this same launch
+    if (prologue) tree_draw_z(td, w, td.next_step, depth, s_z + B9_TREE_MAX_DEPTH);
     if (first_wave) {
         const int last = tree_decide(td, w).last;
         if (tid == 0) s_last = last;
@@ -281,12 +323,12 @@ __device__ __forceinline__ void tree_derive(const DevPack &pk, const TreeDev &td
         for (int n = 0; n < B9_TREE_MAX_NODES; ++n) x = (last == n) ? +cand_v[n + 1] : x;
         if (tid < B9_NPARAM) s_par[tid] = x;
     }
-    // delta of every step: sum_j chol[i][j] z_j
+    // delta of every step: the table's (K launches), or sum_j chol[i][j] z_j formed here (prologue) -- the same operations
 #pragma unroll
     for (int si = 0; si < 2 * B9_TREE_MAX_DEPTH; ++si) {
-        const bool have = (si < B9_TREE_MAX_DEPTH) ? (!prologue && si < depth) : (si - B9_TREE_MAX_DEPTH < depth);
-        double delta = 0.0;
-        if (have) {
+        double delta = dtab[si];
+        if (prologue && si >= B9_TREE_MAX_DEPTH && si - B9_TREE_MAX_DEPTH < depth) {
+            delta = 0.0;
 #pragma unroll
             for (int j = 0; j < 11; ++j) if (j < d) delta = delta + crow[j] * s_z[si][j];
         }
@@ -363,12 +405,8 @@ __device__ __forceinline__ void tree_writer(const DevPack &pk, const TreeDev &td
             for (int k = 0; k < n_pops; ++k) pv = pv && td.cand_hdr[(cb + n) * n_pops + k].valid;
             out[B9_TS_LPRIOR + n] = pv ? log_prior_cluster(pr, s_prop[n], n_pops) : NEG_INF;
         }
-        if (tid >= 128 && tid < 128 + depth) {               // log u of level j's accept test (draw index n_pairs of its step)
-            const unsigned long long sn = td.step + (unsigned)(tid - 128);
-            unsigned r[4];
-            philox4x32((unsigned)sn, (unsigned)(sn >> 32), (unsigned)td.walker_ids[w], (unsigned)((d + 1) >> 1), td.k0, td.k1, r);
-            out[B9_TS_LOGU + (tid - 128)] = log(u01(r[0], r[1]));
-        }
+        if (tid >= 128 && tid < 128 + depth)                 // log u of level j's accept test: the block's step table
+            out[B9_TS_LOGU + (tid - 128)] = td.step_tab[((size_t)w * td.tab_steps + (size_t)(td.step - td.block_step0) + (tid - 128)) * B9_TREE_TAB_ROW + 11];
     }
     // chain rows of the previous launch's steps: the state after each of its levels
     for (int j = 1; j <= lv; ++j) {
@@ -387,23 +425,39 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS))
 void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int tiles_per_block, int n_front, int derive_parts)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef B9_GANTT
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+#endif
     const int W = td.n_walkers, NN = (1 << td.depth) - 1, NO = td.derive_mode == 2 ? 1 : (1 << td.depth);
-    int b = blockIdx.x;
-    if (b >= n_front) { tree_hot<NFP, NPOPS>(pk, st, td, b - n_front, tiles_per_block, smem); return; }
-    const int n_writers = td.derive_mode == 2 ? 0 : W;       // (the prologue has no tree to take a decision on)
-    if (b < n_writers) { tree_writer(pk, td, pr, b, nullptr); return; }
-    b -= n_writers;
+    int b = blockIdx.x, role = 3;                            // 0 hot, 1 heavy, 2 derivation, 3 padding, 4 writer (tools/gantt_step.py)
+    const int n_writers = W;                                 // (the prologue has no tree to take a decision on: its "writers" write the block's step table)
     const int n_derive = td.derive_mode == 0 ? 0 : W * NO * NN * NPOPS * derive_parts;
-    if (b < n_derive) {          // b = (((w * NO + o2) * NN + n2) * NPOPS + pop) * parts + part
+    if (b >= n_front) { role = 0; tree_hot<NFP, NPOPS>(pk, st, td, b - n_front, tiles_per_block, smem); }
+    else if (b < n_writers) { role = 4; if (td.derive_mode == 2) tree_table(td, b); else tree_writer(pk, td, pr, b, nullptr); }
+    else if (b - n_writers < n_derive) {          // b = (((w * NO + o2) * NN + n2) * NPOPS + pop) * parts + part
+        role = 2;
+        b -= n_writers;
         const int part = b % derive_parts; b /= derive_parts;
         const int pop = b % NPOPS; b /= NPOPS;
         const int n2 = b % NN; b /= NN;
         const int o2 = b % NO; b /= NO;
         tree_derive(pk, td, b, o2, n2, pop, part, derive_parts);
-        return;
+    } else if (td.levels > 0 && b - n_writers - n_derive < W * NN * td.heavy_parts) {
+        role = 1;
+        tree_heavy<NFP, NPOPS>(pk, st, td, b - n_writers - n_derive, smem);
     }
-    b -= n_derive;
-    if (td.levels > 0 && b < W * NN * td.heavy_parts) tree_heavy<NFP, NPOPS>(pk, st, td, b, smem);
+#ifdef B9_GANTT
+    __syncthreads();          // the workgroup's last wave
+    if (threadIdx.x == 0 && blockIdx.x < B9_GANTT_WG) {
+        const unsigned long long launch = td.step / (unsigned)td.depth;
+        unsigned long long *g = g_gantt + ((launch & 7ull) * B9_GANTT_WG + blockIdx.x) * 4;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g[0] = t_in; g[1] = __builtin_amdgcn_s_memrealtime(); g[2] = (unsigned long long)role | ((unsigned long long)(xcc & 15u) << 8); g[3] = launch;
+    }
+#else
+    (void)role;
+#endif
 }
 
 // the block's last walk: one workgroup per walker, writer role only (+ the block's summary rows, the host mirror)
