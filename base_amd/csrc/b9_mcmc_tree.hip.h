@@ -485,7 +485,15 @@ __global__ __launch_bounds__(256) void k_tree_begin(const double *__restrict__ h
                                                     const double *__restrict__ prev_final, double *__restrict__ state, int n_walkers)
 {
     const int tid = threadIdx.x;
-    for (int i = tid; i < up_words; i += 256) dev[i] = host_up[i];
+    // (the source is HOST memory: four words per thread are requested together -- one PCIe round trip for up to 1024 words,
+    //  not one per loop iteration)
+    for (int i0 = 0; i0 < up_words; i0 += 1024) {
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + tid + 256 * k; v[k] = host_up[i < up_words ? i : up_words - 1]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + tid + 256 * k; if (i < up_words) dev[i] = v[k]; }
+    }
     if (!prev_final) return;
     __syncthreads();
     for (int w = 0; w < n_walkers; ++w) {

@@ -4,6 +4,7 @@
 #include "../../include/base9_host.h"
 #include "b9host.hpp"
 #include "b9sampler.hpp"
+#include "cli_common.hpp"
 
 #include <hip/hip_runtime_api.h>
 
@@ -64,6 +65,11 @@ int b9h_settings_dump(int argc, char **argv, char *out, int cap)
         std::strncpy(out, d.c_str(), (size_t)cap - 1);
         out[cap - 1] = '\0';
     });
+}
+
+int b9h_merge_parts(const char *final_path, int world, int walkers_per_rank, long rows_per_part)
+{
+    return guard([&] { b9h::merge_result_parts(final_path, world, walkers_per_rank, rows_per_part); });
 }
 
 // ---- ranks, exchange ---------------------------------------------------------------------------------------------

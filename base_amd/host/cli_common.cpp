@@ -251,6 +251,47 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
     return true;
 }
 
+void merge_result_parts(const std::string &final_path, int world, int per, long rows_per_part)
+{
+    // Interleave the parts in walker order.  Nothing is deleted unless the merged file was written completely: every
+    // part must deliver exactly the rows its rank wrote (the same count on every rank), and every write is checked.
+    std::vector<std::ifstream> parts;
+    for (int r = 0; r < world; ++r) {
+        parts.emplace_back(final_path + ".part" + std::to_string(r));
+        if (!parts.back()) throw std::runtime_error("cannot read " + final_path + ".part" + std::to_string(r));
+    }
+    std::ofstream fin(final_path);
+    if (!fin) throw std::runtime_error("cannot write " + final_path + " (the part files are kept)");
+    std::string line;
+    for (int r = 0; r < world; ++r)              // leading comment lines and the column header: part 0's
+        while (std::getline(parts[r], line)) {
+            if (r == 0) fin << line << "\n";
+            if (line.empty() || line[0] != '#') break;
+        }
+    std::vector<long> got(world, 0);
+    for (bool more = true; more;)
+        for (int r = 0; r < world && more; ++r)
+            for (int w = 0; w < per; ++w) {
+                if (!std::getline(parts[r], line)) { more = false; break; }
+                fin << line << "\n";
+                ++got[r];
+            }
+    for (int r = 0; r < world; ++r) {
+        while (std::getline(parts[r], line)) ++got[r];               // anything left over is a mismatch too
+        if (got[r] != rows_per_part) {
+            fin.close();
+            std::remove(final_path.c_str());                          // no half-merged file is left behind
+            throw std::runtime_error(final_path + ".part" + std::to_string(r) + " holds " + std::to_string(got[r]) + " rows, expected " +
+                                     std::to_string(rows_per_part) + " (truncated or mismatched part; the part files are kept)");
+        }
+    }
+    fin.flush();
+    if (!fin) throw std::runtime_error("writing " + final_path + " failed (disk full?); the part files are kept");
+    fin.close();
+    parts.clear();
+    for (int r = 0; r < world; ++r) std::remove((final_path + ".part" + std::to_string(r)).c_str());
+}
+
 McmcResult run_mcmc(Session &s, Exchange &ex, const std::vector<std::string> &columns)
 {
     const McmcConfig &cfg = s.mcmc;
@@ -307,43 +348,7 @@ McmcResult run_mcmc(Session &s, Exchange &ex, const std::vector<std::string> &co
     out.reset();
     if (parts_route) {
         ex.barrier();                                 // every part file is complete
-        if (ex.rank() == 0) {
-            // Interleave the parts in walker order.  Nothing is deleted unless the merged file was written completely: every
-            // part must deliver exactly the rows its rank wrote (the same count on every rank), and every write is checked.
-            const int world = ex.world();
-            std::vector<std::ifstream> parts;
-            for (int r = 0; r < world; ++r) {
-                parts.emplace_back(final_path + ".part" + std::to_string(r));
-                if (!parts.back()) throw std::runtime_error("cannot read " + final_path + ".part" + std::to_string(r));
-            }
-            std::ofstream fin(final_path);
-            if (!fin) throw std::runtime_error("cannot write " + final_path + " (the part files are kept)");
-            std::string line;
-            for (int r = 0; r < world; ++r)              // leading comment lines and the column header: part 0's
-                while (std::getline(parts[r], line)) {
-                    if (r == 0) fin << line << "\n";
-                    if (line.empty() || line[0] != '#') break;
-                }
-            std::vector<long> got(world, 0);
-            for (bool more = true; more;)
-                for (int r = 0; r < world && more; ++r)
-                    for (int w = 0; w < per; ++w) {
-                        if (!std::getline(parts[r], line)) { more = false; break; }
-                        fin << line << "\n";
-                        ++got[r];
-                    }
-            for (int r = 0; r < world; ++r) {
-                if (std::getline(parts[r], line)) ++got[r];                  // anything left over is a mismatch too
-                if (got[r] != rows_written)
-                    throw std::runtime_error(final_path + ".part" + std::to_string(r) + " holds " + std::to_string(got[r]) + " rows, expected " +
-                                             std::to_string(rows_written) + " (truncated or mismatched part; the part files are kept)");
-            }
-            fin.flush();
-            if (!fin) throw std::runtime_error("writing " + final_path + " failed (disk full?); the part files are kept");
-            fin.close();
-            parts.clear();
-            for (int r = 0; r < world; ++r) std::remove((final_path + ".part" + std::to_string(r)).c_str());
-        }
+        if (ex.rank() == 0) merge_result_parts(final_path, ex.world(), per, rows_written);
         ex.barrier();
     }
     return res;

@@ -49,6 +49,12 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code);
 // rank writes a part file and rank 0 merges them into <output_base>.res.
 McmcResult run_mcmc(Session &s, Exchange &exchange, const std::vector<std::string> &columns);
 
+// Rank 0's merge of <final_path>.part<r>, r < world (each `rows_per_part` data rows, `per` walkers per step and rank), into
+// <final_path>: comment + header of part 0, then the steps' rows in walker order.  Throws -- keeping every part file and
+// leaving no merged file -- when a part is short, long or unreadable, or the output cannot be written; removes the parts
+// only after the merged file is complete.
+void merge_result_parts(const std::string &final_path, int world, int per, long rows_per_part);
+
 int report_and_exit_code(const char *prog, const std::exception &e);
 
 }  // namespace b9h

@@ -34,7 +34,7 @@ HOST_SYMBOLS = [
     "b9h_forced_ranks", "b9h_test_stall",
     "b9h_sampler_create", "b9h_sampler_create_callback", "b9h_sampler_free", "b9h_sampler_initialise", "b9h_sampler_run",
     "b9h_sampler_n_local", "b9h_sampler_state", "b9h_summary_rows",
-    "b9h_load_pack", "b9h_free_pack", "b9h_read_phot", "b9h_free_phot", "b9h_settings_dump",
+    "b9h_load_pack", "b9h_free_pack", "b9h_read_phot", "b9h_free_phot", "b9h_settings_dump", "b9h_merge_parts",
 ]
 
 _lib = None
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
     lib.b9h_read_phot.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_int, C.POINTER(vp), C.POINTER(abi.b9_stars), C.c_char_p, C.c_int]
     lib.b9h_free_phot.argtypes = [vp]
     lib.b9h_settings_dump.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
+    lib.b9h_merge_parts.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_long]
     _lib = lib
     return lib
 

@@ -77,6 +77,8 @@ int b9h_read_phot(const char *path, double min_mag, double max_mag, int index, v
                   char *filters_out, int filters_cap);
 void b9h_free_phot(void *handle);
 int b9h_settings_dump(int argc, char **argv, char *out, int cap);
+/* rank 0's merge of <final_path>.part<r> into <final_path> after a --gpus N run (b9h::merge_result_parts; exposed for tests) */
+int b9h_merge_parts(const char *final_path, int world, int walkers_per_rank, long rows_per_part);
 
 #ifdef __cplusplus
 }

@@ -99,3 +99,53 @@ def test_useful_operation_model():
     assert ops["search_rounds"] == 3 and ops["single"] < ops["binary"]
     assert abs(ops["mean"] - (0.7 * ops["single"] + 0.3 * ops["binary"])) < 1e-9
     assert bench.useful_lane_ops(8, 400, 0.3, n_pops=2)["single"] > ops["single"]
+
+
+def _write_part(path, n_rows, first_walker, per, comment=True):
+    with open(path, "w") as f:
+        if comment:
+            f.write("# base9_hip ABI 3; mode=givenMass; populations=1; walkers=4\n")
+        f.write("      logAge      logPost stage\n")
+        for k in range(n_rows):
+            f.write(f"{9.0 + 0.001 * (k // per):12.6f} {-100.0 - (first_walker + k % per):14.6f} {3:5d}\n")
+
+
+def test_part_file_merge_is_checked(tmp_path):
+    """Rank 0's merge after a --gpus N run: rows interleaved in walker order; a truncated part or an unwritable
+    output is an ERROR that keeps every part file and leaves no half-merged .res behind."""
+    from base_amd import hostlib
+    lib = hostlib.load()
+    base = str(tmp_path / "run.res")
+    per, steps = 2, 5
+    for r in range(2):
+        _write_part(f"{base}.part{r}", per * steps, r * per, per)
+    assert lib.b9h_merge_parts(base.encode(), 2, per, per * steps) == 0
+    lines = open(base).read().splitlines()
+    assert lines[0].startswith("# base9_hip ABI 3") and lines[1].split()[0] == "logAge" and len(lines) == 2 + 2 * per * steps
+    walkers = [int(round(-float(ln.split()[1]) - 100.0)) for ln in lines[2:]]
+    assert walkers == [0, 1, 2, 3] * steps                      # walker order within every step
+    assert not os.path.exists(base + ".part0") and not os.path.exists(base + ".part1")
+    # a truncated part: error, parts kept, no merged file
+    os.unlink(base)
+    _write_part(f"{base}.part0", per * steps, 0, per)
+    _write_part(f"{base}.part1", per * steps - 3, per, per)
+    assert lib.b9h_merge_parts(base.encode(), 2, per, per * steps) != 0
+    assert b"part1 holds 7 rows, expected 10" in lib.b9h_last_error()
+    assert os.path.exists(base + ".part0") and os.path.exists(base + ".part1") and not os.path.exists(base)
+    # a part with rows left over
+    _write_part(f"{base}.part1", per * steps + 2, per, per)
+    assert lib.b9h_merge_parts(base.encode(), 2, per, per * steps) != 0
+    assert os.path.exists(base + ".part0") and not os.path.exists(base)
+    # an output that cannot be written
+    _write_part(f"{base}.part1", per * steps, per, per)
+    bad = str(tmp_path / "no_such_dir" / "run.res")
+    os.makedirs(os.path.dirname(bad))
+    for r in range(2):
+        os.replace(f"{base}.part{r}", f"{bad}.part{r}")
+    os.chmod(os.path.dirname(bad), 0o500)
+    try:
+        if os.geteuid() != 0:                                     # (root writes anywhere)
+            assert lib.b9h_merge_parts(bad.encode(), 2, per, per * steps) != 0
+            assert os.path.exists(bad + ".part0") and os.path.exists(bad + ".part1")
+    finally:
+        os.chmod(os.path.dirname(bad), 0o700)
