@@ -171,10 +171,10 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
 
 // nodes of the companion table per (walker, population, mass ratio, filter): whole 64-node chunks of the longest isochrone
 int b9k_marg_table_npad(int mass_cap, int K) { return (((mass_cap - 1) * K + 63) / 64) * 64; }
-// doubles of one (walker, population)'s table: (Q - 1) NFP companion planes + NFP magnitude + NFP flux planes + the log weights
+// doubles of one (walker, population)'s table: (Q - 1) NFP combined-magnitude planes + NFP primary-magnitude planes + the log weights
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q)
 {
-    return ((long long)(Q - 1) * nfp + 2LL * nfp + 1) * b9k_marg_table_npad(mass_cap, K);
+    return ((long long)(Q - 1) * nfp + nfp + 1) * b9k_marg_table_npad(mass_cap, K);
 }
 
 template <int NFP, int NPOPS, bool SAMPLE>

@@ -15,12 +15,12 @@
 // magnitude rows) and the chunk-bound table are staged in LDS ONCE per workgroup; its four waves then walk
 // the star slots in strides of the launch's wave count (each wave on its own: no workgroup barrier after
 // the staging).  Lane = primary-mass node of a 64-node chunk.  NOTHING about a node depends on the star: its primary
-// magnitudes and fluxes, its log(prior dM / n_q), and -- per mass ratio j / n_q -- its companion's fluxes are tabulated
-// once per call (k_marg_table; L2-resident: the workgroups of a walker share an XCD).  A star's work is then, per node,
-// the chi^2 of the single star (j = 0) and, per companion, one add and one logarithm per filter: -2.5 log10(F1 + F2).
+// magnitudes, its log(prior dM / n_q), and -- per mass ratio j / n_q -- the COMBINED magnitudes of the node with that
+// companion are tabulated once per call (k_marg_table; L2-resident: the workgroups of a walker share an XCD).  A star's
+// work is then nothing but chi^2 sums: per node the single star's (j = 0) and one per companion.
 // (Round 2's kernel re-derived all of that per star: bracket searches, interpolations, an exponential and a logarithm per
-// flux combine -- 9090 VALU wave-instructions per star-eval against 4.5k now; its LDS rows at a 64-byte stride were 4-way
-// bank-conflicted, a padded stride removed the conflicts without moving the time, and the rows then left LDS altogether.)
+// flux combine -- 9090 VALU wave-instructions per star-eval; its LDS rows at a 64-byte stride were 4-way bank-conflicted,
+// a padded stride removed the conflicts without moving the time, and the rows then left LDS altogether.)
 // A star of stage WD integrates over (AGB tip, M_wd_up] in 8 iso_increm steps through the WD branch: those stars (a few
 // per cent of a cluster, listed at load time: DevStars::wd_slot) have a kernel of their own, k_star_marg_wd, so that
 // the WD branch's registers (it alone wants > 200 VGPRs) do not set the occupancy of every other star's evaluation.
@@ -104,7 +104,7 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // Waves per SIMD the instances are built for (tools/kernel_resources.py; every instance at <= 16 B of scratch per lane).
 #ifndef B9_MARG_WAVES
-#define B9_MARG_WAVES(NFP, NPOPS, SAMPLE) (((NFP) >= 16 && (NPOPS) == 2 && (SAMPLE)) ? 1 : (((NFP) >= 16 || (SAMPLE) || ((NPOPS) == 2 && (NFP) >= 8)) ? 2 : 3))
+#define B9_MARG_WAVES(NFP, NPOPS, SAMPLE) (((NFP) >= 16 || (SAMPLE)) ? 2 : 3)
 #endif
 
 // doubles of per-wave LDS scratch: the star's shift / obs / weight per filter
@@ -253,11 +253,10 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
 #pragma unroll
         for (int kp = 0; kp < NPOPS; ++kp) {
             const double *const mass = lds_mass[kp];
-            // this (walker, population)'s table: companions [(j - 1) NFP + f][npad], then per node the primary's magnitudes
-            // [f][npad], fluxes [f][npad] and log(prior dM / Q) [npad]
+            // this (walker, population)'s table: the COMBINED magnitudes of (node, companion j) [(j - 1) NFP + f][npad], then per
+            // node the primary's magnitudes [f][npad] and log(prior dM / Q) [npad]
             const double *const tab_wp = tab + (size_t)(w * NPOPS + kp) * tab_stride;
-            const double *const tab_p1 = tab_wp + (size_t)(Q - 1) * NFP * npad, *const tab_f1 = tab_p1 + (size_t)NFP * npad,
-                         *const tab_base = tab_f1 + (size_t)NFP * npad;
+            const double *const tab_p1 = tab_wp + (size_t)(Q - 1) * NFP * npad, *const tab_base = tab_p1 + (size_t)NFP * npad;
             const int n_eep = iso_g[kp].n;
             const double tip = iso_g[kp].tip;
             Lse acc; acc.mx = NEG_INF; acc.sm = 0.0;
@@ -361,11 +360,6 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                         chi0 = fma(wdd, dd, chi0);
                         chi_lb = dd < 0.0 ? fma(wdd, dd, chi_lb) : chi_lb;
                     }
-                    // the primary's fluxes (for the companions below): requested now that the magnitudes' registers are free,
-                    // in flight across the tests and the single-star term
-                    double F1[NFP];
-#pragma unroll
-                    for (int f = 0; f < NFP; ++f) F1[f] = tab_f1[(size_t)f * npad + pnode];
                     // with the bound bmax on this node's (prior + weight) nothing of it can matter: skip
                     const double cut_ub = 2.0 * ((bmax[kp] - wmx) + B9_MARG_CUT);
                     live = live && !(chi_lb > cut_ub);                           // chi0 >= chi_lb
@@ -381,36 +375,32 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                     const unsigned long long wmask = __ballot(want);
                     if (wmask == 0ull || Q < 2) continue;                        // (A) for the whole wave
                     MSTAT(3, 1); MSTAT(6, __popcll(wmask));
-                    // ---- companions: a (node, j, filter) costs one add and one logarithm: -2.5 log10(F1 + F2), both fluxes table
-                    // words.  The NFP words of a mass ratio are requested together, one mass ratio ahead of their use.
+                    // ---- companions: the combined magnitude of (node, mass ratio j, filter) does not depend on the star either:
+                    // a table word.  What is left per star is the chi^2.
                     const double *tp = tab_wp + pnode;
-                    double F2[NFP];
+                    {
+                        // (no look-ahead of the next mass ratio's words: measured 2.39 -> 2.23 ms per call without -- its
+                        //  registers cost more than the latency it hid; 16 filters go eight at a time)
+                        constexpr int FB = NFP < 8 ? NFP : 8;
+                        for (int j = 1; j < Q; ++j) {
+                            double chi2 = want ? 0.0 : __builtin_inf();
+                            MSTAT(4, 1);
+#pragma unroll 1
+                            for (int f0 = 0; f0 < NFP; f0 += FB) {
+                                double C8[FB];
 #pragma unroll
-                    for (int f = 0; f < NFP; ++f) F2[f] = tp[(size_t)f * npad];
-                    for (int j = 1; j < Q; ++j) {
-                        const int jn = j + 1 < Q ? j : j - 1;                   // (the last iteration re-requests its own words)
-                        double F2n[NFP];
+                                for (int f = 0; f < FB; ++f) C8[f] = tp[((size_t)(j - 1) * NFP + f0 + f) * npad];
 #pragma unroll
-                        for (int f = 0; f < NFP; ++f) F2n[f] = tp[((size_t)jn * NFP + f) * npad];
-                        double chi2 = want ? 0.0 : __builtin_inf();
-                        bool done = false;
-                        MSTAT(4, 1);
-#pragma unroll
-                        for (int f = 0; f < NFP; ++f) {
-                            if (!done) {
-                                MSTAT(5, 1);
-                                const double pc = (-2.5 / LN10) * log_pos(F1[f] + F2[f]);
-                                const double dd = (pc + s_shift[f]) - s_obs[f];
-                                chi2 = fma(s_wgt[f] * dd, dd, chi2);
-                                done = (__ballot(chi2 <= cut) == 0ull);          // (B): uniform across the wave
+                                for (int f = 0; f < FB; ++f) {
+                                    const double dd = (C8[f] + s_shift[f0 + f]) - s_obs[f0 + f];
+                                    chi2 = fma(s_wgt[f0 + f] * dd, dd, chi2);
+                                }
+                            }
+                            if (want && isfinite(chi2) && chi2 <= cut) {
+                                lse_add(acc, base - 0.5 * chi2);
+                                B9_SAMPLE_NODE(base - 0.5 * chi2, (long long)pnode * Q + j, m1, (double)j / (double)Q)
                             }
                         }
-                        if (want && !done && isfinite(chi2) && chi2 <= cut) {
-                            lse_add(acc, base - 0.5 * chi2);
-                            B9_SAMPLE_NODE(base - 0.5 * chi2, (long long)pnode * Q + j, m1, (double)j / (double)Q)
-                        }
-#pragma unroll
-                        for (int f = 0; f < NFP; ++f) F2[f] = F2n[f];
                     }
                 }
             }
@@ -452,12 +442,11 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
 }
 
 // ------------------------------------------------------------------------------------------
-// k_marg_table: the companions' fluxes of one call.  For walker-population wp, primary node n (EEP interval n / K,
+// k_marg_table: one call's node table.  For walker-population wp, primary node n (EEP interval n / K,
 // sub-step n % K: the primary mass the main kernel forms, same operations) and mass ratio j / Q, j = 1 .. Q-1:
-// secondary mass m2 = (j / Q) m1, bracket + linear interpolation of the derived isochrone's rows (below the
-// isochrone's first point: no flux, magnitude 99.999), and F2 = 10^(-0.4 magnitude) per filter.
-// And per node the primary itself: magnitudes, fluxes F1 = 10^(-0.4 magnitude), log(prior(m1) dM / Q) (-inf: no such node).
-// Layout tab[wp]: [(j - 1) * NFP + f][npad] companions, [f][npad] magnitudes, [f][npad] fluxes, [npad] log weights
+// secondary mass m2 = (j / Q) m1, bracket + linear interpolation of the derived isochrone's rows, and the SYSTEM's combined
+// magnitude per filter.  And per node the primary itself: magnitudes, log(prior(m1) dM / Q) (-inf: no such node).
+// Layout tab[wp]: [(j - 1) * NFP + f][npad] combined magnitudes, [f][npad] primary magnitudes, [npad] log weights
 // (npad = whole 64-node chunks; nodes past the end hold 0 / -inf).
 // Grid: (walkers * pops, parts).
 // ------------------------------------------------------------------------------------------
@@ -475,35 +464,40 @@ __global__ __launch_bounds__(256) void k_marg_table(const IsoHdr *__restrict__ h
     __syncthreads();
     const int n_nodes = (h.n - 1) * K;
     double *out = tab + (size_t)wp * tab_stride;
+    // Every (node, mass ratio j >= 1): the system's combined magnitude per filter,
+    //     -2.5 log10(10^(-0.4 p1) + 10^(-0.4 p2)),   p1 / p2 = the primary's / companion's interpolated magnitudes
+    // (companion below the isochrone's first point: no flux, magnitude 99.999).
     for (int idx = blockIdx.y * 256 + tid; idx < npad * (Q - 1); idx += gridDim.y * 256) {
         const int jm1 = idx / npad, node = idx - jm1 * npad, j = jm1 + 1;
-        double F[NFP];
+        double C[NFP];
 #pragma unroll
-        for (int f = 0; f < NFP; ++f) F[f] = 0.0;
+        for (int f = 0; f < NFP; ++f) C[f] = 0.0;
         if (node < n_nodes) {
             const int e = node / K, s = node - e * K;
             const double a = s_mass[e], d = s_mass[e + 1] - a;
             if (d > 0.0) {
                 const double dM = d / K;
                 const double m1 = fma((double)s, dM, a);
+                const double t1 = (m1 - a) / d;
+                const double *r0 = g_mags + (size_t)e * NFP;
                 const double m2 = ((double)j / (double)Q) * m1;
-                if (m2 < s_mass[0]) {
+                const bool dark2 = m2 < s_mass[0];
+                int lo2; double t2;
+                find_bracket(s_mass, h.n, m2, lo2, t2);
+                const double *r2 = g_mags + (size_t)lo2 * NFP;
 #pragma unroll
-                    for (int f = 0; f < NFP; ++f) F[f] = exp_fast((-0.4 * LN10) * B9_MAG_NOFLUX);
-                } else {
-                    int lo2; double t2;
-                    find_bracket(s_mass, h.n, m2, lo2, t2);
-                    const double *r = g_mags + (size_t)lo2 * NFP;
-#pragma unroll
-                    for (int f = 0; f < NFP; ++f) F[f] = exp_fast((-0.4 * LN10) * lerp(r[f], r[NFP + f], t2));
+                for (int f = 0; f < NFP; ++f) {
+                    const double p1 = lerp(r0[f], r0[NFP + f], t1);
+                    const double p2 = dark2 ? B9_MAG_NOFLUX : lerp(r2[f], r2[NFP + f], t2);
+                    C[f] = (-2.5 / LN10) * log_pos(exp_fast((-0.4 * LN10) * p1) + exp_fast((-0.4 * LN10) * p2));
                 }
             }
         }
 #pragma unroll
-        for (int f = 0; f < NFP; ++f) out[((size_t)jm1 * NFP + f) * npad + node] = F[f];
+        for (int f = 0; f < NFP; ++f) out[((size_t)jm1 * NFP + f) * npad + node] = C[f];
     }
-    // the primaries: magnitudes, fluxes, log(prior(m1) dM / Q) of every node (the operations the star kernel used to repeat per star)
-    double *p1 = out + (size_t)(Q - 1) * NFP * npad, *f1 = p1 + (size_t)NFP * npad, *bs = f1 + (size_t)NFP * npad;
+    // the primaries: magnitudes and log(prior(m1) dM / Q) of every node
+    double *p1o = out + (size_t)(Q - 1) * NFP * npad, *bs = p1o + (size_t)NFP * npad;
     for (int node = blockIdx.y * 256 + tid; node < npad; node += gridDim.y * 256) {
         double P[NFP], base = NEG_INF;
 #pragma unroll
@@ -520,7 +514,7 @@ __global__ __launch_bounds__(256) void k_marg_table(const IsoHdr *__restrict__ h
             if (d > 0.0) base = log_prior_mass_dev(lmn, m1) + log_pos(dM / Q);
         }
 #pragma unroll
-        for (int f = 0; f < NFP; ++f) { p1[(size_t)f * npad + node] = P[f]; f1[(size_t)f * npad + node] = exp_fast((-0.4 * LN10) * P[f]); }
+        for (int f = 0; f < NFP; ++f) p1o[(size_t)f * npad + node] = P[f];
         bs[node] = base;
     }
 }
