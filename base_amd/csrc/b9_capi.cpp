@@ -216,10 +216,10 @@ int build_stars(b9_ctx *ctx)
             double sig = h.sigma[(size_t)s * nf + f];
             // an unused filter (sigma <= 0) carries weight 0; its observation is stored as 0 so that whatever the
             // file holds there (99.999, NaN, ...) cannot turn 0 * d * d into NaN
-            obs[(size_t)f * n_pad + i] = sig > 0.0 ? h.obs[(size_t)s * nf + f] : 0.0;
+            obs[B9_SIDX(nfp, f, i)] = sig > 0.0 ? h.obs[(size_t)s * nf + f] : 0.0;
             if (sig > 0.0) {
                 double var = sig * sig;
-                w[(size_t)f * n_pad + i] = 1.0 / var;
+                w[B9_SIDX(nfp, f, i)] = 1.0 / var;
                 g -= 0.5 * std::log(2.0 * M_PI * var);
             }
         }
@@ -249,7 +249,7 @@ int build_stars(b9_ctx *ctx)
     std::vector<int> hv_flags(hv_pad, 0), hv_perm(hv_pad, -1);
     for (int k = 0; k < n; ++k) {
         const int i = heavy_slot[k];
-        for (int f = 0; f < nfp; ++f) { hv_obs[(size_t)f * hv_pad + k] = obs[(size_t)f * n_pad + i]; hv_w[(size_t)f * hv_pad + k] = w[(size_t)f * n_pad + i]; }
+        for (int f = 0; f < nfp; ++f) { hv_obs[(size_t)f * hv_pad + k] = obs[B9_SIDX(nfp, f, i)]; hv_w[(size_t)f * hv_pad + k] = w[B9_SIDX(nfp, f, i)]; }
         hv_q[k] = q[i]; hv_c0[k] = c0[i]; hv_la[k] = la[i]; hv_flags[k] = flags[i]; hv_perm[k] = permp[i];
     }
     DevStars st{};

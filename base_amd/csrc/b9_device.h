@@ -48,8 +48,12 @@ struct DevPack {
 // padded to whole 256-star tiles.  Empty slots have mass1 = +inf and perm = -1.
 struct DevStars {
     int n, n_pad;                    // real stars / slots
-    const double *obs;               // [nfp][n_pad]
-    const double *w;                 // [nfp][n_pad]  1/sigma^2, 0 = filter unused
+    // Observations and weights, CHUNK-major: element (filter f, slot i) is at ((i >> 6) * nfp + f) * 64 + (i & 63) -- a wave's
+    // 64 stars of one filter are 512 contiguous bytes and a star's filters sit 512 bytes apart, so the hot role forms ONE
+    // address per array and star and reaches the filters through the loads' immediate offsets (with [nfp][n_pad] every one
+    // of its 16 loads needed its own 64-bit multiply-add: a tenth of the role's VALU instructions).  B9_SIDX(st, nfp, f, i).
+    const double *obs;               // [n_pad / 64][nfp][64]
+    const double *w;                 // [n_pad / 64][nfp][64]  1/sigma^2, 0 = filter unused
     const double *mass1, *q;         // [n_pad]
     const double *c0;                // [n_pad] log p + logPriorMass(mass1) + sum_f -0.5 log(2 pi sigma_f^2)
     const double *c0m;               // [n_pad] log p + sum_f -0.5 log(2 pi sigma_f^2)   (marginalised mode)
@@ -71,6 +75,8 @@ struct DevStars {
     int n_wd;
     const int *wd_slot;              // [max(1, n_wd)]
 };
+
+#define B9_SIDX(nfp, f, i) ((((size_t)((i) >> 6) * (nfp)) + (f)) * 64 + ((i) & 63))
 
 // Header of one derived isochrone (one per walker x population).
 struct IsoHdr {

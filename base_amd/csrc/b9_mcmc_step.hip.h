@@ -100,8 +100,8 @@ __device__ __forceinline__ void stage_tile(const DevStars &st, int slot0 /* firs
     if (lane < 32) {
 #pragma unroll
         for (int f = 0; f < NFP; ++f) {
-            __builtin_amdgcn_global_load_lds((gptr)(st.obs + (size_t)f * st.n_pad + slot0 + 2 * lane), (lptr)(dst + f * 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr)(st.w + (size_t)f * st.n_pad + slot0 + 2 * lane), (lptr)(dst + (NFP + f) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(st.obs + B9_SIDX(NFP, f, slot0) + 2 * lane), (lptr)(dst + f * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(st.w + B9_SIDX(NFP, f, slot0) + 2 * lane), (lptr)(dst + (NFP + f) * 64), 16, 0, 0);
         }
         __builtin_amdgcn_global_load_lds((gptr)(st.c0 + slot0 + 2 * lane), (lptr)(dst + 2 * NFP * 64), 16, 0, 0);
     }

@@ -453,8 +453,8 @@ __device__ __forceinline__ double chi2_system(const DevPack &pk, const WdAxes &a
 #pragma unroll
     for (int f = 0; f < NFP; ++f) {
         const double pred = p1[f] + (mod + pk.abs_m1[f] * av);
-        const double d = pred - st.obs[(size_t)f * st.n_pad + i];
-        chi2 = fma(st.w[(size_t)f * st.n_pad + i] * d, d, chi2);
+        const double d = pred - st.obs[B9_SIDX(NFP, f, i)];
+        chi2 = fma(st.w[B9_SIDX(NFP, f, i)] * d, d, chi2);
     }
     // a non-finite predicted magnitude (NaN or inf, also under a zero weight: 0 * inf = NaN)
     // leaves chi2 non-finite: the star is impossible under this isochrone

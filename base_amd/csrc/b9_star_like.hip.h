@@ -92,8 +92,8 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
             double o[4], wv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[j] = st.obs[(size_t)(4 * h + j) * st.n_pad + il];
-                wv[j] = st.w[(size_t)(4 * h + j) * st.n_pad + il];
+                o[j] = st.obs[B9_SIDX(NFP, 4 * h + j, il)];
+                wv[j] = st.w[B9_SIDX(NFP, 4 * h + j, il)];
             }
             double p[4];
             p[0] = dark1 ? B9_MAG_NOFLUX : lerp(a1[0].x, a1[2].x, t1);
@@ -163,8 +163,8 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         } else {
 #pragma unroll
             for (int f = 0; f < NFP; ++f) {
-                obs[f] = st.obs[(size_t)f * st.n_pad + il];
-                wgt[f] = st.w[(size_t)f * st.n_pad + il];
+                obs[f] = st.obs[B9_SIDX(NFP, f, il)];
+                wgt[f] = st.w[B9_SIDX(NFP, f, il)];
             }
             c0 = st.c0[il];
         }
@@ -532,8 +532,8 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevP
     double obs[NFP], wgt[NFP], c0;
 #pragma unroll
     for (int f = 0; f < NFP; ++f) {
-        obs[f] = st.obs[(size_t)f * st.n_pad + il];
-        wgt[f] = st.w[(size_t)f * st.n_pad + il];
+        obs[f] = st.obs[B9_SIDX(NFP, f, il)];
+        wgt[f] = st.w[B9_SIDX(NFP, f, il)];
     }
     c0 = st.c0[il];
 #endif
@@ -587,8 +587,8 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevP
 #ifndef B9_LATE_OBS
 #pragma unroll
             for (int f = 0; f < NFP; ++f) {
-                obs[f] = st.obs[(size_t)f * st.n_pad + il];
-                wgt[f] = st.w[(size_t)f * st.n_pad + il];
+                obs[f] = st.obs[B9_SIDX(NFP, f, il)];
+                wgt[f] = st.w[B9_SIDX(NFP, f, il)];
             }
             c0 = st.c0[il];
 #endif

@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
             for (int f = 0; f < NFP; ++f) sh = (lane == f) ? mod + pk.abs_m1[f] * av : sh;
             if (lane < NFP) {
                 s_shift[lane] = sh;
-                s_obs[lane] = st.obs[(size_t)lane * st.n_pad + slot];
-                s_wgt[lane] = st.w[(size_t)lane * st.n_pad + slot];
+                s_obs[lane] = st.obs[B9_SIDX(NFP, lane, slot)];
+                s_wgt[lane] = st.w[B9_SIDX(NFP, lane, slot)];
             }
         }
         const double c0m = st.c0m[slot], la = st.la[slot];
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
     double obs[NFP], wgt[NFP], shift[NFP];
     const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
 #pragma unroll
-    for (int f = 0; f < NFP; ++f) { obs[f] = st.obs[(size_t)f * st.n_pad + slot]; wgt[f] = st.w[(size_t)f * st.n_pad + slot]; shift[f] = mod + pk.abs_m1[f] * av; }
+    for (int f = 0; f < NFP; ++f) { obs[f] = st.obs[B9_SIDX(NFP, f, slot)]; wgt[f] = st.w[B9_SIDX(NFP, f, slot)]; shift[f] = mod + pk.abs_m1[f] * av; }
     const double c0m = st.c0m[slot], la = st.la[slot];
     const int wd_type = st.flags[slot] & 1;
     double ll[NPOPS];
