@@ -1253,7 +1253,7 @@ static int run_block_tree(b9_ctx *ctx, b9_mcmc_block *blk, const TreePlan &tp)
         double *const mirror = static_cast<double *>(sl.h_dev);
         td.host_state = zero_copy ? mirror + ((M & 1) ? o_st1 : o_st0) : nullptr;
         td.host_rows = (zero_copy && want_rows) ? mirror + o_rows : nullptr;
-        HIPCHK(ctx, b9k_tree_finish(ctx->pk, td, ctx->pr, s));
+        HIPCHK(ctx, b9k_tree_finish(td, ctx->pr, s));
         const bool rows_event = want_rows && (blk->flags & B9_BLOCK_ROWS_EVENT) != 0;
         if (rows_event) HIPCHK(ctx, hipEventRecord(sl.rows_ready, s));
         blk->d_rows = want_rows ? (void *)(dev + o_rows) : nullptr;

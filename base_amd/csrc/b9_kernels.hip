@@ -370,9 +370,9 @@ hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &t
 #undef MT2
 }
 
-hipError_t b9k_tree_finish(const DevPack &pk, const TreeDev &td, const DevPriors &pr, hipStream_t stream)
+hipError_t b9k_tree_finish(const TreeDev &td, const DevPriors &pr, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_tree_finish, dim3(td.n_walkers), dim3(256), 0, stream, pk, td, pr);
+    hipLaunchKernelGGL(k_tree_finish, dim3(td.n_walkers), dim3(256), 0, stream, td, pr);
     return hipGetLastError();
 }
 

@@ -64,7 +64,7 @@ hipError_t b9k_mcmc_finish(const DevPack &pk, const StepDev &sd, const DevPriors
 hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int tiles_per_block /* < 0: strided */,
                          int derive_parts, hipStream_t stream);
 hipError_t b9k_mcmc_tree_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu);
-hipError_t b9k_tree_finish(const DevPack &pk, const TreeDev &td, const DevPriors &pr, hipStream_t stream);
+hipError_t b9k_tree_finish(const TreeDev &td, const DevPriors &pr, hipStream_t stream);
 hipError_t b9k_tree_begin(const double *host_up, double *dev, int up_words, const double *prev_final, double *state, int n_walkers, hipStream_t stream);
 
 // summary rows of a two-launch block from its chain record on the device (sd: d, n_walkers, n_steps, samples, free_idx, row_origin, rows)

@@ -60,7 +60,7 @@ __device__ __forceinline__ bool tree_test(double lpr, double t, double logu, dou
 
 // The walk: per node, lane l adds the hot waves' partials l, l + 64, ... in order, then heavy-star partial l, then the
 // shuffle tree -- the same bits in every workgroup; then the sequential algorithm's tests, level by level.
-__device__ __forceinline__ TreeWalk tree_walk(const TreeDev &td, int w, const TreeLoads &tl)
+__device__ __forceinline__ TreeWalk tree_walk(const TreeDev &td, const TreeLoads &tl)
 {
     const int lane = threadIdx.x & 63, n_hot = 4 * td.n_groups;      // (the launch plan keeps n_hot <= 64 B9_TREE_KD)
     double T[B9_TREE_MAX_NODES];
@@ -123,7 +123,7 @@ __device__ __forceinline__ TreeWalk tree_decide(const TreeDev &td, int w)
 {
     TreeLoads tl;
     tree_issue(td, w, tl);
-    return tree_walk(td, w, tl);
+    return tree_walk(td, tl);
 }
 
 // index of candidate (walker w, outcome o of the previous launch, node n) in cand_par / cand_hdr / cand_iso of parity `set`
@@ -279,7 +279,7 @@ __device__ __forceinline__ void tree_table(const TreeDev &td, int w)
 // its own.  Nothing here waits for memory after the first round trip until the isochrone tables.
 __device__ __forceinline__ void tree_derive(const DevPack &pk, const TreeDev &td, int w, int o2, int n2, int pop, int part, int parts)
 {
-    const int tid = threadIdx.x, d = td.d, W = td.n_walkers, n_pops = td.n_pops, depth = td.depth;
+    const int tid = threadIdx.x, d = td.d, n_pops = td.n_pops, depth = td.depth;
     __shared__ double s_par[B9_NPARAM], s_z[2 * B9_TREE_MAX_DEPTH][12], s_delta[2 * B9_TREE_MAX_DEPTH][12];
     __shared__ int s_last;
     const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void tree_derive(const DevPack &pk, const TreeDev &td
 
 // ---- writer: the walk's result -- new state, chain rows of the previous launch's steps, and what the NEXT launch's walk
 // needs about the tree this launch evaluates (every node's proposal and log-prior, every level's log u) -----------------
-__device__ __forceinline__ void tree_writer(const DevPack &pk, const TreeDev &td, const DevPriors &pr, int w, double *s_state_out /* LDS [14] or null */)
+__device__ __forceinline__ void tree_writer(const TreeDev &td, const DevPriors &pr, int w, double *s_state_out /* LDS [14] or null */)
 {
     const int tid = threadIdx.x, d = td.d, W = td.n_walkers, n_pops = td.n_pops, depth = td.depth, NN = (1 << depth) - 1;
     __shared__ double s_lvl[B9_TREE_MAX_DEPTH + 1][B9_NPARAM];       // state after level j (0: before the walk)
@@ -433,7 +433,7 @@ void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int tiles_pe
     const int n_writers = W;                                 // (the prologue has no tree to take a decision on: its "writers" write the block's step table)
     const int n_derive = td.derive_mode == 0 ? 0 : W * NO * NN * NPOPS * derive_parts;
     if (b >= n_front) { role = 0; tree_hot<NFP, NPOPS>(pk, st, td, b - n_front, tiles_per_block, smem); }
-    else if (b < n_writers) { role = 4; if (td.derive_mode == 2) tree_table(td, b); else tree_writer(pk, td, pr, b, nullptr); }
+    else if (b < n_writers) { role = 4; if (td.derive_mode == 2) tree_table(td, b); else tree_writer(td, pr, b, nullptr); }
     else if (b - n_writers < n_derive) {          // b = (((w * NO + o2) * NN + n2) * NPOPS + pop) * parts + part
         role = 2;
         b -= n_writers;
@@ -461,10 +461,10 @@ void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int tiles_pe
 }
 
 // the block's last walk: one workgroup per walker, writer role only (+ the block's summary rows, the host mirror)
-__global__ __launch_bounds__(256) void k_tree_finish(DevPack pk, TreeDev td, DevPriors pr)
+__global__ __launch_bounds__(256) void k_tree_finish(TreeDev td, DevPriors pr)
 {
     __shared__ double s_last[B9_NPARAM + 2];
-    tree_writer(pk, td, pr, blockIdx.x, s_last);
+    tree_writer(td, pr, blockIdx.x, s_last);
     __syncthreads();
     if (td.rows) {
         StepDev sd{};
