@@ -119,12 +119,21 @@ int fail(b9_ctx *ctx, int code, const std::string &msg)
     return code;
 }
 
+// an enqueued sampler block owns the context's work buffers (candidate isochrones, partial sums) until it is collected
+bool block_outstanding(const b9_ctx *ctx);
+
 #define HIPCHK(ctx, call)                                                                     \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
         if (e_ != hipSuccess)                                                                 \
             return fail(ctx, B9_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
     } while (0)
+
+bool block_outstanding(const b9_ctx *ctx)
+{
+    for (const auto &sl : ctx->slot) if (sl.in_flight) return true;
+    return false;
+}
 
 template <class T>
 int upload(b9_ctx *ctx, std::vector<void *> &owner, const T *src, size_t count, const T **out)
@@ -607,6 +616,7 @@ const char *b9_last_error(const b9_ctx *ctx) { return ctx ? ctx->err.c_str() : g
 int b9_load_pack(b9_ctx *ctx, const b9_pack *p)
 {
     if (!ctx || !p) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (p->n_filt < 1 || p->n_filt > B9_MAX_FILT) return fail(ctx, B9_ERR_CAPACITY, "n_filt must be in [1, 16]");
     if (p->n_feh < 2 || p->n_age < 2 || p->n_y < 1) return fail(ctx, B9_ERR_INVALID, "grid needs >= 2 FeH and >= 2 ages");
@@ -734,6 +744,7 @@ int b9_load_pack(b9_ctx *ctx, const b9_pack *p)
 int b9_load_stars(b9_ctx *ctx, const b9_stars *s)
 {
     if (!ctx || !s) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     if (s->n_stars < 1 || s->n_filt < 1 || s->n_filt > B9_MAX_FILT) return fail(ctx, B9_ERR_INVALID, "bad star or filter count");
     if (!s->obs || !s->sigma || !s->mass1 || !s->mass_ratio || !s->clust_prior || !s->filter_prior_min || !s->filter_prior_max)
         return fail(ctx, B9_ERR_INVALID, "NULL pointer in stars");
@@ -796,6 +807,7 @@ int b9_set_tuning(b9_ctx *ctx, const b9_tuning *t)
 int b9_set_options(b9_ctx *ctx, const b9_options *o)
 {
     if (!ctx || !o) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     if (o->mode != B9_MODE_GIVEN_MASS && o->mode != B9_MODE_MARGINALISED) return fail(ctx, B9_ERR_INVALID, "unknown mode");
     if (o->n_pops != 1 && o->n_pops != 2) return fail(ctx, B9_ERR_INVALID, "n_pops must be 1 or 2");
     ctx->opt = *o;
@@ -902,6 +914,7 @@ int b9_logpost_device(b9_ctx *ctx, const double *d_params, int32_t n_walkers, do
                       double *d_perstar, void *stream_v)
 {
     if (!ctx || !d_params || !d_logpost || n_walkers < 1) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     int rc = check_ready(ctx);
     if (rc) return rc;
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
@@ -1404,6 +1417,9 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     for (int i = 0; i < d; ++i)
         if (blk->free_idx[i] < 0 || blk->free_idx[i] >= B9_NPARAM) return fail(ctx, B9_ERR_INVALID, "free_idx out of range");
     if (S == 0) { blk->n_accept = 0; return B9_OK; }
+    // (the work buffers are sized for the walker count: they must not be re-allocated under an enqueued block)
+    for (const auto &sl : ctx->slot)
+        if (sl.in_flight && sl.W != W) return fail(ctx, B9_ERR_STATE, "collect the outstanding block(s) before running a block with another number of walkers");
     const Plan plan = make_plan(ctx, W, n_pops);
     rc = ensure_capacity(ctx, W, n_pops, (size_t)ctx->st.n_pad * W, false);
     if (rc) return rc;
@@ -1433,6 +1449,7 @@ int b9_mcmc_wait(b9_ctx *ctx, b9_mcmc_block *blk)
 int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out_logpost, double *out_perstar)
 {
     if (!ctx || !params || !out_logpost || n_walkers < 1) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     int rc = check_ready(ctx);
     if (rc) return rc;
     const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
@@ -1468,6 +1485,7 @@ int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t s
                    double *out_mass, double *out_ratio, double *out_member, int32_t *out_pop)
 {
     if (!ctx || !params || n_rows < 1 || !out_mass || !out_ratio || !out_member) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     int rc = check_ready(ctx);
     if (rc) return rc;
     const int n_pops = ctx->opt.n_pops, n = ctx->st.n;
@@ -1516,6 +1534,7 @@ int b9_derive_isochrone(b9_ctx *ctx, const double *param_row, int32_t pop, int32
 {
     if (!ctx || !param_row || !out_mass || !out_mags || !out_first_eep || !out_n || !out_agb_tip) return B9_ERR_INVALID;
     if (!ctx->have_pack) return fail(ctx, B9_ERR_STATE, "load the pack first");
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = ensure_capacity(ctx, 1, 1, 1, false);
     if (rc) return rc;

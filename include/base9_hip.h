@@ -275,7 +275,9 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk);
  * blocks until it has run and fills params / logpost / samples / lps / n_accept.  B9_BLOCK_CONTINUE: the block
  * starts from the state the PREVIOUS block of this context left on the device (its params / logpost inputs are
  * ignored; n_walkers must match), so it can be enqueued before that block has finished.  At most two blocks
- * may be outstanding; they are collected in the order they were enqueued.  A driver that adapts the proposal
+ * may be outstanding; they are collected in the order they were enqueued.  While a block is outstanding it owns the
+ * context's work buffers: b9_logpost / b9_sample_mass / b9_derive_isochrone, the staging calls, b9_set_options and a block
+ * with another n_walkers return B9_ERR_STATE until it has been collected.  A driver that adapts the proposal
  * from block b-1 while block b runs keeps the GPU's queue non-empty: enqueue b+1 (CONTINUE | ASYNC), wait(b), ...
  */
 #define B9_BLOCK_CONTINUE 1

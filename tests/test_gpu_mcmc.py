@@ -212,3 +212,30 @@ def test_sampler_device_pipeline_equals_unpipelined(monkeypatch):
         out.append((s.params.copy(), s.logpost.copy(), s.chol.copy(), s.scale, s.accepted, s.step, np.concatenate([r[0] for r in rec])))
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+def test_an_outstanding_block_owns_the_work_buffers():
+    """While an asynchronous block is enqueued, calls that would overwrite or re-allocate the context's work buffers
+    (b9_logpost evaluates into the candidate isochrones the block is reading; a block with another walker count resizes
+    them) are refused with B9_ERR_STATE instead of corrupting the chain; after the block is collected they work again."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=3000, wd_frac=0.02, small=False, seed=3)
+    eng = engine.Engine(pack, stars, priors, options)
+    free = np.array(mcmc.DEFAULT_FREE)
+    start = synth.walker_params(cl["truth"], 4, seed=1, scale=0.05)
+    lp0 = eng.logpost(start)
+    chol = np.diag([mcmc.DEFAULT_STEP[int(k)] for k in free])
+    ref = eng.mcmc_run_block(start, lp0, np.arange(4), free, chol, 3, 0, 40)
+    h = eng.mcmc_submit(start, lp0, np.arange(4), free, chol, 3, 0, 40, record=True, asynchronous=True)
+    with pytest.raises(engine.B9Error) as e1:
+        eng.logpost(start)
+    assert e1.value.code == abi.B9_ERR_STATE
+    with pytest.raises(engine.B9Error):
+        eng.mcmc_submit(start[:2], lp0[:2], np.arange(2), free, chol, 3, 0, 5, record=False, asynchronous=True)
+    with pytest.raises(engine.B9Error):
+        eng.set_options(abi.make_options(abi.MODE_MARGINALISED, 1, 2, 2))
+    got = eng.mcmc_collect(h)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    np.testing.assert_array_equal(eng.logpost(start), lp0)
+    eng.close()
