@@ -504,6 +504,18 @@ TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
         if (ctx->derive_parts > 0) parts = std::min(ctx->derive_parts, full_parts);
         const bool fits = parts >= (d == 2 ? 2 : 1) && fixed + per_part * parts <= slots;
         if (!fits && ctx->tree_depth < 2) continue;          // (a pinned depth runs even when it takes several rounds)
+        if (ctx->tree_depth < 2) {
+            // Speculation only pays while the chip is under-filled: a depth-d launch evaluates 2^d - 1 nodes for d steps, so once the
+            // tiles of a launch saturate the CUs the one-step launch wins. Per-step estimate = (launch floor ~9 us + the larger of
+            // ~1.6 us per tile of the longest hot workgroup and ~2.2 us per tile per CU) / d; it reproduces the measured choices:
+            // 1 walker x 100k stars d = 3 (10.8 vs 15.4 us/step), x 200k d = 1 (17.4 vs 18.4), x 500k d = 1 (26.2 vs 38.7),
+            // 2 walkers x 50k d = 2 (8.4 vs 12.1), 1 x 10k d = 3 (4.4 vs 8.7).
+            const int tpb1 = make_step_plan(ctx, n_walkers, n_pops).plan.tiles_per_block;
+            const double per_cu = 2.2 * (double)n_walkers * n_tiles / std::max(1, ctx->n_cu);
+            const double est_tree = (9.0 + std::max(1.6 * tpb, per_cu * (double)NN)) / d;
+            const double est_step = 9.0 + std::max(1.6 * tpb1, per_cu);
+            if (est_tree >= est_step) continue;
+        }
         tp.depth = d; tp.tiles_per_block = tpb; tp.n_groups = n_groups; tp.derive_parts = std::max(1, parts);
         tp.strided = !ctx->contiguous_tiles;
         break;
