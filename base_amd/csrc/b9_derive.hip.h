@@ -161,6 +161,162 @@ __device__ __forceinline__ void derive_iso_block(const DevPack &pk, const double
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same derivation held in ONE WAVE's registers (the tree launch's derivation role, b9_mcmc_tree.hip.h): a wave
+// brackets all three axes itself, reads the corner rows itself and keeps the corner values of its share of the output
+// in registers, so the whole chain {axes} -> corner rows -> table values needs no workgroup barrier and can be run
+// AHEAD, for a guessed grid cell, while another wave still takes the step's decision.  Values and operation order are
+// derive_iso_block's (interp_corner): identical bits.
+// ------------------------------------------------------------------------------------------
+struct GridCell { int i_age, i_feh, i_y; };
+
+__device__ __forceinline__ void preload_axes3(const DevPack &pk, AxisRegs (&a)[3])
+{
+    const int lane = threadIdx.x & 63;
+    a[0].n = pk.n_age; a[1].n = pk.n_feh; a[2].n = pk.n_y;
+    a[0].v0 = lane < pk.n_age ? pk.log_age[lane] : __builtin_inf();
+    a[0].v1 = lane + 64 < pk.n_age ? pk.log_age[lane + 64] : __builtin_inf();
+    a[1].v0 = lane < pk.n_feh ? pk.feh[lane] : __builtin_inf();
+    a[1].v1 = lane + 64 < pk.n_feh ? pk.feh[lane + 64] : __builtin_inf();
+    a[2].v0 = lane < pk.n_y ? pk.y[lane] : __builtin_inf();
+    a[2].v1 = lane + 64 < pk.n_y ? pk.y[lane + 64] : __builtin_inf();
+}
+
+__device__ __forceinline__ GridCell grid_cell(const DevPack &pk, const AxisRegs (&a)[3], double log_age, double feh, double y)
+{
+    const int lane = threadIdx.x & 63;
+    GridCell g;
+    g.i_age = bracket_regs(a[0], pk.log_age, log_age, lane);
+    g.i_feh = bracket_regs(a[1], pk.feh, feh, lane);
+    g.i_y = pk.n_y > 1 ? bracket_regs(a[2], pk.y, y, lane) : 0;
+    return g;
+}
+
+__device__ __forceinline__ double wave_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ long long wave_bcast(long long v, int src)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+    return ((long long)hi << 32) | (long long)lo;
+}
+
+// a grid cell's corner rows and axis values, wave-uniform (what derive_iso_block keeps in `sc` / `sh`)
+struct CornerRegs {
+    long long off[8];       // point offset of EEP `lo` in each corner isochrone, index (dfeh * 2 + dy) * 2 + dage
+    int lo, n;              // first common EEP, common points (hi - lo: < 2 or > mass_cap = no isochrone)
+    double a_lo, a_hi, f_lo, f_hi, y_lo, y_hi, a_min, a_max, f_min, f_max, y_min, y_max;
+};
+
+__device__ __forceinline__ CornerRegs corner_rows(const DevPack &pk, const GridCell &g)
+{
+    const int lane = threadIdx.x & 63;
+    const int ny = pk.n_y > 1 ? 2 : 1;
+    const int df = (lane >> 2) & 1, dy = (lane >> 1) & 1, da = lane & 1;
+    const int dyc = dy < ny ? dy : 0;
+    const int kk = ((g.i_feh + df) * pk.n_y + (g.i_y + dyc)) * pk.n_age + g.i_age + da;
+    int f0 = -2147483647, f1 = 2147483647;
+    long long off = 0;
+    double ax0 = 0.0;
+    if (lane < 8) { f0 = pk.first[kk]; f1 = f0 + pk.cnt[kk]; off = pk.off[kk]; }
+    // lanes 8..19: the cell's axis values and the axes' ends (same round trip)
+    if (lane >= 8 && lane < 20) {
+        const int j = lane - 8, ax = (j >> 1) % 3, up = j & 1;
+        const double *base = ax == 0 ? pk.log_age : (ax == 1 ? pk.feh : pk.y);
+        const int n_ax = ax == 0 ? pk.n_age : (ax == 1 ? pk.n_feh : pk.n_y);
+        const int i_ax = ax == 0 ? g.i_age : (ax == 1 ? g.i_feh : g.i_y);
+        const int step = (ax == 2 && ny == 1) ? 0 : 1;
+        ax0 = base[j < 6 ? i_ax + (up ? step : 0) : (up ? n_ax - 1 : 0)];
+    }
+    int lo = f0, hi = f1;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 > lo ? l2 : lo;
+        hi = h2 < hi ? h2 : hi;
+    }
+    CornerRegs c;
+    c.lo = __builtin_amdgcn_readlane(lo, 0);
+    c.n = __builtin_amdgcn_readlane(hi, 0) - c.lo;
+    const long long adj = off + (c.lo - f0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.off[j] = wave_bcast(adj, j);
+    c.a_lo = wave_bcast(ax0, 8);  c.a_hi = wave_bcast(ax0, 9);
+    c.f_lo = wave_bcast(ax0, 10); c.f_hi = wave_bcast(ax0, 11);
+    c.y_lo = wave_bcast(ax0, 12); c.y_hi = wave_bcast(ax0, 13);
+    c.a_min = wave_bcast(ax0, 14); c.a_max = wave_bcast(ax0, 15);
+    c.f_min = wave_bcast(ax0, 16); c.f_max = wave_bcast(ax0, 17);
+    c.y_min = wave_bcast(ax0, 18); c.y_max = wave_bcast(ax0, 19);
+    return c;
+}
+
+// the isochrone's header for parameters (log_age, feh, y) in cell g (derive_iso_block's lane-0 block; agb_tip is left 0)
+__device__ __forceinline__ IsoHdr header_of(const DevPack &pk, const GridCell &g, const CornerRegs &c, double log_age, double feh,
+                                            double y, int mass_cap)
+{
+    IsoHdr h;
+    h.valid = 0; h.first_eep = 0; h.n = 0; h.i_feh = g.i_feh; h.i_y = g.i_y; h.i_age = g.i_age;
+    h.agb_tip = 0.0; h.t_feh = h.t_y = h.t_age = 0.0;
+    bool ok = (log_age >= c.a_min && log_age <= c.a_max) && (feh >= c.f_min && feh <= c.f_max) && pk.n_age >= 2 && pk.n_feh >= 2;
+    if (pk.n_y > 1) ok = ok && (y >= c.y_min && y <= c.y_max);
+    if (ok && c.n >= 2 && c.n <= mass_cap) {
+        h.t_age = (log_age - c.a_lo) / (c.a_hi - c.a_lo);
+        h.t_feh = (feh - c.f_lo) / (c.f_hi - c.f_lo);
+        if (pk.n_y > 1) h.t_y = (y - c.y_lo) / (c.y_hi - c.y_lo);
+        h.first_eep = c.lo; h.n = c.n; h.valid = 1;
+    }
+    return h;
+}
+
+// Corner values of KV output items of this thread: item = first + k * stride (< total), item -> (EEP, column) as in
+// derive_iso_block; column nfp = the mass.
+template <int KV>
+__device__ __forceinline__ void corner_values(const DevPack &pk, const CornerRegs &c, int total, int first, int stride, double (&v)[KV][8])
+{
+    const int nfp = pk.nfp, ny = pk.n_y > 1 ? 2 : 1;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int idx = first + k * stride;
+        const bool live = idx < total;
+        const int e = idx / (nfp + 1), col = idx - e * (nfp + 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[k][j] = 0.0;
+            if (((j >> 1) & 1) && ny == 1) continue;
+            const long long p = c.off[j] + e;
+            if (live && col == nfp) v[k][j] = pk.mass[p];
+            else if (live && col < pk.nf) v[k][j] = pk.mags[p * nfp + col];
+        }
+    }
+}
+
+// ... and their interpolation + store (interp_corner's order: age, then Y, then FeH)
+template <int KV>
+__device__ __forceinline__ void store_values(const DevPack &pk, const IsoHdr &h, int total, int first, int stride, const double (&v)[KV][8],
+                                             double *__restrict__ omass, double *__restrict__ omags, double *__restrict__ agb_tip)
+{
+    const int nfp = pk.nfp, ny = pk.n_y > 1 ? 2 : 1;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int idx = first + k * stride;
+        if (idx >= total) continue;
+        const int e = idx / (nfp + 1), col = idx - e * (nfp + 1);
+        double vf[2];
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+            const double v0 = lerp(v[k][df * 4 + 0], v[k][df * 4 + 1], h.t_age);
+            const double v1 = lerp(v[k][df * 4 + 2], v[k][df * 4 + 3], h.t_age);
+            vf[df] = (ny == 2) ? lerp(v0, v1, h.t_y) : v0;
+        }
+        const double out = lerp(vf[0], vf[1], h.t_feh);
+        if (col == nfp) { omass[e] = out; if (idx == total - 1) *agb_tip = out; }      // the last point's mass = the AGB-tip mass
+        else omags[(size_t)e * nfp + col] = (col < pk.nf) ? out : 0.0;
+    }
+}
+
 // k_derive_iso: grid = (walkers * pops, parts).  Every workgroup of a row re-derives the (cheap)
 // header and then produces its share of the values, so the table reads of one isochrone are a
 // single round trip spread over ~15 workgroups.

@@ -277,7 +277,7 @@ __device__ __forceinline__ void tree_table(const TreeDev &td, int w)
 // o2 accepts (each an `s_par[free[i]] += sum_j chol[i][j] z_j`, j ascending, plain multiply-add -- the sequential
 // algorithm's own update, so the same bits); node n2's proposal = that plus the next tree's accepted ancestors' steps and
 // its own.  Nothing here waits for memory after the first round trip until the isochrone tables.
-__device__ __forceinline__ void tree_derive(const DevPack &pk, const TreeDev &td, int w, int o2, int n2, int pop, int part, int parts)
+__device__ __forceinline__ void tree_derive_prologue(const DevPack &pk, const TreeDev &td, int w, int o2, int n2, int pop, int part, int parts)
 {
     const int tid = threadIdx.x, d = td.d, n_pops = td.n_pops, depth = td.depth;
     __shared__ double s_par[B9_NPARAM], s_z[2 * B9_TREE_MAX_DEPTH][12], s_delta[2 * B9_TREE_MAX_DEPTH][12];
@@ -416,6 +416,101 @@ __device__ __forceinline__ void tree_writer(const TreeDev &td, const DevPriors &
     if (s_state_out) {
         if (tid < B9_NPARAM) s_state_out[tid] = s_lvl[lv][tid];
         if (tid == 0) { s_state_out[B9_NPARAM] = tw_lp; s_state_out[B9_NPARAM + 1] = nacc_in + (double)tw_n_acc; }
+    }
+}
+
+// The K launches' derivation role.  The first wave takes the decision and forms the candidate's parameters (registers and
+// one LDS row; no barrier inside); the other three waves meanwhile run the derivation AHEAD for the grid cell of the
+// previous state (a candidate is that state plus at most 2 x depth steps: almost always the same cell) -- corner rows,
+// then the corner values of the workgroup's share, held in registers (b9_derive.hip.h) -- so that when the parameters
+// arrive only the interpolation and the stores remain.  A candidate in another cell repeats the two round trips for
+// its own cell: same values either way.  Measured on C1 (tools/gantt_step.py): the role ended 4.8 us after its decision
+// (parameters 0.8, corner rows 1.1, values + stores 1.6 + barriers); now the decision's own 5.2 us hide the two trips.
+#define B9_TREE_KV 3          // output items per thread whose corner values are kept in registers at a time
+__device__ __forceinline__ void tree_derive(const DevPack &pk, const TreeDev &td, int w, int o2, int n2, int pop, int part, int parts)
+{
+    if (td.derive_mode == 2) { tree_derive_prologue(pk, td, w, o2, n2, pop, part, parts); return; }
+    const int tid = threadIdx.x, d = td.d, n_pops = td.n_pops, depth = td.depth;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ double s_par[B9_NPARAM];
+    const double *in = tree_state_in(td, w);
+    const size_t cb = tree_cand(td, td.set ^ 1, w, o2, n2);
+    if (wave == 0) {
+        // the old state and every node's proposal of the previous launch's tree: which of them is x, the walk says
+        double cand_v[B9_TREE_MAX_NODES + 1];
+        const int NN = (1 << depth) - 1;
+        cand_v[0] = tid < B9_NPARAM ? in[B9_TS_CUR + tid] : 0.0;
+#pragma unroll
+        for (int n = 0; n < B9_TREE_MAX_NODES; ++n) cand_v[n + 1] = (tid < B9_NPARAM && n < NN) ? in[B9_TS_PROP + 12 * n + tid] : 0.0;
+        const int fidx = tid < d ? td.free_idx[tid] : 0;
+        // the steps' increments: table words, requested with everything else of the first round trip
+        double dtab[2 * B9_TREE_MAX_DEPTH];
+        {
+            const double *tab = td.step_tab + (size_t)w * td.tab_steps * B9_TREE_TAB_ROW;
+            const long long r_cur = (long long)(td.step - td.block_step0), r_next = (long long)(td.next_step - td.block_step0);
+#pragma unroll
+            for (int i = 0; i < B9_TREE_MAX_DEPTH; ++i) {
+                dtab[i] = (tid < d && i < depth) ? tab[(size_t)(r_cur + i) * B9_TREE_TAB_ROW + tid] : 0.0;
+                dtab[B9_TREE_MAX_DEPTH + i] = (tid < d && i < depth) ? tab[(size_t)(r_next + i) * B9_TREE_TAB_ROW + tid] : 0.0;
+            }
+        }
+        const int last = tree_decide(td, w).last;
+        double x = cand_v[0];
+#pragma unroll
+        for (int n = 0; n < B9_TREE_MAX_NODES; ++n) x = (last == n) ? +cand_v[n + 1] : x;
+        if (tid < B9_NPARAM) s_par[tid] = x;
+        __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS accesses complete in program order)
+        if (tid < d) {
+            double v = s_par[fidx];                          // each lane owns one sampled parameter: sequential adds, no hazard
+            const int lv = tree_level(n2), p2 = n2 + 1 - (1 << (lv - 1));
+#pragma unroll
+            for (int i = 1; i <= B9_TREE_MAX_DEPTH; ++i) if (i <= depth && ((o2 >> (depth - i)) & 1)) v += dtab[i - 1];
+#pragma unroll
+            for (int i = 1; i < B9_TREE_MAX_DEPTH; ++i) if (i < lv && ((p2 >> (lv - 1 - i)) & 1)) v += dtab[B9_TREE_MAX_DEPTH + i - 1];
+#pragma unroll
+            for (int i = 0; i < B9_TREE_MAX_DEPTH; ++i) if (i == lv - 1) v += dtab[B9_TREE_MAX_DEPTH + i];
+            s_par[fidx] = v;
+        }
+        __syncthreads();
+        if (pop == 0 && part == 0 && tid < B9_NPARAM) td.cand_par[cb * B9_NPARAM + tid] = s_par[tid];
+        return;
+    }
+    // ---- waves 1..3: the derivation, ahead for the previous state's cell ----
+    const int nfp = pk.nfp, mass_cap = td.mass_cap, wp = (int)(cb * n_pops + pop);
+    const int first = part * 192 + (tid - 64), stride = parts * 192;
+    AxisRegs ax[3];
+    preload_axes3(pk, ax);
+    const double g_age = in[B9_TS_CUR + B9_P_LOGAGE], g_feh = in[B9_TS_CUR + B9_P_FEH];
+    const double g_y = in[B9_TS_CUR + (pop ? B9_P_Y2 : B9_P_Y)];
+    GridCell cell = grid_cell(pk, ax, g_age, g_feh, g_y);
+    CornerRegs cr = corner_rows(pk, cell);
+    double v[B9_TREE_KV][8];
+    {
+        const int total = (cr.n >= 2 && cr.n <= mass_cap) ? cr.n * (nfp + 1) : 0;
+        corner_values<B9_TREE_KV>(pk, cr, total, first, stride, v);
+    }
+    __syncthreads();                                         // the candidate's parameters (first wave)
+    const double log_age = s_par[B9_P_LOGAGE], feh = s_par[B9_P_FEH], y = pop ? s_par[B9_P_Y2] : s_par[B9_P_Y];
+    const GridCell own = grid_cell(pk, ax, log_age, feh, y);
+    const bool same = own.i_age == cell.i_age && own.i_feh == cell.i_feh && own.i_y == cell.i_y;
+    if (!same) { cell = own; cr = corner_rows(pk, cell); }
+    const IsoHdr h = header_of(pk, cell, cr, log_age, feh, y, mass_cap);
+    IsoHdr *hp = td.cand_hdr + wp;
+    if (part == 0 && tid == 64) {
+        // (agb_tip of a valid isochrone is stored by the thread that interpolates the last point's mass)
+        hp->valid = h.valid; hp->first_eep = h.first_eep; hp->n = h.n; hp->i_feh = h.i_feh; hp->i_y = h.i_y; hp->i_age = h.i_age;
+        hp->t_feh = h.t_feh; hp->t_y = h.t_y; hp->t_age = h.t_age;
+        if (!h.valid) hp->agb_tip = 0.0;
+    }
+    if (!h.valid) return;
+    const int total = h.n * (nfp + 1);
+    double *omass = td.cand_iso + (size_t)wp * td.iso_stride;
+    double *omags = omass + mass_cap;
+    if (!same) corner_values<B9_TREE_KV>(pk, cr, total, first, stride, v);
+    store_values<B9_TREE_KV>(pk, h, total, first, stride, v, omass, omags, &hp->agb_tip);
+    for (int f = first + B9_TREE_KV * stride; f < total; f += B9_TREE_KV * stride) {      // (few derivation parts: more than KV items per thread)
+        corner_values<B9_TREE_KV>(pk, cr, total, f, stride, v);
+        store_values<B9_TREE_KV>(pk, h, total, f, stride, v, omass, omags, &hp->agb_tip);
     }
 }
 

@@ -100,6 +100,37 @@ def test_fused_step_plans_all_give_the_same_chain(monkeypatch, env, n_steps):
     assert dev[4] + two[4] == one[4]
 
 
+@pytest.mark.parametrize("depth", ["2", "3"])
+@pytest.mark.parametrize("n_pops,n_y", [(1, 1), (2, 3)])
+def test_tree_candidates_in_other_grid_cells(monkeypatch, depth, n_pops, n_y):
+    """The tree launch's derivation role reads its tables AHEAD for the grid cell of the previous state; walkers that
+    sit on cell borders (age, FeH, Y) and take steps of a cell's size put many candidates in another cell, which then
+    repeat the reads for their own: the chain is the host twin's either way."""
+    from base_amd import engine
+    monkeypatch.setenv("B9_TREE_DEPTH", depth)
+    pack_d, cl, pack, stars, priors, options = build_problem("dsed", 5, n_stars=1500, wd_frac=0.02, n_y=n_y, n_pops=n_pops, small=False, seed=5)
+    eng = engine.Engine(pack, stars, priors, options)
+    free = np.array([abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS] + ([abi.P_Y, abi.P_Y2, abi.P_LAMBDA] if n_pops == 2 else []))
+    W = 4
+    start = synth.walker_params(cl["truth"], W, seed=3, scale=0.05, n_pops=n_pops)
+    ages, fehs = np.asarray(pack_d["log_age"]), np.asarray(pack_d["feh"])
+    for w in range(W):                                                             # on (or a hair beside) a grid line in age and FeH
+        start[w, abi.P_LOGAGE] = ages[len(ages) // 2 + w] + (w - 1) * 1e-9
+        start[w, abi.P_FEH] = fehs[1 + w % (len(fehs) - 2)] + (1 - w) * 1e-9
+    d_age, d_feh = float(np.min(np.diff(ages))), float(np.min(np.diff(fehs)))
+    steps = [0.7 * d_age, 0.5 * d_feh, 5e-4, 5e-4] + ([0.05, 0.05, 2e-3] if n_pops == 2 else [])
+    chol = np.diag(steps)
+    lp0 = eng.logpost(start)
+    assert eng.step_depth(W) == int(depth)
+    host = mcmc.HostBlockRunner(eng.logpost).run(start, lp0, np.arange(W), free, chol, 21, 0, 40)
+    dev = mcmc.DeviceBlockRunner(eng).run(start, lp0, np.arange(W), free, chol, 21, 0, 40)
+    assert dev[4] == host[4]
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
+    cells = {(int(np.searchsorted(ages, r[0], side="right")), int(np.searchsorted(fehs, r[1], side="right"))) for r in dev[2].reshape(-1, len(free))}
+    assert len(cells) >= 3, "the chain should have visited several grid cells"
+
+
 def test_fused_step_many_walkers_and_two_populations_several_rounds(monkeypatch):
     """More walkers than one occupancy round holds at 1 tile per workgroup: later workgroups may take the
     published decision instead of re-deriving it -- same chain."""
