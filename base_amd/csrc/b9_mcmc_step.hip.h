@@ -451,7 +451,10 @@ void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_pe
         unsigned long long *g = g_gantt + ((sd.step & 7ull) * B9_GANTT_WG + blockIdx.x) * 4;
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g[0] = t_in; g[1] = __builtin_amdgcn_s_memrealtime(); g[2] = (unsigned long long)role | ((unsigned long long)(xcc & 15u) << 8); g[3] = sd.step;
+        unsigned hw;                                       // HW_ID: CU (bits 8-11), SH (12), SE (13-15) of the workgroup's first wave
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g[0] = t_in; g[1] = __builtin_amdgcn_s_memrealtime();
+        g[2] = (unsigned long long)role | ((unsigned long long)(xcc & 15u) << 8) | ((unsigned long long)(hw & 0xFFFFu) << 16); g[3] = sd.step;
     }
 #else
     (void)role;

@@ -69,6 +69,20 @@ print("slowest 10% of the hot workgroups (id - first hot id, xcc, us):", [(int(i
 for r_, nm in ((0, "hot"), (1, "heavy"), (2, "derive")):
     m_ = role == r_
     print(f"   per XCC, {nm}: " + " ".join(f"{x}: n={int((m_ & (xcc == x)).sum())} mean {((b - a)[m_ & (xcc == x)].mean() / 100 if (m_ & (xcc == x)).any() else 0):.2f}" for x in range(8)))
+if name in ("C2", "C4"):
+    # placement: hot workgroups per CU (XCC, SE, SH, CU of HW_ID) against their end times
+    hw = (s[:, 2] >> 16) & 0xFFFF
+    cu_key = xcc * 4096 + ((hw >> 13) & 7) * 256 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15)
+    by_n = {}
+    for key in np.unique(cu_key):
+        m_ = cu_key == key
+        n_hot, n_front = int((m_ & (role == 0)).sum()), int((m_ & (role != 0) & (role != 3)).sum())
+        if n_hot:
+            by_n.setdefault((n_hot, n_front), []).append((b[m_ & (role == 0)].max() - t0) / 100.0)
+    print(f"   CUs in use: {len(np.unique(cu_key))}; last hot end per CU by (hot workgroups, other workgroups) on the CU:")
+    for k_ in sorted(by_n):
+        v_ = np.array(by_n[k_])
+        print(f"      {k_[0]} hot + {k_[1]} other: {len(v_):3d} CUs, last hot end mean {v_.mean():6.2f} max {v_.max():6.2f}")
 print("last finishers of a middle launch (workgroup, role, xcc, start, end):", [(int(i), ROLE[int(role[i])], int(xcc[i]), round((a[i] - t0) / 100, 2), round((b[i] - t0) / 100, 2)) for i in last])
 hb = np.zeros((64, 8), dtype=np.uint64)
 eng.lib.b9_debug_read_gantt_heavy.argtypes = [C.c_void_p]
