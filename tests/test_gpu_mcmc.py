@@ -150,6 +150,23 @@ def test_fused_step_many_walkers_and_two_populations_several_rounds(monkeypatch)
     np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
 
 
+def test_tree_depth_follows_the_catalogue_size():
+    """Speculation pays only while the chip is under-filled: one walker on a small catalogue takes three steps per launch, on a
+    catalogue whose tiles saturate the CUs the one-step launch (make_tree_plan's cost estimate); a pinned depth still runs."""
+    from base_amd import engine
+    pack_d = synth.make_pack("parsec", 8)
+    truth = synth.default_params(pack_d)
+    depth = {}
+    for n_stars in (10000, 400000):
+        cl = synth.make_cluster(pack_d, n_stars, seed=3, truth=truth)
+        eng = engine.Engine(abi.make_pack(pack_d), abi.make_stars(cl), synth.default_priors(pack_d, truth), abi.make_options())
+        depth[n_stars] = eng.step_depth(1)
+        if n_stars == 400000:
+            eng.set_tuning(tree_depth=2)
+            assert eng.step_depth(1) == 2
+    assert depth == {10000: 3, 400000: 1}
+
+
 def test_device_chain_is_bit_reproducible():
     """No atomics on the data path, fixed summation orders, counter-based RNG: the same block run twice is the
     same bits (also when several occupancy rounds let late workgroups take the published decision)."""
