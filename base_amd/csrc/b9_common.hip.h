@@ -55,6 +55,13 @@ extern "C" int b9_debug_read_gantt_heavy2(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_heavy2), sizeof(unsigned long long) * 64 * 16);
 }
+__device__ unsigned long long g_gantt_walk[8];                 // the tree walk of workgroup 0: kernel entry | loads issued | loads landed | walk done
+extern "C" int b9_debug_read_gantt_walk(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_walk), sizeof(unsigned long long) * 8);
+}
+#define WSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_gantt_walk[7] == 1ull) g_gantt_walk[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WSTAMP_ON(v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_gantt_walk[7] = (v); } while (0)
 #ifndef HS2_LANE
 #define HS2_LANE 0
 #endif
@@ -63,6 +70,8 @@ extern "C" int b9_debug_read_gantt_heavy2(unsigned long long *out)
 #else
 #define HS2(k) do {} while (0)
 #define HSTAMP(k) do {} while (0)
+#define WSTAMP(k) do {} while (0)
+#define WSTAMP_ON(v) do {} while (0)
 #endif
 
 __device__ __forceinline__ double lerp(double a, double b, double t) { return fma(t, b - a, a); }
@@ -146,11 +155,61 @@ __device__ __forceinline__ double logaddexp(double a, double b)
     return hi + log1pexp(lo - hi);
 }
 
+// Cross-lane moves of a double without the LDS crossbar (ds_bpermute, what __shfl_* compile to: two per double and step):
+// DPP row shifts inside a row of 16 lanes, gfx950's v_permlane16_swap / v_permlane32_swap between rows.  lane_down<O>(v) in
+// lane l = v of lane l + O wherever a reduction towards lane 0 reads it (l + O inside the row for O < 16, l in an even
+// row for O = 16, l < 32 for O = 32); other lanes hold something unspecified.  Full EXEC.
+template <int O>
+__device__ __forceinline__ double lane_down(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (O == 32) {
+        lo = (int)__builtin_amdgcn_permlane32_swap((unsigned)lo, (unsigned)lo, false, false)[1];
+        hi = (int)__builtin_amdgcn_permlane32_swap((unsigned)hi, (unsigned)hi, false, false)[1];
+    } else if (O == 16) {
+        lo = (int)__builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)lo, false, false)[1];
+        hi = (int)__builtin_amdgcn_permlane16_swap((unsigned)hi, (unsigned)hi, false, false)[1];
+    } else {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 | O, 0xf, 0xf, false);      // row_shl:O
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 | O, 0xf, 0xf, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the wave in lane 0: the tree v[l] += v[l + 32], += v[l + 16], ... += v[l + 1] (as with __shfl_down: same bits)
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    v += lane_down<32>(v); v += lane_down<16>(v);
+    v += lane_down<8>(v); v += lane_down<4>(v); v += lane_down<2>(v); v += lane_down<1>(v);
     return v;   // valid in lane 0
+}
+
+// lane 0's value in every lane, as a scalar
+__device__ __forceinline__ double wave_bcast0(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// N independent wave sums
+// maximum over the wave, in every lane (wave-uniform; exact whatever the order)
+__device__ __forceinline__ double wave_max_all(double v)
+{
+    double t;
+    t = lane_down<32>(v); v = t > v ? t : v;
+    t = lane_down<16>(v); v = t > v ? t : v;
+    t = lane_down<8>(v); v = t > v ? t : v;
+    t = lane_down<4>(v); v = t > v ? t : v;
+    t = lane_down<2>(v); v = t > v ? t : v;
+    t = lane_down<1>(v); v = t > v ? t : v;
+    return wave_bcast0(v);
+}
+
+template <int N>
+__device__ __forceinline__ void wave_sums(double (&v)[N])
+{
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] = wave_sum(v[n]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -70,8 +70,11 @@ __device__ __forceinline__ TreeWalk tree_walk(const TreeDev &td, const TreeLoads
 #pragma unroll
         for (int k = 0; k < B9_TREE_KD; ++k) acc = (lane + 64 * k < n_hot) ? acc + tl.v[n][k] : acc;
         acc = (lane < td.heavy_parts) ? acc + tl.hv[n] : acc;
-        T[n] = __shfl(wave_sum(acc), 0, 64);
+        T[n] = acc;
     }
+    wave_sums<B9_TREE_MAX_NODES>(T);
+#pragma unroll
+    for (int n = 0; n < B9_TREE_MAX_NODES; ++n) T[n] = wave_bcast0(T[n]);
     TreeWalk tw;
     tw.outcome = 0; tw.last = -1; tw.n_acc = 0; tw.lp = tl.lp;
 #pragma unroll
@@ -122,8 +125,18 @@ __device__ __forceinline__ TreeWalk tree_walk(const TreeDev &td, const TreeLoads
 __device__ __forceinline__ TreeWalk tree_decide(const TreeDev &td, int w)
 {
     TreeLoads tl;
+    WSTAMP(1);
     tree_issue(td, w, tl);
+#ifdef B9_GANTT
+    WSTAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WSTAMP(3);
+    const TreeWalk tw = tree_walk(td, tl);
+    if (tw.outcome >= 0) WSTAMP(4);
+    return tw;
+#else
     return tree_walk(td, tl);
+#endif
 }
 
 // index of candidate (walker w, outcome o of the previous launch, node n) in cand_par / cand_hdr / cand_iso of parity `set`
@@ -523,6 +536,8 @@ void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int tiles_pe
 #ifdef B9_GANTT
     const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
 #endif
+    WSTAMP_ON(td.derive_mode == 1 ? 1ull : 0ull);    // (the K launches only)
+    WSTAMP(0);
     const int W = td.n_walkers, NN = (1 << td.depth) - 1, NO = td.derive_mode == 2 ? 1 : (1 << td.depth);
     int b = blockIdx.x, role = 3;                            // 0 hot, 1 heavy, 2 derivation, 3 padding, 4 writer (tools/gantt_step.py)
     const int n_writers = W;                                 // (the prologue has no tree to take a decision on: its "writers" write the block's step table)
@@ -559,6 +574,7 @@ void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int tiles_pe
 __global__ __launch_bounds__(256) void k_tree_finish(TreeDev td, DevPriors pr)
 {
     __shared__ double s_last[B9_NPARAM + 2];
+    WSTAMP_ON(0ull);
     tree_writer(td, pr, blockIdx.x, s_last);
     __syncthreads();
     if (td.rows) {

@@ -322,9 +322,7 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
                     const int p0 = (n_list >= 0 ? my_list[iv] : iv) << 6;
                     const int pnode = p0 + lane;
                     // wave-wide running maximum (conservative for every lane)
-                    double wmx = acc.mx > seed ? acc.mx : seed;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(wmx, o, 64); wmx = t > wmx ? t : wmx; }
+                    const double wmx = wave_max_all(acc.mx > seed ? acc.mx : seed);
                     MSTAT(0, 1);
                     if (chunk_cap > 0) {       // the whole chunk at once (wave-uniform: every lane reads the same LDS words)
                         const double *cm = chunk_tab + ((size_t)kp * chunk_cap + (p0 >> 6)) * NFP;
@@ -406,12 +404,9 @@ __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE)) void k_star
             }
             // wavefront combine of the 64 partial log-sum-exps: the wave's maximum first, then every lane's sum rescaled to it
             // ONCE and a plain shuffle sum (one exponential per lane instead of one per lane and shuffle step)
-            double wm = acc.mx;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(wm, o, 64); wm = t > wm ? t : wm; }
-            double ssum = (acc.mx == NEG_INF) ? 0.0 : acc.sm * exp_fast(acc.mx - wm);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
+            const double wm = wave_max_all(acc.mx);
+            // (lane 0's sum: the same pairs in the same order as the xor butterfly gave it; the star's value is lane 0's)
+            const double ssum = wave_sum((acc.mx == NEG_INF) ? 0.0 : acc.sm * exp_fast(acc.mx - wm));
             ll[kp] = (wm == NEG_INF) ? NEG_INF : c0m + (wm + log(ssum));
         }
 #undef B9_SAMPLE_NODE

@@ -105,3 +105,10 @@ if eng.lib.b9_debug_read_gantt_heavy2(h2.ctypes.data) == 0:
         t0 = hb64[k, 3]
         print("   wg %2d: " % k + " ".join("%d:%5.2f" % (j, (g[k, j] - t0) / 100) if g[k, j] else "%d:  -  " % j for j in (1, 11, 12, 3, 2, 4, 13, 14, 6, 7, 8))
               + "   | stars phase ends %5.2f" % ((hb64[k, 4] - t0) / 100))
+wk = np.zeros(8, dtype=np.uint64)
+if hasattr(eng.lib, "b9_debug_read_gantt_walk"):
+    eng.lib.b9_debug_read_gantt_walk.argtypes = [C.c_void_p]
+    if eng.lib.b9_debug_read_gantt_walk(wk.ctypes.data) == 0 and wk[4] > 0:
+        t = wk.astype(np.int64)
+        print("tree walk of workgroup 0 (the writer), us since kernel entry: loads issued from %.2f to %.2f | landed %.2f | walk done %.2f"
+              % ((t[1] - t[0]) / 100, (t[2] - t[0]) / 100, (t[3] - t[0]) / 100, (t[4] - t[0]) / 100))
