@@ -176,6 +176,14 @@ __device__ __forceinline__ double lane_down(double v)
     return __hiloint2double(hi, lo);
 }
 
+template <int O>
+__device__ __forceinline__ int lane_down(int v)
+{
+    if (O == 32) return (int)__builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false)[1];
+    if (O == 16) return (int)__builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false)[1];
+    return __builtin_amdgcn_update_dpp(v, v, 0x100 | O, 0xf, 0xf, false);
+}
+
 // sum over the wave in lane 0: the tree v[l] += v[l + 32], += v[l + 16], ... += v[l + 1] (as with __shfl_down: same bits)
 __device__ __forceinline__ double wave_sum(double v)
 {

@@ -218,16 +218,18 @@ __device__ __forceinline__ double mix_value(double ea, double l)
 // wave-wide combine; result valid in lane 0:  log(prod) + sum(add)
 __device__ __forceinline__ double mix_wave_total(MixAcc a)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double m2 = __shfl_down(a.mant, o, 64);
-        const int e2 = __shfl_down(a.expo, o, 64);
-        const double d2 = __shfl_down(a.add, o, 64);
-        const double m = a.mant * m2;                      // both in [0.5, 1): product in [0.25, 1)
-        a.expo += e2 + __builtin_amdgcn_frexp_exp(m);
-        a.mant = __builtin_amdgcn_frexp_mant(m);
-        a.add += d2;
+    // (lane 0's tree l <- l + 32, + 16, ... + 1 on DPP / permlane moves: b9_common.hip.h lane_down)
+#define B9_MIX_STEP(O) {                                                                                   \
+        const double m2 = lane_down<O>(a.mant);                                                            \
+        const int e2 = lane_down<O>(a.expo);                                                               \
+        const double d2 = lane_down<O>(a.add);                                                             \
+        const double m = a.mant * m2;                      /* both in [0.5, 1): product in [0.25, 1) */    \
+        a.expo += e2 + __builtin_amdgcn_frexp_exp(m);                                                      \
+        a.mant = __builtin_amdgcn_frexp_mant(m);                                                           \
+        a.add += d2;                                                                                       \
     }
+    B9_MIX_STEP(32) B9_MIX_STEP(16) B9_MIX_STEP(8) B9_MIX_STEP(4) B9_MIX_STEP(2) B9_MIX_STEP(1)
+#undef B9_MIX_STEP
     // mant in [0.5, 1): log(mant) = log_ge1(2 mant) - ln 2 (the lean log instead of the library one)
     return (log_ge1(a.mant + a.mant) + (double)(a.expo - 1) * 0.693147180559945309417) + a.add;
 }
