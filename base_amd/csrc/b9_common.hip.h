@@ -199,7 +199,6 @@ __device__ __forceinline__ double wave_bcast0(double v)
     return __hiloint2double(hi, lo);
 }
 
-// N independent wave sums
 // maximum over the wave, in every lane (wave-uniform; exact whatever the order)
 __device__ __forceinline__ double wave_max_all(double v)
 {
@@ -211,13 +210,6 @@ __device__ __forceinline__ double wave_max_all(double v)
     t = lane_down<2>(v); v = t > v ? t : v;
     t = lane_down<1>(v); v = t > v ? t : v;
     return wave_bcast0(v);
-}
-
-template <int N>
-__device__ __forceinline__ void wave_sums(double (&v)[N])
-{
-#pragma unroll
-    for (int n = 0; n < N; ++n) v[n] = wave_sum(v[n]);
 }
 
 // ------------------------------------------------------------------------------------------

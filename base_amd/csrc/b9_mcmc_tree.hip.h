@@ -70,11 +70,8 @@ __device__ __forceinline__ TreeWalk tree_walk(const TreeDev &td, const TreeLoads
 #pragma unroll
         for (int k = 0; k < B9_TREE_KD; ++k) acc = (lane + 64 * k < n_hot) ? acc + tl.v[n][k] : acc;
         acc = (lane < td.heavy_parts) ? acc + tl.hv[n] : acc;
-        T[n] = acc;
+        T[n] = wave_bcast0(wave_sum(acc));
     }
-    wave_sums<B9_TREE_MAX_NODES>(T);
-#pragma unroll
-    for (int n = 0; n < B9_TREE_MAX_NODES; ++n) T[n] = wave_bcast0(T[n]);
     TreeWalk tw;
     tw.outcome = 0; tw.last = -1; tw.n_acc = 0; tw.lp = tl.lp;
 #pragma unroll
