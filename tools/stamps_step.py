@@ -24,12 +24,15 @@ t = buf.astype(np.int64)
 t = t[(t[:, 8] > 0) & (t[:, 0] > 0)]
 t0 = t[:, 0].min()
 names = ["entry", "loads issued", "decision", "LDS fill+barrier", "primary search", "rows+lerp", "secondary+combine", "obs/w+chi2+mix", "reduce+store"]
-print(f"hot waves {len(t)}  span {t[:,8].max()-t0} ticks of 10 ns")
+# (stamps are s_memtime shader-clock counts; a wave that skipped a phase keeps an older launch's stamp there: read the medians)
+print(f"hot waves {len(t)}; phase durations in shader cycles (s_memtime), last tile of each wave")
 d = np.diff(t[:, :9], axis=1)
 for k in range(8):
-    print(f"  {names[k+1]:24s} mean {d[:,k].mean():9.1f}  p50 {np.median(d[:,k]):9.1f}  p95 {np.percentile(d[:,k],95):9.1f}")
+    print(f"  {names[k+1]:24s} p50 {np.median(d[:,k]):9.1f}  p95 {np.percentile(d[:,k],95):9.1f}")
 dd = t[:, [1, 9, 10, 11, 2]]
 for k, nm in enumerate(["partials loaded", "philox+log", "wave_sum+2 barriers", "compare"]):
     x = dd[:, k + 1] - dd[:, k]
-    print(f"    decision/{nm:22s} mean {x.mean():9.1f}  p50 {np.median(x):9.1f}  p95 {np.percentile(x,95):9.1f}")
-print("  wave lifetime mean", (t[:,8]-t[:,0]).mean(), " start offsets p5/p50/p95/max", np.percentile(t[:,0]-t0,[5,50,95,100]), " end offsets p50/p95/max", np.percentile(t[:,8]-t0,[50,95,100]))
+    ok = np.abs(x) < 1e7
+    if ok.any(): print(f"    decision/{nm:22s} p50 {np.median(x[ok]):9.1f}  p95 {np.percentile(x[ok],95):9.1f}")
+life = t[:, 8] - t[:, 0]
+print("  wave lifetime p50 %.0f p95 %.0f cycles" % tuple(np.percentile(life[np.abs(life) < 1e7], [50, 95])))
