@@ -184,7 +184,9 @@ typedef struct b9_tuning {
     int32_t tree_depth;        /* given-mass sampler blocks: Metropolis steps per launch.  1 = the one-step fused launch;   */
                                /* 2 / 3 = the tree-speculative launch (every proposal of the chain's next 2 / 3 steps --   */
                                /* 3 / 7 of them -- evaluated at once, same chain); default: the deepest tree whose          */
-                               /* workgroups are all resident at once (few walkers per GPU), else 1.  Env: B9_TREE_DEPTH    */
+                               /* workgroups are all resident at once AND whose estimated cost per step beats the one-step  */
+                               /* launch's (few walkers per GPU, catalogues that leave the chip under-filled), else 1.      */
+                               /* Env: B9_TREE_DEPTH                                                                        */
     int32_t reserved[5];
 } b9_tuning;
 
