@@ -199,6 +199,46 @@ __device__ __forceinline__ double wave_bcast0(double v)
     return __hiloint2double(hi, lo);
 }
 
+// Seven wave sums at once (the tree walk's seven nodes): the SAME tree as wave_sum for each -- v[l] + v[l + 32], then + 16,
+// ... + 1, operands at most commuted -- but with the sums packed side by side: level 32 adds two nodes per instruction (one in
+// each half of the wave: v_permlane32_swap hands both halves their partner at once), level 16 four (one per row of 16 lanes,
+// v_permlane16_swap), and the levels inside a row run on two registers instead of seven: 42 instructions for 126.
+__device__ __forceinline__ void lane_swap32(double &x, double &y)      // x' = [x.lo32, y.lo32], y' = [x.hi32, y.hi32] (halves of the wave)
+{
+    unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x), yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
+    const auto a = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+    x = __hiloint2double((int)b[0], (int)a[0]); y = __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ void lane_swap16(double &x, double &y)      // x' = rows [x0, y0, x2, y2], y' = rows [x1, y1, x3, y3]
+{
+    unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x), yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
+    const auto a = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+    x = __hiloint2double((int)b[0], (int)a[0]); y = __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double lane_read(double v, int lane /* constant */)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sum7(const double (&a)[7], double (&S)[7])        // S[n]: wave-uniform
+{
+    double x, y, p01, p23, p45, p6;
+    x = a[0]; y = a[1]; lane_swap32(x, y); p01 = x + y;          // lower half: a0[l] + a0[l + 32]; upper: a1[l - 32] + a1[l]
+    x = a[2]; y = a[3]; lane_swap32(x, y); p23 = x + y;
+    x = a[4]; y = a[5]; lane_swap32(x, y); p45 = x + y;
+    x = a[6]; y = a[6]; lane_swap32(x, y); p6 = x + y;
+    lane_swap16(p01, p23); double q0 = p01 + p23;                 // rows: node 0, 2, 1, 3  (each: its level-32 sums l + (l + 16))
+    lane_swap16(p45, p6);  double q1 = p45 + p6;                  // rows: node 4, 6, 5, -
+    q0 += lane_down<8>(q0); q1 += lane_down<8>(q1);
+    q0 += lane_down<4>(q0); q1 += lane_down<4>(q1);
+    q0 += lane_down<2>(q0); q1 += lane_down<2>(q1);
+    q0 += lane_down<1>(q0); q1 += lane_down<1>(q1);
+    S[0] = lane_read(q0, 0); S[2] = lane_read(q0, 16); S[1] = lane_read(q0, 32); S[3] = lane_read(q0, 48);
+    S[4] = lane_read(q1, 0); S[6] = lane_read(q1, 16); S[5] = lane_read(q1, 32);
+}
+
 // maximum over the wave, in every lane (wave-uniform; exact whatever the order)
 __device__ __forceinline__ double wave_max_all(double v)
 {

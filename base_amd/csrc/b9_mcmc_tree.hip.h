@@ -70,7 +70,14 @@ __device__ __forceinline__ TreeWalk tree_walk(const TreeDev &td, const TreeLoads
 #pragma unroll
         for (int k = 0; k < B9_TREE_KD; ++k) acc = (lane + 64 * k < n_hot) ? acc + tl.v[n][k] : acc;
         acc = (lane < td.heavy_parts) ? acc + tl.hv[n] : acc;
-        T[n] = wave_bcast0(wave_sum(acc));
+        T[n] = acc;
+    }
+    {
+        static_assert(B9_TREE_MAX_NODES == 7, "wave_sum7");
+        double S[B9_TREE_MAX_NODES];
+        wave_sum7(T, S);
+#pragma unroll
+        for (int n = 0; n < B9_TREE_MAX_NODES; ++n) T[n] = S[n];
     }
     TreeWalk tw;
     tw.outcome = 0; tw.last = -1; tw.n_acc = 0; tw.lp = tl.lp;
