@@ -150,6 +150,32 @@ def test_fused_step_many_walkers_and_two_populations_several_rounds(monkeypatch)
     np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
 
 
+@pytest.mark.parametrize("n_pops,n_y", [(1, 1), (2, 3)])
+def test_tree_and_one_step_launches_give_the_same_bits(monkeypatch, n_pops, n_y):
+    """With the star-to-partial-sum grouping pinned (tiles per workgroup), the tree launch at depth 2 and 3 walks exactly the
+    one-step launch's sums (per node the same words in the same lanes, the same cross-lane tree -- packed seven at a time in
+    the tree walk) and takes exactly its decisions: the chains are equal bit for bit, not just to the tolerance."""
+    from base_amd import engine
+    monkeypatch.setenv("B9_TILES_PER_BLOCK", "2")
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=5000, wd_frac=0.04, n_y=n_y, n_pops=n_pops, small=False, seed=21)
+    free = np.array([abi.P_LOGAGE, abi.P_FEH, abi.P_MOD, abi.P_ABS] + ([abi.P_Y, abi.P_Y2, abi.P_LAMBDA] if n_pops == 2 else []))
+    W = 2
+    start = synth.walker_params(cl["truth"], W, seed=9, scale=0.05, n_pops=n_pops)
+    chol = np.diag([3e-4, 2e-3, 8e-4, 6e-4] + ([3e-4, 3e-4, 2e-3] if n_pops == 2 else []))
+    runs = {}
+    for depth in ("1", "2", "3"):
+        monkeypatch.setenv("B9_TREE_DEPTH", depth)
+        eng = engine.Engine(pack, stars, priors, options)
+        assert eng.step_depth(W) == int(depth)
+        lp0 = eng.logpost(start)
+        runs[depth] = eng.mcmc_run_block(start, lp0, np.arange(W), free, chol, 17, 3, 31)
+    assert runs["1"][4] > 0
+    for depth in ("2", "3"):
+        for a, b in zip(runs["1"][:4], runs[depth][:4]):
+            np.testing.assert_array_equal(a, b)
+        assert runs["1"][4] == runs[depth][4]
+
+
 def test_tree_depth_follows_the_catalogue_size():
     """Speculation pays only while the chip is under-filled: one walker on a small catalogue takes three steps per launch, on a
     catalogue whose tiles saturate the CUs the one-step launch (make_tree_plan's cost estimate); a pinned depth still runs."""
