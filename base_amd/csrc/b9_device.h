@@ -78,6 +78,41 @@ struct DevStars {
 
 #define B9_SIDX(nfp, f, i) ((((size_t)((i) >> 6) * (nfp)) + (f)) * 64 + ((i) & 63))
 
+// ------------------------------------------------------------------------------------------
+// Marginalised mode: layout of ONE (walker, population)'s per-call node table (k_marg_table writes it, k_star_marg
+// reads it through SCALAR loads: a wave evaluates 64 stars against one node at a time, so a node's words are
+// wave-uniform).  Nodes come in chunks of 64 = 4 sub-chunks of 16; npad = whole chunks of the longest isochrone.
+// Everything starts on a 64-byte boundary (offsets in doubles, multiples of 8).
+//   rows    [chunk][sub][j = 0..Q-1][node 0..15][f]   APPARENT magnitude of the system (node, mass ratio j / Q) in filter f
+//                                                     (j = 0: the primary alone); modulus and absorption already added
+//   nb      [node]                                    -2 log(prior(m1) dM / Q)  (+inf: no such node / empty EEP interval)
+//   box2    [chunk][sub][j]{lo[f], hi[f]}             brightest / faintest magnitude among the unit's 16 rows
+//   nbmin16 [chunk][sub]                              smallest nb of the sub-chunk
+//   box1    [chunk]{lo[f], hi[f]}                     the same over the chunk's 64 nodes and all mass ratios
+//   nbmin64 [chunk]
+// ------------------------------------------------------------------------------------------
+struct MargLayout {
+    int npad, n_chunks, nfp, Q;
+    long long o_rows, o_nb, o_box2, o_nbmin16, o_box1, o_nbmin64, total;
+};
+
+static inline __host__ __device__ MargLayout marg_layout(int nfp, int mass_cap, int K, int Q)
+{
+    MargLayout L;
+    L.n_chunks = ((mass_cap - 1) * K + 63) / 64;
+    if (L.n_chunks < 1) L.n_chunks = 1;
+    L.npad = L.n_chunks * 64; L.nfp = nfp; L.Q = Q;
+    long long o = 0;
+    L.o_rows = o;    o += (long long)L.npad * Q * nfp;
+    L.o_nb = o;      o += L.npad;
+    L.o_box2 = o;    o += (long long)L.n_chunks * 4 * Q * 2 * nfp;
+    L.o_nbmin16 = o; o += (L.n_chunks * 4 + 7) / 8 * 8;
+    L.o_box1 = o;    o += (long long)L.n_chunks * 2 * nfp;
+    L.o_nbmin64 = o; o += (L.n_chunks + 7) / 8 * 8;
+    L.total = o;
+    return L;
+}
+
 // Header of one derived isochrone (one per walker x population).
 struct IsoHdr {
     int valid, first_eep, n, i_feh, i_y, i_age;

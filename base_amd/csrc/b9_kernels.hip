@@ -169,50 +169,33 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
     return hipGetLastError();
 }
 
-// nodes of the companion table per (walker, population, mass ratio, filter): whole 64-node chunks of the longest isochrone
-int b9k_marg_table_npad(int mass_cap, int K) { return (((mass_cap - 1) * K + 63) / 64) * 64; }
-// doubles of one (walker, population)'s table: (Q - 1) NFP combined-magnitude planes + NFP primary-magnitude planes + the log weights
-long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q)
-{
-    return ((long long)(Q - 1) * nfp + nfp + 1) * b9k_marg_table_npad(mass_cap, K);
-}
+// doubles of one (walker, population)'s node table (MargLayout, b9_device.h)
+long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q) { return marg_layout(nfp, mass_cap, K, Q).total; }
 
 template <int NFP, int NPOPS, bool SAMPLE>
 static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                      long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                     double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool chunk_bounds, int n_cu,
+                                     double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool prune,
                                      double *tab, hipStream_t stream)
 {
-    // [mass columns][chunk-bound table: three planes][per wave: star constants][per wave: chunk list]
-    size_t lds = sizeof(double) * ((size_t)NPOPS * (mass_cap + 8) + (size_t)4 * B9_MARG_WAVE_SCRATCH(NFP));
-    int chunk_cap = ((mass_cap - 1) * K + 63) / 64 + 1;                     // chunk-bound table, when LDS has room for it
-    const size_t with_table = lds + sizeof(double) * ((size_t)NPOPS * chunk_cap * NFP * 3) + sizeof(int) * 4 * ((size_t)chunk_cap + 1);
-    if (with_table <= 160 * 1024 && chunk_bounds) lds = with_table; else chunk_cap = 0;
-    auto kern = k_star_marg<NFP, NPOPS, SAMPLE>;
     MargSample ms{};
     if (SAMPLE) { ms.mass = smp->mass; ms.ratio = smp->ratio; ms.member = smp->member; ms.pop = smp->pop; ms.k0 = smp->k0; ms.k1 = smp->k1; ms.row0 = smp->row0; }
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (!tab) return hipErrorInvalidValue;
+    const MargLayout L = marg_layout(NFP, mass_cap, K, Q);
+    // the call's node table: one workgroup per (walker-population, 64-node chunk)
+    const size_t lds = sizeof(double) * ((size_t)mass_cap + 8 + 8 * NFP);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_marg_table<NFP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    // Persistent workgroups: as many as are resident at once (occupancy of THIS instantiation with its LDS), shared out
-    // over the walkers; each stages its walker's isochrone once and its waves stride over the star slots.
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    const int n_quads = (st.n_pad + 3) / 4;
-    const int gx = std::max(1, std::min(n_quads, (per_cu * std::max(1, n_cu)) / std::max(1, n_walkers)));
-    // the companions' flux table of this call (per walker and population; nothing to build for a single mass ratio)
-    const int npad = b9k_marg_table_npad(mass_cap, K);
-    const long long tab_stride = b9k_marg_table_doubles(NFP, mass_cap, K, Q);
-    {
-        if (!tab) return hipErrorInvalidValue;
-        const int parts = std::max(1, std::min(64, (npad * Q + 1023) / 1024));
-        hipLaunchKernelGGL((k_marg_table<NFP>), dim3(n_walkers * NPOPS, parts), dim3(256), sizeof(double) * (mass_cap + 8), stream, hdr, iso_data,
-                           iso_stride, mass_cap, K, Q, tab, tab_stride, npad, pk.log_mass_norm);
-    }
-    hipLaunchKernelGGL(kern, dim3(gx * n_walkers), dim3(256), lds, stream, pk, st, hdr, iso_data, iso_stride,
-                       mass_cap, d_params, vals, perstar, K, Q, ms, chunk_cap, tab, tab_stride, npad, n_walkers, gx);
+    hipLaunchKernelGGL((k_marg_table<NFP>), dim3(n_walkers * NPOPS, L.n_chunks), dim3(256), lds, stream, pk, hdr, iso_data,
+                       iso_stride, mass_cap, NPOPS, d_params, K, Q, tab, L);
+    // the stars: one wave (= one workgroup) per (64-star chunk, walker); XCD x takes the x-th eighth of the chunks
+    const int n_sc = st.n_pad / 64, cpx = (n_sc + 7) / 8;
+    const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
+    hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE>), dim3(8 * cpx * n_walkers), dim3(64), 0, stream, pk, st, hdr, iso_data, iso_stride,
+                       mass_cap, d_params, vals, perstar, K, Q, ms, tab, L, n_walkers, cpx, cut2);
     if (st.n_wd > 0)          // the catalogue's WD-stage stars: their own (register-hungry) kernel, beside the main one's tail
         hipLaunchKernelGGL((k_star_marg_wd<NFP, NPOPS, SAMPLE>), dim3((st.n_wd + 3) / 4, n_walkers), dim3(256), 0, stream, pk, st, hdr,
                            iso_data, iso_stride, mass_cap, d_params, vals, perstar, K, ms);
@@ -222,17 +205,17 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
 template <int NFP, int NPOPS>
 static hipError_t launch_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                    long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                   double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool chunk_bounds, int n_cu, double *tab, hipStream_t stream)
+                                   double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, hipStream_t stream)
 {
-    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, chunk_bounds, n_cu, tab, stream)
-               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, chunk_bounds, n_cu, tab, stream);
+    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, prune, tab, stream)
+               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, prune, tab, stream);
 }
 
 hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
-                         double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool chunk_bounds, int n_cu, double *tab, hipStream_t stream)
+                         double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, hipStream_t stream)
 {
-#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, chunk_bounds, n_cu, tab, stream
+#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, prune, tab, stream
 #define SM2(NFP) launch_star_marg<NFP, 2>(SM_ARGS)
 #define SM1(NFP) launch_star_marg<NFP, 1>(SM_ARGS)
     B9_SWITCH_NFP(SM2, SM1)
