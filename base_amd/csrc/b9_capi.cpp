@@ -837,10 +837,14 @@ static Bufs buffer_set(const b9_ctx *ctx, int set)
 }
 
 // number of partial sums one walker gets from the star kernel under the current plan / mode
+// (marginalised mode: one per 64-star chunk -- the star kernel sums a chunk's values in a fixed order -- and one per WD-stage star)
 static int partial_count(const b9_ctx *ctx, const Plan &plan)
 {
-    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.n_pad : plan.n_groups * 4 + ctx->heavy_parts;
+    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.n_pad / 64 + ctx->st.n_wd : plan.n_groups * 4 + ctx->heavy_parts;
 }
+
+// doubles between two walkers' partial rows (room for either mode's row)
+static long long partial_stride(const b9_ctx *ctx) { return (long long)ctx->st.n_pad + ctx->st.n_pad / 64; }
 
 // The star-likelihood launch (given-mass: hot + heavy workgroups; marginalised: one wave per star)
 // on buffer set `set`, bracketed by timing events when sampled.
@@ -868,10 +872,10 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
         const int rc = ensure_marg_table(ctx, n_walkers, n_pops, K, Q);
         if (rc) return rc;
         HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                                  n_walkers, n_pops, ctx->d_partial, d_perstar, K, Q, nullptr, ctx->chunk_bounds, ctx->d_marg_tab, stream));
+                                  n_walkers, n_pops, ctx->d_partial, partial_stride(ctx), d_perstar, K, Q, nullptr, ctx->chunk_bounds, ctx->d_marg_tab, stream));
     } else {
         HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                                  n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, ctx->st.n_pad, d_perstar,
+                                  n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, partial_stride(ctx), d_perstar,
                                   plan.tiles_per_block, plan.n_groups, ctx->heavy_parts, stream));
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
@@ -885,7 +889,7 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
 {
     const int n_pops = ctx->opt.n_pops;
     const Plan plan = make_plan(ctx, n_walkers, n_pops);
-    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)ctx->st.n_pad * n_walkers, false);
+    int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)partial_stride(ctx) * n_walkers, false);
     if (rc) return rc;
     Bufs bf = buffer_set(ctx, 0);
     bf.params = d_params;
@@ -899,7 +903,7 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
                                    off, ctx->pr, none, stream));
     rc = launch_stars(ctx, bf, n_walkers, d_perstar, plan, stream);
     if (rc) return rc;
-    HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, partial_count(ctx, plan), ctx->st.n_pad, n_pops, bf.params, ctx->pr,
+    HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, partial_count(ctx, plan), partial_stride(ctx), n_pops, bf.params, ctx->pr,
                              n_walkers, d_logpost, d_perstar, ctx->st.n, off, stream));
     return B9_OK;
 }
@@ -1094,7 +1098,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     sd.d = d; sd.n_walkers = W; sd.n_pops = n_pops;
     sd.n_partial = partial_count(ctx, plan); sd.mass_cap = ctx->mass_cap; sd.heavy_parts = ctx->heavy_parts;
     sd.k0 = (unsigned)(blk->seed & 0xFFFFFFFFull); sd.k1 = (unsigned)(blk->seed >> 32);
-    sd.partial_stride = ctx->st.n_pad; sd.iso_stride = ctx->iso_stride;
+    sd.partial_stride = partial_stride(ctx); sd.iso_stride = ctx->iso_stride;
     sd.state = d_state; sd.partial = ctx->d_partial;
     sd.cand_par = ctx->d_params; sd.cand_hdr = ctx->d_hdr; sd.cand_iso = ctx->d_iso;
     sd.chol = d_chol; sd.free_idx = d_free; sd.walker_ids = d_ids;
@@ -1371,7 +1375,7 @@ static int run_block_two_launch(b9_ctx *ctx, b9_mcmc_block *blk, const Plan &pla
         mc.has_prev = t > 0;
         mc.pin = t > 0 ? (t - 1) & 1 : 0;                   // state half on entry
         mc.row = t - 1;                                     // chain row of the step being finished
-        const B9Prev prev{ctx->d_partial, n_part, (long long)ctx->st.n_pad, bp.hdr, bp.params};
+        const B9Prev prev{ctx->d_partial, n_part, partial_stride(ctx), bp.hdr, bp.params};
         HIPCHK(ctx, b9k_derive_iso(ctx->pk, bf.params, W, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap,
                                    mc, ctx->pr, prev, s));
         const int rc = launch_stars(ctx, bf, W, nullptr, plan, s);
@@ -1384,7 +1388,7 @@ static int run_block_two_launch(b9_ctx *ctx, b9_mcmc_block *blk, const Plan &pla
         mc.pin = S > 1 ? (S - 2) & 1 : 0;                   // the half D(S-1) wrote (or the initial half)
         if (S > 1) mc.pin ^= 1;
         mc.row = S - 1;
-        HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, n_part, ctx->st.n_pad, n_pops, bf.params, ctx->pr, W,
+        HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, n_part, partial_stride(ctx), n_pops, bf.params, ctx->pr, W,
                                  ctx->d_logpost, nullptr, ctx->st.n, mc, s));
     }
     const int fin = mc.pin ^ 1;                             // half that holds the final state
@@ -1433,7 +1437,7 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     for (const auto &sl : ctx->slot)
         if (sl.in_flight && sl.W != W) return fail(ctx, B9_ERR_STATE, "collect the outstanding block(s) before running a block with another number of walkers");
     const Plan plan = make_plan(ctx, W, n_pops);
-    rc = ensure_capacity(ctx, W, n_pops, (size_t)ctx->st.n_pad * W, false);
+    rc = ensure_capacity(ctx, W, n_pops, (size_t)partial_stride(ctx) * W, false);
     if (rc) return rc;
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) {
         const TreePlan tp = make_tree_plan(ctx, W, n_pops);
@@ -1466,7 +1470,7 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     if (rc) return rc;
     const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
     (void)plan;
-    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)ctx->st.n_pad * n_walkers, out_perstar != nullptr);
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)partial_stride(ctx) * n_walkers, out_perstar != nullptr);
     if (rc) return rc;
     // The per-step call of a host-driven sampler (the reference's logPostStep) is latency: for up
     // to 8 rows the parameters ride in the first launch's kernel arguments and the log-posteriors are written by
@@ -1504,7 +1508,7 @@ int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t s
     const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
     const int Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
     const int chunk = std::min<int>(n_rows, 32);
-    rc = ensure_capacity(ctx, chunk, n_pops, (size_t)ctx->st.n_pad * chunk, false);
+    rc = ensure_capacity(ctx, chunk, n_pops, (size_t)partial_stride(ctx) * chunk, false);
     if (rc) return rc;
     rc = ensure_marg_table(ctx, chunk, n_pops, K, Q);
     if (rc) return rc;
@@ -1527,7 +1531,7 @@ int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t s
         B9MargSample smp{d_out, d_out + per, d_out + 2 * per, d_pop, (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), (long long)(row0 + r0)};
         // the kernel indexes its outputs [row][n_stars] with the launch's own row count: rows are contiguous for any m
         if (e == hipSuccess) e = b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params, m, n_pops,
-                                               ctx->d_partial, nullptr, K, Q, &smp, ctx->chunk_bounds, ctx->d_marg_tab, s);
+                                               ctx->d_partial, partial_stride(ctx), nullptr, K, Q, &smp, ctx->chunk_bounds, ctx->d_marg_tab, s);
         const size_t cnt = (size_t)m * n, o = (size_t)r0 * n;
         if (e == hipSuccess) e = hipMemcpyAsync(out_mass + o, d_out, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(out_ratio + o, d_out + per, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
@@ -1585,7 +1589,7 @@ int b9_step_tiles_per_block(b9_ctx *ctx, int32_t n_walkers)
     if (!ctx || n_walkers < 1) return B9_ERR_INVALID;
     int rc = check_ready(ctx);
     if (rc) return rc;
-    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)ctx->st.n_pad * n_walkers, false);   // (the plan keys on mass_cap)
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)partial_stride(ctx) * n_walkers, false);   // (the plan keys on mass_cap)
     if (rc) return rc;
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) {
         const TreePlan tp = make_tree_plan(ctx, n_walkers, ctx->opt.n_pops);
@@ -1599,7 +1603,7 @@ int b9_step_depth(b9_ctx *ctx, int32_t n_walkers)
     if (!ctx || n_walkers < 1) return B9_ERR_INVALID;
     int rc = check_ready(ctx);
     if (rc) return rc;
-    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)ctx->st.n_pad * n_walkers, false);
+    rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)partial_stride(ctx) * n_walkers, false);
     if (rc) return rc;
     if (ctx->opt.mode != B9_MODE_GIVEN_MASS || ctx->two_launch_steps) return 1;
     return make_tree_plan(ctx, n_walkers, ctx->opt.n_pops).depth;

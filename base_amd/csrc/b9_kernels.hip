@@ -175,7 +175,7 @@ long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q) { return m
 template <int NFP, int NPOPS, bool SAMPLE>
 static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                      long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                     double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool prune,
+                                     double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune,
                                      double *tab, hipStream_t stream)
 {
     MargSample ms{};
@@ -191,31 +191,31 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     }
     hipLaunchKernelGGL((k_marg_table<NFP>), dim3(n_walkers * NPOPS, L.n_chunks), dim3(256), lds, stream, pk, hdr, iso_data,
                        iso_stride, mass_cap, NPOPS, d_params, K, Q, tab, L);
-    // the stars: one wave (= one workgroup) per (64-star chunk, walker); XCD x takes the x-th eighth of the chunks
+    // the stars: one workgroup (four waves sharing the node table's sub-chunks) per (64-star chunk, walker); XCD x takes the x-th eighth of the chunks
     const int n_sc = st.n_pad / 64, cpx = (n_sc + 7) / 8;
     const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
-    hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE>), dim3(8 * cpx * n_walkers), dim3(64), 0, stream, pk, st, hdr, iso_data, iso_stride,
-                       mass_cap, d_params, vals, perstar, K, Q, ms, tab, L, n_walkers, cpx, cut2);
+    hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE>), dim3(8 * cpx * n_walkers), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
+                       mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cpx, cut2);
     if (st.n_wd > 0)          // the catalogue's WD-stage stars: their own (register-hungry) kernel, beside the main one's tail
         hipLaunchKernelGGL((k_star_marg_wd<NFP, NPOPS, SAMPLE>), dim3((st.n_wd + 3) / 4, n_walkers), dim3(256), 0, stream, pk, st, hdr,
-                           iso_data, iso_stride, mass_cap, d_params, vals, perstar, K, ms);
+                           iso_data, iso_stride, mass_cap, d_params, partial, partial_stride, perstar, K, ms);
     return hipGetLastError();
 }
 
 template <int NFP, int NPOPS>
 static hipError_t launch_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                    long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                   double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, hipStream_t stream)
+                                   double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, hipStream_t stream)
 {
-    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, prune, tab, stream)
-               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, prune, tab, stream);
+    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, stream)
+               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, stream);
 }
 
 hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
-                         double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, hipStream_t stream)
+                         double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, hipStream_t stream)
 {
-#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, vals, perstar, K, Q, smp, prune, tab, stream
+#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, stream
 #define SM2(NFP) launch_star_marg<NFP, 2>(SM_ARGS)
 #define SM1(NFP) launch_star_marg<NFP, 1>(SM_ARGS)
     B9_SWITCH_NFP(SM2, SM1)

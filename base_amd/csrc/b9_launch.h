@@ -40,7 +40,8 @@ struct B9MargSample {
 // smp == nullptr: the plain marginal likelihood; else every star also draws one (mass, ratio[, population]) node
 hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
-                         double *vals, double *perstar, int K, int Q, const B9MargSample *smp, bool prune /* false: every node of every star is evaluated */,
+                         double *partial /* per walker: one sum per 64-star chunk, then one value per WD-stage star */, long long partial_stride,
+                         double *perstar, int K, int Q, const B9MargSample *smp, bool prune /* false: every node of every star is evaluated */,
                          double *tab /* the call's node table: n_walkers * n_pops * b9k_marg_table_doubles(nfp, mass_cap, K, Q) doubles */, hipStream_t stream);
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q);
 

@@ -122,9 +122,9 @@ __device__ __forceinline__ double exp_marg(double x)
 // One more term t = -X / 2 into the lane's log-sum-exp:  value = ref + log(sm).  The reference is FIXED while terms stay
 // within 600 e-folds above it (sm then holds up to e^600: no overflow, and a term 40 e-folds under the largest still adds
 // its full precision), so the common path is one exponential and one add; a term further above (first terms of a lane
-// whose reference was a poor seed) moves the reference -- wave-uniform branch, rare.  The pruning threshold follows the
-// largest term seen: xcut = min(xcut, -2 t + cut2).
-__device__ __forceinline__ void lse_term(double t, double cut2, double &ref, double &sm, double &xcut)
+// whose reference was a poor seed) moves the reference -- wave-uniform branch, rare.  tmax: the largest term seen (the
+// pruning threshold follows it).
+__device__ __forceinline__ void lse_term(double t, double &ref, double &sm, double &tmax)
 {
     const double d = t - ref;
     if (__ballot(d > 600.0) != 0ull) {
@@ -135,23 +135,32 @@ __device__ __forceinline__ void lse_term(double t, double cut2, double &ref, dou
     } else {
         sm += exp_marg(d);
     }
-    xcut = __builtin_fmin(xcut, fma(-2.0, t, cut2));
+    tmax = __builtin_fmax(tmax, t);
 }
 
 // Waves per SIMD the instances are built for (tools/kernel_resources.py)
 #define B9_MARG_WAVES(NFP, NPOPS, SAMPLE) (((NFP) >= 16 || (SAMPLE)) ? 4 : 6)
 
+// A workgroup = FOUR waves holding the SAME 64 stars; wave k takes sub-chunk k of every 64-node chunk (a quarter of every
+// star's window, wherever it lies) and the four partial log-sum-exps are merged through LDS at the end.  (With one wave
+// per 64 stars the launch lasted as long as its heaviest wave -- a chunk of giants whose windows barely overlap walks
+// 2000 terms against an average of 240; the mean wave lived a quarter of the launch.)  The waves share their running
+// maxima through LDS -- plain reads and writes of a double per lane, no barrier: any earlier value of another wave's
+// maximum is still a valid pruning reference -- so each prunes as if it had seen the whole window.
 template <int NFP, int NPOPS, bool SAMPLE>
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(B9_MARG_WAVES(NFP, NPOPS, SAMPLE))))
+__global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE))
 void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                  const double *__restrict__ iso_data, long long iso_stride,
                  int mass_cap, const double *__restrict__ params,
-                 double *__restrict__ vals, double *__restrict__ perstar,
+                 double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
                  int K, int Q, MargSample ms, const double *__restrict__ tab, MargLayout L,
                  int n_walkers, int chunks_per_xcd, double cut2)
 {
-    const int lane = threadIdx.x;
-    // 1-D grid of 8 * chunks_per_xcd * n_walkers one-wave workgroups; ids are dealt round-robin over the 8 XCDs.  XCD x takes
+    __shared__ double s_tmax[NPOPS][4][64], s_ref[NPOPS][4][64], s_sm[NPOPS][4][64];
+    __shared__ double s_bkey[SAMPLE ? 4 : 1][64], s_bmass[SAMPLE ? 4 : 1][64], s_bratio[SAMPLE ? 4 : 1][64];
+    __shared__ int s_bpop[SAMPLE ? 4 : 1][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // 1-D grid of 8 * chunks_per_xcd * n_walkers workgroups; ids are dealt round-robin over the 8 XCDs.  XCD x takes
     // the star chunks [x, x + 1) * chunks_per_xcd -- a contiguous mass range, so it reads that range of every walker's table
     // (plus the windows' fringes) into its L2, not the whole of it -- and inside an XCD the walkers of one star chunk are
     // neighbours in dispatch order: the chunk's star data is fetched from HBM once.  (Speed only; any placement is correct.)
@@ -168,9 +177,9 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     const int flags = st.flags[slot];
     const bool wd_stage = (flags >> 8) == B9_STAGE_WD;             // WD-stage stars: k_star_marg_wd (their own launch)
     if (!valid) {
-        if (!wd_stage) {
-            vals[(size_t)w * st.n_pad + slot] = 0.0;
-            if (perstar && orig >= 0) perstar[(size_t)w * st.n + orig] = NEG_INF;
+        if (wave == 0) {
+            if (lane == 0) partial[(size_t)w * partial_stride + sc] = 0.0;
+            if (perstar && orig >= 0 && !wd_stage) perstar[(size_t)w * st.n + orig] = NEG_INF;
         }
         return;
     }
@@ -181,8 +190,10 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     const double c0m = st.c0m[slot], la = st.la[slot];
     // the field floor (in the units of the terms: the star's constant c0m is added at the end)
     const double floor_t = (SAMPLE || !(cut2 < __builtin_inf())) ? NEG_INF : la - c0m;
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) s_tmax[kp][wave][lane] = dead ? __builtin_inf() : floor_t;
+    __syncthreads();
 
-    double ll[NPOPS];
     Best best; best.key = NEG_INF; best.mass = 0.0; best.ratio = 0.0; best.pop = 0;
     const unsigned long long g_row = SAMPLE ? (unsigned long long)(ms.row0 + w) : 0ull;
     double lw_pop[2] = {0.0, 0.0};                       // log weight of the population in the key
@@ -195,76 +206,102 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
         const double *__restrict__ const t_box2 = t_wp + L.o_box2, *__restrict__ const t_nbmin16 = t_wp + L.o_nbmin16;
         const double *__restrict__ const t_box1 = t_wp + L.o_box1, *__restrict__ const t_nbmin64 = t_wp + L.o_nbmin64;
         const int n_nodes = (iso_g[kp].n - 1) * K, n_chunks = (n_nodes + 63) >> 6;
-        double ref = floor_t, sm = 0.0;                                  // the lane's value so far: ref + log(sm)
-        double xcut = dead ? NEG_INF : fma(-2.0, ref, cut2);            // a term counts while X < xcut
-        // ---- seed pass: lanes without a reference take the best single-star term among every 16th node
-        if (__ballot(!dead && ref == NEG_INF) != 0ull && cut2 < __builtin_inf()) {
+        double ref = floor_t, sm = 0.0;                                  // this wave's share of the lane's value: ref + log(sm)
+        double tmax = dead ? __builtin_inf() : floor_t;                  // pruning reference: a term counts while it is within CUT of it
+        // ---- seed pass: lanes without a reference take the best single-star term among every 16th node (this wave: its sub-chunks)
+        if (__ballot(!dead && tmax == NEG_INF) != 0ull && cut2 < __builtin_inf()) {
             double xmin = __builtin_inf();
-            for (int u = 0; u < n_chunks * 4; ++u) {
+            for (int u = wave; u < n_chunks * 4; u += 4) {
                 const double x = row_x<NFP>(t_rows + (size_t)u * Q * 16 * NFP, t_nb[u * 16], obs, wgt);
                 xmin = __builtin_fmin(xmin, x);
             }
-            if (!dead && ref == NEG_INF) { ref = -0.5 * xmin; xcut = fma(-2.0, ref, cut2); }
+            if (!dead && tmax == NEG_INF) { ref = -0.5 * xmin; tmax = ref; s_tmax[kp][wave][lane] = tmax; }
         }
         for (int c = 0; c < n_chunks; ++c) {
-            // level 1: the chunk's 64 nodes with all their mass ratios
+            // level 1: the chunk's 64 nodes with all their mass ratios (every wave: the test is a fraction of a unit's cost)
             const double lb1 = box_bound<NFP>(t_box1 + (size_t)c * 2 * NFP, obs, wgt);
             MSTAT(0, 1);
-            if (__ballot(lb1 + t_nbmin64[c] < xcut) == 0ull) continue;
+            if (__ballot(lb1 + t_nbmin64[c] < fma(-2.0, tmax, cut2)) == 0ull) continue;
             MSTAT(1, 1);
-            for (int sub = 0; sub < 4; ++sub) {
-                const int u = c * 4 + sub;
-                const double nbm = t_nbmin16[u];
-                const double *__restrict__ const nbp = t_nb + u * 16;
-                for (int j = 0; j < Q; ++j) {
-                    // level 2: 16 nodes x one mass ratio
-                    const double lb2 = box_bound<NFP>(t_box2 + ((size_t)u * Q + j) * 2 * NFP, obs, wgt);
-                    MSTAT(2, 1);
-                    if (__ballot(lb2 + nbm < xcut) == 0ull) continue;
-                    MSTAT(3, 1);
-                    const double *__restrict__ const rowp = t_rows + ((size_t)u * Q + j) * 16 * NFP;
+            // the other waves' maxima (whatever they have published so far)
+            tmax = __builtin_fmax(__builtin_fmax(tmax, s_tmax[kp][0][lane]), __builtin_fmax(s_tmax[kp][1][lane], __builtin_fmax(s_tmax[kp][2][lane], s_tmax[kp][3][lane])));
+            double xcut = fma(-2.0, tmax, cut2);                         // a term counts while X < xcut
+            const int u = c * 4 + wave;
+            const double nbm = t_nbmin16[u];
+            const double *__restrict__ const nbp = t_nb + u * 16;
+            bool any = false;
+            for (int j = 0; j < Q; ++j) {
+                // level 2: this wave's 16 nodes x one mass ratio
+                const double lb2 = box_bound<NFP>(t_box2 + ((size_t)u * Q + j) * 2 * NFP, obs, wgt);
+                MSTAT(2, 1);
+                if (__ballot(lb2 + nbm < xcut) == 0ull) continue;
+                MSTAT(3, 1);
+                any = true;
+                const double *__restrict__ const rowp = t_rows + ((size_t)u * Q + j) * 16 * NFP;
 #pragma unroll 2
-                    for (int i = 0; i < 16; ++i) {
-                        const double x = row_x<NFP>(rowp + i * NFP, nbp[i], obs, wgt);
-                        const bool live = x < xcut;
-                        MSTAT(4, __popcll(__ballot(live)));
-                        if (live) {
-                            const double t = -0.5 * x;
-                            if (SAMPLE) {
-                                const int node = u * 16 + i;
-                                const double key = t + lw_pop[kp] + gumbel(ms.k0, ms.k1, g_row, (unsigned)orig, (unsigned long long)((long long)node * Q + j), (unsigned)kp);
-                                if (key > best.key) {
-                                    const int e = node / K, sb = node - e * K;
-                                    const double a = iso_g[kp].mass[e];
-                                    best.key = key; best.mass = fma((double)sb, (iso_g[kp].mass[e + 1] - a) / K, a);
-                                    best.ratio = (double)j / (double)Q; best.pop = kp;
-                                }
+                for (int i = 0; i < 16; ++i) {
+                    const double x = row_x<NFP>(rowp + i * NFP, nbp[i], obs, wgt);
+                    const bool live = x < xcut;
+#ifdef B9_MARG_STATS
+                    { const unsigned long long lm = __ballot(live); MSTAT(4, __popcll(lm)); }
+#endif
+                    if (live) {
+                        const double t = -0.5 * x;
+                        if (SAMPLE) {
+                            const int node = u * 16 + i;
+                            const double key = t + lw_pop[kp] + gumbel(ms.k0, ms.k1, g_row, (unsigned)orig, (unsigned long long)((long long)node * Q + j), (unsigned)kp);
+                            if (key > best.key) {
+                                const int e = node / K, sb = node - e * K;
+                                const double a = iso_g[kp].mass[e];
+                                best.key = key; best.mass = fma((double)sb, (iso_g[kp].mass[e + 1] - a) / K, a);
+                                best.ratio = (double)j / (double)Q; best.pop = kp;
                             }
-                            lse_term(t, cut2, ref, sm, xcut);
                         }
+                        lse_term(t, ref, sm, tmax);
                     }
                 }
+                xcut = fma(-2.0, tmax, cut2);
             }
+            if (any) s_tmax[kp][wave][lane] = tmax;
         }
-        ll[kp] = (sm > 0.0) ? c0m + (ref + log(sm)) : NEG_INF;
+        s_ref[kp][wave][lane] = ref; s_sm[kp][wave][lane] = sm;
     }
-    if (dead) {
-        if (!wd_stage) vals[(size_t)w * st.n_pad + slot] = 0.0;
-        return;
+    if (SAMPLE) { s_bkey[wave][lane] = best.key; s_bmass[wave][lane] = best.mass; s_bratio[wave][lane] = best.ratio; s_bpop[wave][lane] = best.pop; }
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- wave 0: merge the four shares, finish the star, sum the chunk
+    double ll[NPOPS];
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        double r = NEG_INF;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r = (s_sm[kp][k][lane] > 0.0 && s_ref[kp][k][lane] > r) ? s_ref[kp][k][lane] : r;
+        double S = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S += (s_sm[kp][k][lane] > 0.0) ? s_sm[kp][k][lane] * exp_fast(s_ref[kp][k][lane] - r) : 0.0;
+        ll[kp] = (S > 0.0) ? c0m + (r + log(S)) : NEG_INF;
     }
-    double l = ll[0];
-    if (NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; l = logaddexp(log(lam) + ll[0], log1p(-lam) + ll[NPOPS - 1]); }
-    const double v = logaddexp(la, l);
-    vals[(size_t)w * st.n_pad + slot] = v;
-    if (perstar) perstar[(size_t)w * st.n + orig] = v;
-    if (SAMPLE) {
-        const size_t o = (size_t)w * st.n + orig;
-        const bool any = best.key != NEG_INF;
-        ms.mass[o] = any ? best.mass : 0.0;
-        ms.ratio[o] = any ? best.ratio : 0.0;
-        ms.member[o] = (l == NEG_INF) ? 0.0 : exp(l - v);       // p L_cluster / (p L_cluster + (1 - p) L_field)
-        if (ms.pop) ms.pop[o] = any ? best.pop : 0;
+    double v = 0.0;
+    if (!dead) {
+        double l = ll[0];
+        if (NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; l = logaddexp(log(lam) + ll[0], log1p(-lam) + ll[NPOPS - 1]); }
+        v = logaddexp(la, l);
+        if (perstar) perstar[(size_t)w * st.n + orig] = v;
+        if (SAMPLE) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (s_bkey[k][lane] > best.key) { best.key = s_bkey[k][lane]; best.mass = s_bmass[k][lane]; best.ratio = s_bratio[k][lane]; best.pop = s_bpop[k][lane]; }
+            const size_t o = (size_t)w * st.n + orig;
+            const bool any = best.key != NEG_INF;
+            ms.mass[o] = any ? best.mass : 0.0;
+            ms.ratio[o] = any ? best.ratio : 0.0;
+            ms.member[o] = (l == NEG_INF) ? 0.0 : exp(l - v);       // p L_cluster / (p L_cluster + (1 - p) L_field)
+            if (ms.pop) ms.pop[o] = any ? best.pop : 0;
+        }
     }
+    // the chunk's partial sum (fixed order: the wave's shuffle tree; empty and WD-stage slots add 0)
+    const double tot = wave_sum(v);
+    if (lane == 0) partial[(size_t)w * partial_stride + sc] = tot;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -403,7 +440,7 @@ template <int NFP, int NPOPS, bool SAMPLE>
 __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                                                       const double *__restrict__ iso_data, long long iso_stride,
                                                       int mass_cap, const double *__restrict__ params,
-                                                      double *__restrict__ vals, double *__restrict__ perstar,
+                                                      double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
                                                       int K, MargSample ms)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), w = blockIdx.y;
@@ -415,7 +452,7 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
     double tip_min;
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
     if (!valid) {
-        if (lane == 0) { vals[(size_t)w * st.n_pad + slot] = 0.0; if (perstar) perstar[(size_t)w * st.n + orig] = NEG_INF; }
+        if (lane == 0) { partial[(size_t)w * partial_stride + (st.n_pad >> 6) + k_wd] = 0.0; if (perstar) perstar[(size_t)w * st.n + orig] = NEG_INF; }
         return;
     }
     double obs[NFP], wgt[NFP], shift[NFP];
@@ -480,7 +517,7 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
         double l = ll[0];
         if (NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; l = logaddexp(log(lam) + ll[0], log1p(-lam) + ll[NPOPS - 1]); }
         const double v = logaddexp(la, l);
-        vals[(size_t)w * st.n_pad + slot] = v;
+        partial[(size_t)w * partial_stride + (st.n_pad >> 6) + k_wd] = v;        // (a WD-stage star's value is a partial of its own)
         if (perstar) perstar[(size_t)w * st.n + orig] = v;
         if (SAMPLE) {
             const size_t o = (size_t)w * st.n + orig;

@@ -1,22 +1,43 @@
 #!/usr/bin/env python3
-"""Diagnostic (build/variants/lib_mstats.so, -DB9_MARG_STATS): how many 64-node chunks / mass-ratio iterations /
-filter evaluations the marginalised kernel executes per star."""
-import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["B9_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build/variants/lib_mstats.so")
+"""Diagnostic (build/variants/lib_mstats.so = tools/build_variant.py mstats -DB9_MARG_STATS): what the marginalised
+kernel (one lane per star; a wave = 64 slot-neighbouring stars walking the node table) executes, per wave and per
+star-eval, on the bench cluster; writes profiles/<tag>_marg_stats.json when given a tag.
+
+    python tools/marg_stats.py [tag] [n_stars] [K] [Q] [walkers]
+"""
+import os, sys, json, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["B9_HIP_LIB"] = os.path.join(ROOT, "build/variants/lib_mstats.so")
 import numpy as np
 from base_amd import abi, engine, synth
+a = sys.argv[1:]
+tag = a[0] if a and not a[0].isdigit() else None
+if tag: a = a[1:]
+n_stars, K, Q, W = (int(a[i]) if len(a) > i else d for i, d in enumerate((50000, 4, 4, 8)))
 pack_d = synth.make_pack("parsec", 8); truth = synth.default_params(pack_d)
-cl = synth.make_cluster(pack_d, 50000, seed=9003, truth=truth)
+cl = synth.make_cluster(pack_d, n_stars, seed=9003, truth=truth)
 eng = engine.Engine(abi.make_pack(pack_d), abi.make_stars(cl), synth.default_priors(pack_d, truth),
-                    abi.make_options(mode=abi.MODE_MARGINALISED, marg_iso_increm=4, marg_n_q=4))
-rows = synth.walker_params(truth, 8, seed=42, scale=0.05)
+                    abi.make_options(mode=abi.MODE_MARGINALISED, marg_iso_increm=K, marg_n_q=Q))
+rows = synth.walker_params(truth, W, seed=42, scale=0.05)
 buf = (C.c_ulonglong * 8)()
 eng.lib.b9_debug_marg_stats(buf, 1)
 eng.logpost(rows)
 eng.lib.b9_debug_marg_stats(buf, 1)
-n = 8 * 50000
-names = ["chunks visited", "chunks past the chunk bound", "chunks with a live node", "chunks entering the mass-ratio loop",
-         "mass-ratio iterations", "filter evaluations in them", "lanes wanting the mass-ratio loop (sum)"]
+n_evals = W * n_stars
+n_waves = W * ((n_stars + 63) // 64 + 1)          # (binary and single runs each end in a partial chunk)
+names = ["level-1 boxes tested (64-node chunks)", "chunks entered", "level-2 boxes tested (16 nodes x 1 mass ratio)",
+         "units evaluated (16 terms each)", "live lane-terms (terms that enter a star's sum)"]
+out = {"n_stars": n_stars, "walkers": W, "K": K, "Q": Q, "nodes_per_star": (eng.max_eep() - 1) * K * Q}
 for k, nm in enumerate(names):
-    print(f"{nm:45s} {buf[k]/n:10.2f} per star")
+    print(f"{nm:55s} {buf[k]/n_waves:10.1f} per wave   {buf[k]/n_evals:9.2f} per star-eval")
+    out[nm] = {"per_wave": buf[k] / n_waves, "per_star_eval": buf[k] / n_evals}
+terms_wave = 16.0 * buf[3] / n_waves
+print(f"terms evaluated per wave {terms_wave:.0f} (x 64 lanes = {terms_wave:.0f} per star-eval); live share of the lane-terms {buf[4] / (16.0 * buf[3] * 64):.3f}")
+out["terms_evaluated_per_wave"] = terms_wave
+out["live_terms_per_star_eval"] = buf[4] / n_evals
+out["live_share"] = buf[4] / (16.0 * buf[3] * 64)
+if tag:
+    p = os.path.join(ROOT, "profiles", f"{tag}_marg_stats.json")
+    json.dump(out, open(p, "w"), indent=1)
+    print("wrote", p)
