@@ -290,6 +290,33 @@ int build_stars(b9_ctx *ctx)
         if (wd_slot.empty()) wd_slot.push_back(0);
         if ((rc = upload(ctx, ctx->star_allocs, wd_slot.data(), wd_slot.size(), &st.wd_slot))) return rc;
     }
+    {
+        // dispatch order of the marginalised kernel's chunks: descending photometric spread (10th to 90th percentile of the
+        // chunk's observations, summed over the filters -- robust against the few field stars every chunk holds)
+        const int n_sc = n_pad / 64;
+        std::vector<double> spread(n_sc, -1.0);
+        std::vector<double> v;
+        for (int c = 0; c < n_sc; ++c) {
+            double sp = 0.0;
+            bool any = false;
+            for (int f = 0; f < nf; ++f) {
+                v.clear();
+                for (int j = 0; j < 64; ++j) {
+                    const int i = c * 64 + j;
+                    if (slot[i] >= 0 && w[B9_SIDX(nfp, f, i)] > 0.0 && std::isfinite(obs[B9_SIDX(nfp, f, i)])) v.push_back(obs[B9_SIDX(nfp, f, i)]);
+                }
+                if (v.size() < 2) continue;
+                std::sort(v.begin(), v.end());
+                sp += v[(v.size() - 1) * 9 / 10] - v[(v.size() - 1) / 10];
+                any = true;
+            }
+            if (any) spread[c] = sp;
+        }
+        std::vector<int> order(n_sc);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return spread[a] > spread[b]; });
+        if ((rc = upload(ctx, ctx->star_allocs, order.data(), order.size(), &st.marg_order))) return rc;
+    }
     ctx->st = st;
     ctx->n_wd_stage = 0;
     for (int i = 0; i < n; ++i) ctx->n_wd_stage += h.stage[i] == B9_STAGE_WD;

@@ -74,6 +74,10 @@ struct DevStars {
     // them in a launch of their own (k_star_marg_wd)
     int n_wd;
     const int *wd_slot;              // [max(1, n_wd)]
+    // Marginalised mode: the order in which the 64-star chunks are dispatched -- most expensive first (a chunk costs what the
+    // UNION of its stars' node windows holds, which grows with the stars' photometric spread: giants), so that the launch
+    // does not end on its heaviest workgroups.  Speed only.
+    const int *marg_order;           // [n_pad / 64]
 };
 
 #define B9_SIDX(nfp, f, i) ((((size_t)((i) >> 6) * (nfp)) + (f)) * 64 + ((i) & 63))

@@ -79,6 +79,15 @@ extern "C" int b9_debug_marg_stats(unsigned long long *out, int clear)
 #else
 #define MSTAT(k, v) do {} while (0)
 #endif
+#ifdef B9_MARG_LIFE       // diagnostic build only (tools/marg_life.py): start / end of every workgroup, units evaluated by its wave 0
+__device__ unsigned long long g_marg_life[16384 * 4];
+#define MLIFE(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_marg_life[blockIdx.x * 4 + (k)] = (v); } while (0)
+#define MLIFE_UNIT() do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_marg_life[blockIdx.x * 4 + 2] += 1; } while (0)
+extern "C" int b9_debug_marg_life(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_marg_life), sizeof(unsigned long long) * 16384 * 4); }
+#else
+#define MLIFE(k, v) do {} while (0)
+#define MLIFE_UNIT() do {} while (0)
+#endif
 
 // lower bound of sum_f w_f (C_f - obs_f)^2 over every row with lo_f <= C_f <= hi_f (box = {lo[NFP], hi[NFP]}, wave-uniform)
 template <int NFP>
@@ -146,7 +155,10 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
 // per 64 stars the launch lasted as long as its heaviest wave -- a chunk of giants whose windows barely overlap walks
 // 2000 terms against an average of 240; the mean wave lived a quarter of the launch.)  The waves share their running
 // maxima through LDS -- plain reads and writes of a double per lane, no barrier: any earlier value of another wave's
-// maximum is still a valid pruning reference -- so each prunes as if it had seen the whole window.
+// maximum is still a valid pruning reference -- so each prunes as if it had seen the whole window.  The level-1 boxes are
+// dealt over the waves too (wave k tests chunks k, k + 4, ...) and the outcome travels as a bit mask in LDS.
+#define B9_MARG_MASK_WORDS 16        // level-1 outcomes of up to 1024 chunks go through the mask; later chunks are tested by every wave
+
 template <int NFP, int NPOPS, bool SAMPLE>
 __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE))
 void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
@@ -154,20 +166,24 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                  int mass_cap, const double *__restrict__ params,
                  double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
                  int K, int Q, MargSample ms, const double *__restrict__ tab, MargLayout L,
-                 int n_walkers, int chunks_per_xcd, double cut2)
+                 int n_walkers, double cut2)
 {
     __shared__ double s_tmax[NPOPS][4][64], s_ref[NPOPS][4][64], s_sm[NPOPS][4][64];
+    __shared__ unsigned long long s_mask[NPOPS][B9_MARG_MASK_WORDS];
     __shared__ double s_bkey[SAMPLE ? 4 : 1][64], s_bmass[SAMPLE ? 4 : 1][64], s_bratio[SAMPLE ? 4 : 1][64];
     __shared__ int s_bpop[SAMPLE ? 4 : 1][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // 1-D grid of 8 * chunks_per_xcd * n_walkers workgroups; ids are dealt round-robin over the 8 XCDs.  XCD x takes
-    // the star chunks [x, x + 1) * chunks_per_xcd -- a contiguous mass range, so it reads that range of every walker's table
-    // (plus the windows' fringes) into its L2, not the whole of it -- and inside an XCD the walkers of one star chunk are
-    // neighbours in dispatch order: the chunk's star data is fetched from HBM once.  (Speed only; any placement is correct.)
+    MLIFE(0, __builtin_amdgcn_s_memrealtime());
+    // 1-D grid of ceil(chunks / 8) * 8 * n_walkers workgroups; ids are dealt round-robin over the 8 XCDs.  Dispatch position
+    // p = id / n_walkers' share -> star chunk marg_order[p]: most expensive chunks first, neighbours in the order on different
+    // XCDs (a contiguous share per XCD left the XCD holding the giants working alone for the launch's second half), and
+    // inside an XCD the walkers of one star chunk are neighbours in dispatch order: the chunk's star data is fetched from
+    // HBM once.  (Speed only; any placement is correct.)
     const int xcd = blockIdx.x & 7, i_x = blockIdx.x >> 3;
-    const int sc_local = i_x / n_walkers, w = i_x - sc_local * n_walkers;
-    const int sc = xcd * chunks_per_xcd + sc_local;
-    if (sc_local >= chunks_per_xcd || sc * 64 >= st.n_pad) return;
+    const int p_local = i_x / n_walkers, w = i_x - p_local * n_walkers;
+    const int pos = p_local * 8 + xcd;
+    if (pos * 64 >= st.n_pad) return;
+    const int sc = st.marg_order[pos];
     const int slot = sc * 64 + lane;
     const double *par = params + (size_t)w * B9_NPARAM;
     IsoView<NFP> iso_g[NPOPS];
@@ -190,8 +206,41 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     const double c0m = st.c0m[slot], la = st.la[slot];
     // the field floor (in the units of the terms: the star's constant c0m is added at the end)
     const double floor_t = (SAMPLE || !(cut2 < __builtin_inf())) ? NEG_INF : la - c0m;
+    if (threadIdx.x < NPOPS * B9_MARG_MASK_WORDS) (&s_mask[0][0])[threadIdx.x] = 0ull;
+
+    // ---- per population: the pruning reference every wave starts from, then the level-1 boxes of this wave's chunks
+    double ref[NPOPS], sm[NPOPS], tmax[NPOPS];
 #pragma unroll
-    for (int kp = 0; kp < NPOPS; ++kp) s_tmax[kp][wave][lane] = dead ? __builtin_inf() : floor_t;
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        ref[kp] = floor_t; sm[kp] = 0.0;                                  // this wave's share of the lane's value: ref + log(sm)
+        tmax[kp] = dead ? __builtin_inf() : floor_t;                      // a term counts while it is within CUT of tmax
+        // seed pass: lanes without a reference take the best single-star term among every 16th node (this wave: its sub-chunks)
+        if (__ballot(!dead && tmax[kp] == NEG_INF) != 0ull && cut2 < __builtin_inf()) {
+            const double *__restrict__ const t_wp = tab + (size_t)(w * NPOPS + kp) * L.total;
+            const int n_units = (((iso_g[kp].n - 1) * K + 63) >> 6) * 4;
+            double xmin = __builtin_inf();
+            for (int u = wave; u < n_units; u += 4) {
+                const double x = row_x<NFP>(t_wp + L.o_rows + (size_t)u * Q * 16 * NFP, t_wp[L.o_nb + u * 16], obs, wgt);
+                xmin = __builtin_fmin(xmin, x);
+            }
+            if (!dead && tmax[kp] == NEG_INF) { ref[kp] = -0.5 * xmin; tmax[kp] = ref[kp]; }
+        }
+        s_tmax[kp][wave][lane] = tmax[kp];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        const double *__restrict__ const t_wp = tab + (size_t)(w * NPOPS + kp) * L.total;
+        const int n_chunks = ((iso_g[kp].n - 1) * K + 63) >> 6;
+        tmax[kp] = __builtin_fmax(__builtin_fmax(tmax[kp], s_tmax[kp][0][lane]), __builtin_fmax(s_tmax[kp][1][lane], __builtin_fmax(s_tmax[kp][2][lane], s_tmax[kp][3][lane])));
+        const double xcut = fma(-2.0, tmax[kp], cut2);
+        const int c_end = n_chunks < 64 * B9_MARG_MASK_WORDS ? n_chunks : 64 * B9_MARG_MASK_WORDS;
+        for (int c = wave; c < c_end; c += 4) {
+            const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, obs, wgt);
+            MSTAT(0, 1);
+            if (__ballot(lb1 + t_wp[L.o_nbmin64 + c] < xcut) != 0ull && lane == 0) atomicOr(&s_mask[kp][c >> 6], 1ull << (c & 63));
+        }
+    }
     __syncthreads();
 
     Best best; best.key = NEG_INF; best.mass = 0.0; best.ratio = 0.0; best.pop = 0;
@@ -204,28 +253,13 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
         const double *__restrict__ const t_wp = tab + (size_t)(w * NPOPS + kp) * L.total;
         const double *__restrict__ const t_rows = t_wp + L.o_rows, *__restrict__ const t_nb = t_wp + L.o_nb;
         const double *__restrict__ const t_box2 = t_wp + L.o_box2, *__restrict__ const t_nbmin16 = t_wp + L.o_nbmin16;
-        const double *__restrict__ const t_box1 = t_wp + L.o_box1, *__restrict__ const t_nbmin64 = t_wp + L.o_nbmin64;
-        const int n_nodes = (iso_g[kp].n - 1) * K, n_chunks = (n_nodes + 63) >> 6;
-        double ref = floor_t, sm = 0.0;                                  // this wave's share of the lane's value: ref + log(sm)
-        double tmax = dead ? __builtin_inf() : floor_t;                  // pruning reference: a term counts while it is within CUT of it
-        // ---- seed pass: lanes without a reference take the best single-star term among every 16th node (this wave: its sub-chunks)
-        if (__ballot(!dead && tmax == NEG_INF) != 0ull && cut2 < __builtin_inf()) {
-            double xmin = __builtin_inf();
-            for (int u = wave; u < n_chunks * 4; u += 4) {
-                const double x = row_x<NFP>(t_rows + (size_t)u * Q * 16 * NFP, t_nb[u * 16], obs, wgt);
-                xmin = __builtin_fmin(xmin, x);
-            }
-            if (!dead && tmax == NEG_INF) { ref = -0.5 * xmin; tmax = ref; s_tmax[kp][wave][lane] = tmax; }
-        }
-        for (int c = 0; c < n_chunks; ++c) {
-            // level 1: the chunk's 64 nodes with all their mass ratios (every wave: the test is a fraction of a unit's cost)
-            const double lb1 = box_bound<NFP>(t_box1 + (size_t)c * 2 * NFP, obs, wgt);
-            MSTAT(0, 1);
-            if (__ballot(lb1 + t_nbmin64[c] < fma(-2.0, tmax, cut2)) == 0ull) continue;
+        const int n_chunks = ((iso_g[kp].n - 1) * K + 63) >> 6;
+        // one chunk that passed level 1: this wave's sub-chunk, mass ratio by mass ratio
+        auto chunk = [&](int c) {
             MSTAT(1, 1);
             // the other waves' maxima (whatever they have published so far)
-            tmax = __builtin_fmax(__builtin_fmax(tmax, s_tmax[kp][0][lane]), __builtin_fmax(s_tmax[kp][1][lane], __builtin_fmax(s_tmax[kp][2][lane], s_tmax[kp][3][lane])));
-            double xcut = fma(-2.0, tmax, cut2);                         // a term counts while X < xcut
+            tmax[kp] = __builtin_fmax(__builtin_fmax(tmax[kp], s_tmax[kp][0][lane]), __builtin_fmax(s_tmax[kp][1][lane], __builtin_fmax(s_tmax[kp][2][lane], s_tmax[kp][3][lane])));
+            double xcut = fma(-2.0, tmax[kp], cut2);                      // a term counts while X < xcut
             const int u = c * 4 + wave;
             const double nbm = t_nbmin16[u];
             const double *__restrict__ const nbp = t_nb + u * 16;
@@ -236,6 +270,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                 MSTAT(2, 1);
                 if (__ballot(lb2 + nbm < xcut) == 0ull) continue;
                 MSTAT(3, 1);
+                MLIFE_UNIT();
                 any = true;
                 const double *__restrict__ const rowp = t_rows + ((size_t)u * Q + j) * 16 * NFP;
 #pragma unroll 2
@@ -257,14 +292,24 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                                 best.ratio = (double)j / (double)Q; best.pop = kp;
                             }
                         }
-                        lse_term(t, ref, sm, tmax);
+                        lse_term(t, ref[kp], sm[kp], tmax[kp]);
                     }
                 }
-                xcut = fma(-2.0, tmax, cut2);
+                xcut = fma(-2.0, tmax[kp], cut2);
             }
-            if (any) s_tmax[kp][wave][lane] = tmax;
+            if (any) s_tmax[kp][wave][lane] = tmax[kp];
+        };
+        const int n_words = (n_chunks + 63) >> 6;
+        for (int wi = 0; wi < n_words && wi < B9_MARG_MASK_WORDS; ++wi) {
+            unsigned long long m = s_mask[kp][wi];
+            m = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)m);
+            while (m) { const int c = wi * 64 + __builtin_ctzll(m); m &= m - 1; chunk(c); }
         }
-        s_ref[kp][wave][lane] = ref; s_sm[kp][wave][lane] = sm;
+        for (int c = 64 * B9_MARG_MASK_WORDS; c < n_chunks; ++c) {      // (tables longer than the mask: every wave tests)
+            const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, obs, wgt);
+            if (__ballot(lb1 + t_wp[L.o_nbmin64 + c] < fma(-2.0, tmax[kp], cut2)) != 0ull) chunk(c);
+        }
+        s_ref[kp][wave][lane] = ref[kp]; s_sm[kp][wave][lane] = sm[kp];
     }
     if (SAMPLE) { s_bkey[wave][lane] = best.key; s_bmass[wave][lane] = best.mass; s_bratio[wave][lane] = best.ratio; s_bpop[wave][lane] = best.pop; }
     __syncthreads();
@@ -302,6 +347,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     // the chunk's partial sum (fixed order: the wave's shuffle tree; empty and WD-stage slots add 0)
     const double tot = wave_sum(v);
     if (lane == 0) partial[(size_t)w * partial_stride + sc] = tot;
+    MLIFE(1, __builtin_amdgcn_s_memrealtime());
 }
 
 // ------------------------------------------------------------------------------------------
