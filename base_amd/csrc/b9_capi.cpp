@@ -291,19 +291,58 @@ int build_stars(b9_ctx *ctx)
         if ((rc = upload(ctx, ctx->star_allocs, wd_slot.data(), wd_slot.size(), &st.wd_slot))) return rc;
     }
     {
-        // dispatch order of the marginalised kernel's chunks: descending photometric spread (10th to 90th percentile of the
-        // chunk's observations, summed over the filters -- robust against the few field stars every chunk holds)
-        const int n_sc = n_pad / 64;
-        std::vector<double> spread(n_sc, -1.0);
-        std::vector<double> v;
-        for (int c = 0; c < n_sc; ++c) {
+        // The marginalised kernel's copy (DevStars::mg_*): stars other than WD-stage ones, sorted by the first principal
+        // component of their magnitudes (an unused filter counts as its column's mean; power iteration on the covariance).
+        std::vector<int> ms;
+        for (int s = 0; s < n; ++s) if (h.stage[s] != B9_STAGE_WD) ms.push_back(s);
+        const int n_ms = (int)ms.size();
+        std::vector<double> mean(nf, 0.0), cnt(nf, 0.0);
+        auto used = [&](int s, int f) { const double sg = h.sigma[(size_t)s * nf + f], o = h.obs[(size_t)s * nf + f]; return sg > 0.0 && std::isfinite(o); };
+        for (int s : ms) for (int f = 0; f < nf; ++f) if (used(s, f)) { mean[f] += h.obs[(size_t)s * nf + f]; cnt[f] += 1.0; }
+        for (int f = 0; f < nf; ++f) mean[f] = cnt[f] > 0.0 ? mean[f] / cnt[f] : 0.0;
+        std::vector<double> cov((size_t)nf * nf, 0.0), x(nf);
+        for (int s : ms) {
+            for (int f = 0; f < nf; ++f) x[f] = used(s, f) ? h.obs[(size_t)s * nf + f] - mean[f] : 0.0;
+            for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) cov[(size_t)a * nf + b] += x[a] * x[b];
+        }
+        std::vector<double> pc(nf, 1.0), nx(nf);
+        for (int it = 0; it < 200; ++it) {
+            double nrm = 0.0;
+            for (int a = 0; a < nf; ++a) { double t = 0.0; for (int b = 0; b < nf; ++b) t += cov[(size_t)a * nf + b] * pc[b]; nx[a] = t; nrm += t * t; }
+            if (!(nrm > 0.0)) break;                                     // (all magnitudes equal: any order will do)
+            nrm = std::sqrt(nrm);
+            for (int a = 0; a < nf; ++a) pc[a] = nx[a] / nrm;
+        }
+        std::vector<double> key(n, 0.0);
+        // key = the star's coefficient along that component, least squares over the filters it HAS (a missing filter must not
+        // read as "average brightness": the star would land among strangers and widen their chunk's union)
+        for (int s : ms) {
+            double t = 0.0, nn = 0.0;
+            for (int f = 0; f < nf; ++f) if (used(s, f)) { t += (h.obs[(size_t)s * nf + f] - mean[f]) * pc[f]; nn += pc[f] * pc[f]; }
+            key[s] = nn > 0.0 ? t / nn : 0.0;
+        }
+        std::stable_sort(ms.begin(), ms.end(), [&](int a, int b) { return key[a] < key[b]; });
+        const int n_mc = std::max(1, (n_ms + 63) / 64), mg_pad = n_mc * 64;
+        std::vector<double> mg_obs((size_t)nfp * mg_pad, 0.0), mg_w((size_t)nfp * mg_pad, 0.0), mg_c0m(mg_pad, 0.0), mg_la(mg_pad, -INFINITY);
+        std::vector<int> mg_perm(mg_pad, -1);
+        std::vector<int> slot_of(n, -1);
+        for (int i = 0; i < n_pad; ++i) if (slot[i] >= 0) slot_of[slot[i]] = i;
+        for (int k = 0; k < n_ms; ++k) {
+            const int i = slot_of[ms[k]];
+            for (int f = 0; f < nfp; ++f) { mg_obs[B9_SIDX(nfp, f, k)] = obs[B9_SIDX(nfp, f, i)]; mg_w[B9_SIDX(nfp, f, k)] = w[B9_SIDX(nfp, f, i)]; }
+            mg_c0m[k] = c0m[i]; mg_la[k] = la[i]; mg_perm[k] = ms[k];
+        }
+        // dispatch order of the chunks: descending photometric spread (10th to 90th percentile of the chunk's observations,
+        // summed over the filters -- robust against the few field stars every chunk holds)
+        std::vector<double> spread(n_mc, -1.0), v;
+        for (int c = 0; c < n_mc; ++c) {
             double sp = 0.0;
             bool any = false;
             for (int f = 0; f < nf; ++f) {
                 v.clear();
                 for (int j = 0; j < 64; ++j) {
-                    const int i = c * 64 + j;
-                    if (slot[i] >= 0 && w[B9_SIDX(nfp, f, i)] > 0.0 && std::isfinite(obs[B9_SIDX(nfp, f, i)])) v.push_back(obs[B9_SIDX(nfp, f, i)]);
+                    const int k = c * 64 + j;
+                    if (mg_perm[k] >= 0 && mg_w[B9_SIDX(nfp, f, k)] > 0.0) v.push_back(mg_obs[B9_SIDX(nfp, f, k)]);
                 }
                 if (v.size() < 2) continue;
                 std::sort(v.begin(), v.end());
@@ -312,9 +351,15 @@ int build_stars(b9_ctx *ctx)
             }
             if (any) spread[c] = sp;
         }
-        std::vector<int> order(n_sc);
+        std::vector<int> order(n_mc);
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return spread[a] > spread[b]; });
+        st.mg_pad = mg_pad;
+        if ((rc = upload(ctx, ctx->star_allocs, mg_obs.data(), mg_obs.size(), &st.mg_obs))) return rc;
+        if ((rc = upload(ctx, ctx->star_allocs, mg_w.data(), mg_w.size(), &st.mg_w))) return rc;
+        if ((rc = upload(ctx, ctx->star_allocs, mg_c0m.data(), mg_c0m.size(), &st.mg_c0m))) return rc;
+        if ((rc = upload(ctx, ctx->star_allocs, mg_la.data(), mg_la.size(), &st.mg_la))) return rc;
+        if ((rc = upload(ctx, ctx->star_allocs, mg_perm.data(), mg_perm.size(), &st.mg_perm))) return rc;
         if ((rc = upload(ctx, ctx->star_allocs, order.data(), order.size(), &st.marg_order))) return rc;
     }
     ctx->st = st;
@@ -867,7 +912,7 @@ static Bufs buffer_set(const b9_ctx *ctx, int set)
 // (marginalised mode: one per 64-star chunk -- the star kernel sums a chunk's values in a fixed order -- and one per WD-stage star)
 static int partial_count(const b9_ctx *ctx, const Plan &plan)
 {
-    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.n_pad / 64 + ctx->st.n_wd : plan.n_groups * 4 + ctx->heavy_parts;
+    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.mg_pad / 64 + ctx->st.n_wd : plan.n_groups * 4 + ctx->heavy_parts;
 }
 
 // doubles between two walkers' partial rows (room for either mode's row)

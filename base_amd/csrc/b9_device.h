@@ -74,10 +74,18 @@ struct DevStars {
     // them in a launch of their own (k_star_marg_wd)
     int n_wd;
     const int *wd_slot;              // [max(1, n_wd)]
-    // Marginalised mode: the order in which the 64-star chunks are dispatched -- most expensive first (a chunk costs what the
-    // UNION of its stars' node windows holds, which grows with the stars' photometric spread: giants), so that the launch
-    // does not end on its heaviest workgroups.  Speed only.
-    const int *marg_order;           // [n_pad / 64]
+    // Marginalised mode: its own copy of the stars (WD-stage stars excluded: they are k_star_marg_wd's), in 64-star chunks of
+    // stars that are PHOTOMETRIC neighbours -- sorted by the first principal component of the catalogue's magnitudes.  A wave
+    // of k_star_marg evaluates 64 stars against the union of the node windows that matter for them, so its cost is that
+    // union's size: neighbours in brightness share their windows (neighbours in catalogue mass do not: a binary sits with
+    // singles of another brightness, and the catalogue's masses are only hints in this mode).  Speed only.
+    int mg_pad;                      // slots of the copy (whole chunks)
+    const double *mg_obs, *mg_w;     // [mg_pad / 64][nfp][64]
+    const double *mg_c0m, *mg_la;    // [mg_pad]
+    const int *mg_perm;              // [mg_pad] original index of the star, -1 = empty
+    // ... and the order in which the chunks are dispatched: widest photometric spread (= largest union) first, so that the
+    // launch does not end on its heaviest workgroups
+    const int *marg_order;           // [mg_pad / 64]
 };
 
 #define B9_SIDX(nfp, f, i) ((((size_t)((i) >> 6) * (nfp)) + (f)) * 64 + ((i) & 63))

@@ -192,7 +192,7 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     hipLaunchKernelGGL((k_marg_table<NFP>), dim3(n_walkers * NPOPS, L.n_chunks), dim3(256), lds, stream, pk, hdr, iso_data,
                        iso_stride, mass_cap, NPOPS, d_params, K, Q, tab, L);
     // the stars: one workgroup (four waves sharing the node table's sub-chunks) per (64-star chunk, walker), dispatched in DevStars::marg_order
-    const int cpx = (st.n_pad / 64 + 7) / 8;
+    const int cpx = (st.mg_pad / 64 + 7) / 8;
     const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
     hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE>), dim3(8 * cpx * n_walkers), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
                        mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2);

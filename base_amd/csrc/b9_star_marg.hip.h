@@ -182,28 +182,26 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     const int xcd = blockIdx.x & 7, i_x = blockIdx.x >> 3;
     const int p_local = i_x / n_walkers, w = i_x - p_local * n_walkers;
     const int pos = p_local * 8 + xcd;
-    if (pos * 64 >= st.n_pad) return;
+    if (pos * 64 >= st.mg_pad) return;
     const int sc = st.marg_order[pos];
-    const int slot = sc * 64 + lane;
+    const int slot = sc * 64 + lane;                                // (slot of the marginalised mode's own copy: DevStars::mg_*)
     const double *par = params + (size_t)w * B9_NPARAM;
     IsoView<NFP> iso_g[NPOPS];
     double tip_min;
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso_g, tip_min);
-    const int orig = st.perm[slot];
-    const int flags = st.flags[slot];
-    const bool wd_stage = (flags >> 8) == B9_STAGE_WD;             // WD-stage stars: k_star_marg_wd (their own launch)
+    const int orig = st.mg_perm[slot];
     if (!valid) {
         if (wave == 0) {
             if (lane == 0) partial[(size_t)w * partial_stride + sc] = 0.0;
-            if (perstar && orig >= 0 && !wd_stage) perstar[(size_t)w * st.n + orig] = NEG_INF;
+            if (perstar && orig >= 0) perstar[(size_t)w * st.n + orig] = NEG_INF;
         }
         return;
     }
-    const bool dead = orig < 0 || wd_stage;
+    const bool dead = orig < 0;
     double obs[NFP], wgt[NFP];
 #pragma unroll
-    for (int f = 0; f < NFP; ++f) { obs[f] = st.obs[B9_SIDX(NFP, f, slot)]; wgt[f] = st.w[B9_SIDX(NFP, f, slot)]; }
-    const double c0m = st.c0m[slot], la = st.la[slot];
+    for (int f = 0; f < NFP; ++f) { obs[f] = st.mg_obs[B9_SIDX(NFP, f, slot)]; wgt[f] = st.mg_w[B9_SIDX(NFP, f, slot)]; }
+    const double c0m = st.mg_c0m[slot], la = st.mg_la[slot];
     // the field floor (in the units of the terms: the star's constant c0m is added at the end)
     const double floor_t = (SAMPLE || !(cut2 < __builtin_inf())) ? NEG_INF : la - c0m;
     if (threadIdx.x < NPOPS * B9_MARG_MASK_WORDS) (&s_mask[0][0])[threadIdx.x] = 0ull;
@@ -344,7 +342,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
             if (ms.pop) ms.pop[o] = any ? best.pop : 0;
         }
     }
-    // the chunk's partial sum (fixed order: the wave's shuffle tree; empty and WD-stage slots add 0)
+    // the chunk's partial sum (fixed order: the wave's shuffle tree; empty slots add 0)
     const double tot = wave_sum(v);
     if (lane == 0) partial[(size_t)w * partial_stride + sc] = tot;
     MLIFE(1, __builtin_amdgcn_s_memrealtime());
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
     double tip_min;
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
     if (!valid) {
-        if (lane == 0) { partial[(size_t)w * partial_stride + (st.n_pad >> 6) + k_wd] = 0.0; if (perstar) perstar[(size_t)w * st.n + orig] = NEG_INF; }
+        if (lane == 0) { partial[(size_t)w * partial_stride + (st.mg_pad >> 6) + k_wd] = 0.0; if (perstar) perstar[(size_t)w * st.n + orig] = NEG_INF; }
         return;
     }
     double obs[NFP], wgt[NFP], shift[NFP];
@@ -563,7 +561,7 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
         double l = ll[0];
         if (NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; l = logaddexp(log(lam) + ll[0], log1p(-lam) + ll[NPOPS - 1]); }
         const double v = logaddexp(la, l);
-        partial[(size_t)w * partial_stride + (st.n_pad >> 6) + k_wd] = v;        // (a WD-stage star's value is a partial of its own)
+        partial[(size_t)w * partial_stride + (st.mg_pad >> 6) + k_wd] = v;        // (a WD-stage star's value is a partial of its own)
         if (perstar) perstar[(size_t)w * st.n + orig] = v;
         if (SAMPLE) {
             const size_t o = (size_t)w * st.n + orig;

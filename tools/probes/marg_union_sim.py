@@ -64,3 +64,48 @@ print("union over a 64-star wave, (node, j) terms: mean %.0f  max %d   (of %d)" 
 print("  with the field-star floor:                mean %.0f  max %d" % (uf.mean(), uf.max()))
 print("  primary nodes in the union (any j):       mean %.0f  max %d" % (up.mean(), up.max()))
 print("  64-node chunks in the union:              mean %.2f  max %d" % (uc.mean(), uc.max()))
+
+# ---- unit-granular (16 nodes x 1 mass ratio) unions under different slot orders
+def unions(order_idx, label):
+    ob, sg, pr = cl["obs"][order_idx], cl["sigma"][order_idx], cl["clust_prior"][order_idx]
+    ww = np.where(sg > 0, 1.0 / np.maximum(sg, 1e-30) ** 2, 0.0)
+    gg = np.where(sg > 0, -0.5 * np.log(2 * np.pi * np.maximum(sg, 1e-30) ** 2), 0.0).sum(1)
+    la_ = np.log1p(-pr) + log_fs; c0 = np.log(pr) + gg
+    tot_units, tot_live, n_ch = 0, 0, 0
+    per = []
+    for c0i in range(0, len(order_idx), 64):
+        sl = slice(c0i, min(c0i + 64, len(order_idx)))
+        dd = comb[None] - ob[sl, None, None, :]
+        chi = (ww[sl, None, None, :] * dd * dd).sum(-1)
+        term = base[None, None, :] - 0.5 * chi
+        best = term.reshape(term.shape[0], -1).max(1)
+        ref = np.maximum(best, la_[sl] - c0[sl])
+        want = term >= (ref - CUT)[:, None, None]                # [star, j, node]
+        any_ = want.any(0)                                        # [j, node]
+        pad = (-N) % 16
+        u = np.pad(any_, ((0, 0), (0, pad))).reshape(Q, -1, 16).any(-1)
+        per.append(u.sum()); tot_live += want.sum(); n_ch += 1
+    per = np.array(per)
+    print(f"{label:40s} units/chunk mean {per.mean():6.1f} p90 {np.percentile(per,90):5.0f} max {per.max():4d}; live share {tot_live / (per.sum() * 16 * 64):.3f}")
+    return per
+
+isb = q > 0
+sing = np.where(~isb)[0]; binr = np.where(isb)[0]
+o_s = sing[np.argsort(cl["mass1"][sing])]; o_b = binr[np.argsort(cl["mass1"][binr])]
+pb = unions(o_b, "binaries by mass"); ps = unions(o_s, "singles by mass")
+jb = np.minimum(np.round(q[binr] * Q).astype(int), Q - 1)
+o_b2 = binr[np.lexsort((cl["mass1"][binr], jb))]
+unions(o_b2, "binaries by (round(q Q), mass)")
+alls = np.argsort(cl["mass1"]); unions(alls, "all stars by mass (no split)")
+vmag = cl["obs"][:, 2]; unions(np.argsort(vmag), "all stars by observed magnitude, filter 2")
+ob = cl["obs"]; sgm = cl["sigma"]
+valid = sgm > 0
+meanmag = np.where(valid, ob, 0).sum(1) / np.maximum(valid.sum(1), 1)
+unions(np.argsort(meanmag), "by mean magnitude over valid filters")
+for f in (0, 4, 7): unions(np.argsort(ob[:, f]), f"by observed magnitude, filter {f}")
+X = ob - ob.mean(0); u_, s_, vt = np.linalg.svd(X[valid.all(1)], full_matrices=False)
+unions(np.argsort(X @ vt[0]), "by first principal component")
+# two-key: coarse magnitude bins, colour inside (snake)
+col = ob[:, 0] - ob[:, 7]
+mb = np.floor((meanmag - meanmag.min()) / 0.05).astype(int)
+unions(np.lexsort((col, mb)), "0.05-mag bins of mean magnitude, colour inside")
