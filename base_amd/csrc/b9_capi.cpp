@@ -90,7 +90,7 @@ struct b9_ctx {
     bool two_launch_steps = false;   // b9_tuning.two_launch_steps: the derive + star launch pair per step also in given-mass mode
     bool contiguous_tiles = false;   // b9_tuning.contiguous_tiles: a hot workgroup's tiles are consecutive even in a one-round plan
     bool plan_debug = false;         // b9_tuning.plan_debug: print the fused step's launch plan to stderr when it changes
-    bool chunk_bounds = true;        // marginalised kernel: chunk-level pruning table (b9_tuning.no_chunk_bounds turns it off)
+    bool marg_prune = true;          // marginalised kernel: field floor + box pruning (b9_tuning.marg_no_pruning turns both off)
     int heavy_parts_fixed = 0;       // b9_tuning.heavy_parts: 0 = sized from the catalogue (check_ready)
     int tree_depth = 0;              // b9_tuning.tree_depth: 0 = automatic
     int tree_blocks_per_cu = 0, tree_occ_key = -1;   // k_mcmc_tree workgroups per CU, and the key it was queried for
@@ -508,7 +508,7 @@ void apply_tuning(b9_ctx *ctx, const b9_tuning &t)
     ctx->walkers_per_lane = t.walkers_per_lane >= 2 ? 2 : 1;
     ctx->contiguous_tiles = t.contiguous_tiles != 0;
     ctx->two_launch_steps = t.two_launch_steps != 0;
-    ctx->chunk_bounds = t.no_chunk_bounds == 0;
+    ctx->marg_prune = t.marg_no_pruning == 0;
     ctx->timing_group = t.timing_group > 0 ? t.timing_group : 8;
     ctx->plan_debug = t.plan_debug != 0;
     ctx->tree_depth = std::max(0, std::min(B9_TREE_MAX_DEPTH, t.tree_depth));
@@ -533,7 +533,7 @@ bool tuning_from_env(b9_tuning *t)
     num("B9_WALKERS_PER_LANE", &t->walkers_per_lane);
     num("B9_CONTIGUOUS_TILES", &t->contiguous_tiles);
     num("B9_TWO_LAUNCH_STEPS", &t->two_launch_steps);
-    num("B9_NO_CHUNK_BOUNDS", &t->no_chunk_bounds);
+    num("B9_MARG_NO_PRUNING", &t->marg_no_pruning);
     num("B9_TIMING_GROUP", &t->timing_group);
     num("B9_PLAN_DEBUG", &t->plan_debug);
     num("B9_TREE_DEPTH", &t->tree_depth);
@@ -944,7 +944,7 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
         const int rc = ensure_marg_table(ctx, n_walkers, n_pops, K, Q);
         if (rc) return rc;
         HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                                  n_walkers, n_pops, ctx->d_partial, partial_stride(ctx), d_perstar, K, Q, nullptr, ctx->chunk_bounds, ctx->d_marg_tab, stream));
+                                  n_walkers, n_pops, ctx->d_partial, partial_stride(ctx), d_perstar, K, Q, nullptr, ctx->marg_prune, ctx->d_marg_tab, stream));
     } else {
         HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
                                   n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, partial_stride(ctx), d_perstar,
@@ -1603,7 +1603,7 @@ int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t s
         B9MargSample smp{d_out, d_out + per, d_out + 2 * per, d_pop, (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), (long long)(row0 + r0)};
         // the kernel indexes its outputs [row][n_stars] with the launch's own row count: rows are contiguous for any m
         if (e == hipSuccess) e = b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params, m, n_pops,
-                                               ctx->d_partial, partial_stride(ctx), nullptr, K, Q, &smp, ctx->chunk_bounds, ctx->d_marg_tab, s);
+                                               ctx->d_partial, partial_stride(ctx), nullptr, K, Q, &smp, ctx->marg_prune, ctx->d_marg_tab, s);
         const size_t cnt = (size_t)m * n, o = (size_t)r0 * n;
         if (e == hipSuccess) e = hipMemcpyAsync(out_mass + o, d_out, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(out_ratio + o, d_out + per, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);

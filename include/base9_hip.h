@@ -166,7 +166,7 @@ typedef struct b9_options {
  * number of GPUs the walkers are spread over must pin it (singlePopMcmc --tilesPerBlock n does).
  * The same fields can be set through the environment, read ONCE when the context is created: B9_TILES_PER_BLOCK,
  * B9_DERIVE_PARTS, B9_DERIVE_ORDER (historical coding: 1 default, 0 heavy first, < 0 derivation trails), B9_HEAVY_PARTS,
- * B9_WALKERS_PER_LANE, B9_CONTIGUOUS_TILES, B9_TWO_LAUNCH_STEPS, B9_NO_CHUNK_BOUNDS, B9_TIMING_GROUP, B9_PLAN_DEBUG, B9_TREE_DEPTH;
+ * B9_WALKERS_PER_LANE, B9_CONTIGUOUS_TILES, B9_TWO_LAUNCH_STEPS, B9_MARG_NO_PRUNING, B9_TIMING_GROUP, B9_PLAN_DEBUG, B9_TREE_DEPTH;
  * B9_STREAM_PRIORITY=default gives the context's stream the default priority instead of the lowest.
  */
 typedef struct b9_tuning {
@@ -178,7 +178,8 @@ typedef struct b9_tuning {
     int32_t walkers_per_lane;  /* k_star_like: 2 = two walkers per lane (halves L2 traffic, doubles the chain); default 1 */
     int32_t contiguous_tiles;  /* 1: a hot workgroup's tiles are consecutive even when the launch is one occupancy round  */
     int32_t two_launch_steps;  /* 1: the derive + star launch pair per sampler step also in given-mass mode                */
-    int32_t no_chunk_bounds;   /* 1: marginalised kernel without its chunk-level pruning table                           */
+    int32_t marg_no_pruning;   /* 1: marginalised kernel evaluates every node of every star (no floor, no boxes): the      */
+                               /* brute-force statement of the same sum on the GPU, for tests                            */
     int32_t timing_group;      /* launches per HIP-event bracket of b9_enable_timing in the fused step (default 8)        */
     int32_t plan_debug;        /* 1: print the fused step's launch plan to stderr whenever it changes                    */
     int32_t tree_depth;        /* given-mass sampler blocks: Metropolis steps per launch.  1 = the one-step fused launch;   */

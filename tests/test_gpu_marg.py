@@ -65,3 +65,57 @@ def test_marginalised_device_block_matches_host_twin(n_pops):
     np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
     np.testing.assert_allclose(dev[1], oracle.Oracle(pack, stars, priors, abi.make_options(abi.MODE_MARGINALISED, n_pops, 2, 3)).logpost(dev[0]), rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4"])
+def test_marginalised_matches_oracle_full_size(name):
+    """The marginalised mode at the FULL size of the BASELINE.json configurations (K = Q = 4: 6384 nodes per star and
+    population): one parameter row, every per-star value and the total against the oracle's brute-force integral at
+    1e-9 relative.  C3 holds WD-stage stars (k_star_marg_wd beside k_star_marg), C4 two populations.  The oracle runs its
+    OpenMP build over the stars (same per-star values as the sequential checker; a few seconds per row)."""
+    from base_amd import engine
+    cfg = synth.make_baseline_config(name)
+    n_pops = cfg["n_pops"]
+    opt = abi.make_options(abi.MODE_MARGINALISED, n_pops, 4, 4)
+    eng = engine.Engine(cfg["pack"], cfg["stars"], cfg["priors"], opt)
+    row = synth.walker_params(cfg["truth"], 3, seed=5, n_pops=n_pops, scale=0.05)[2:3]
+    lp_g, ps_g = eng.logpost(row, perstar=True)
+    lp_o, ps_o = oracle.Oracle(cfg["pack"], cfg["stars"], cfg["priors"], opt, native=True).logpost(row, perstar=True)
+    stage = np.asarray(cfg["cluster"]["stage"])
+    if name == "C3":
+        assert (stage == abi.STAGE_WD).sum() > 500
+    if name == "C4":
+        assert n_pops == 2
+    assert np.all(np.isfinite(ps_o)) and np.array_equal(np.isfinite(ps_g), np.isfinite(ps_o))
+    err = np.abs(ps_g - ps_o) / np.maximum(1.0, np.abs(ps_o))
+    assert err.max() <= 1e-9, (name, err.max(), int(err.argmax()))
+    assert abs(lp_g[0] - lp_o[0]) <= 1e-9 * max(1.0, abs(lp_o[0])), (name, lp_g[0], lp_o[0])
+    eng.close()
+
+
+@pytest.mark.parametrize("n_pops,wd_frac,K,Q", [(1, 0.0, 4, 4), (2, 0.05, 2, 3), (1, 0.0, 1, 8)])
+def test_pruning_is_rigorous(n_pops, wd_frac, K, Q):
+    """The marginalised kernel with its pruning (field floor, two levels of boxes, running maxima shared between waves)
+    against THE SAME kernel evaluating every node of every star (b9_tuning.marg_no_pruning): equal to 1e-12 -- what the
+    pruning drops is below e^-40 of what it keeps.  Includes stars the floor prunes entirely (field stars), membership
+    priors of exactly 1 (no floor: the seed pass) and of 1e-200."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, _ = build_problem("parsec", 8, n_stars=6000, wd_frac=wd_frac, n_y=3 if n_pops == 2 else 1,
+                                                       n_pops=n_pops, small=False, seed=77)
+    cl["clust_prior"][:200] = 1.0
+    cl["clust_prior"][200:260] = 1e-200
+    stars = abi.make_stars(cl)
+    opt = abi.make_options(abi.MODE_MARGINALISED, n_pops, K, Q)
+    eng = engine.Engine(pack, stars, priors, opt)
+    rows = synth.walker_params(cl["truth"], 4, seed=9, n_pops=n_pops, scale=0.3)
+    lp_a, ps_a = eng.logpost(rows, perstar=True)
+    eng.set_tuning(marg_no_pruning=1)
+    lp_b, ps_b = eng.logpost(rows, perstar=True)
+    eng.set_tuning()
+    assert np.array_equal(np.isfinite(ps_a), np.isfinite(ps_b))
+    fin = np.isfinite(ps_b)
+    assert fin.mean() > 0.9
+    err = np.abs(ps_a[fin] - ps_b[fin]) / np.maximum(1.0, np.abs(ps_b[fin]))
+    assert err.max() <= 1e-12, err.max()
+    np.testing.assert_allclose(lp_a, lp_b, rtol=1e-12)
+    eng.close()
