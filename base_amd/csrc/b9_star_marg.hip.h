@@ -69,7 +69,7 @@ __device__ __forceinline__ double gumbel(unsigned k0, unsigned k1, unsigned long
 
 #ifdef B9_MARG_STATS      // diagnostic build only (tools/marg_stats.py): what the marginalised kernel executes per star
 __device__ unsigned long long g_marg_stats[8];
-#define MSTAT(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_marg_stats[k], (unsigned long long)(v)); } while (0)
+#define MSTAT(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_marg_stats[k], (unsigned long long)(v)); } while (0)
 extern "C" int b9_debug_marg_stats(unsigned long long *out, int clear)
 {
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_marg_stats), sizeof(unsigned long long) * 8);

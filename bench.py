@@ -58,7 +58,7 @@ MCMC_BLOCK = 100        # steps between adaptation points (= between all-gathers
 TIMING_EVERY = 25       # a HIP-event bracket opens at every 25th launch of the dominant kernel in the timed region and spans 8 launches
 PREWARM_STEPS = 1000    # untimed, BEFORE the W warm-up steps: clocks, first touch of every buffer, RCCL channels, and the sampler's
                         # own burn-in (10 adaptation blocks: the timed steps run with the adapted proposal, as a real run's do)
-PROFILE_TAG = "r03"     # profiles/<tag>_summary.json: rocprofv3 PMC passes of this command (tools/profile_round.sh)
+PROFILE_TAG = "r04"     # profiles/<tag>_summary.json: rocprofv3 PMC passes of this command (tools/profile_round.sh)
 MARG_K = MARG_Q = 4     # marginalised leg: sub-steps per EEP interval x mass ratios
 
 
@@ -294,13 +294,40 @@ def cpu_baseline(pack_d, cl, truth, budget_s: float = 14.0, eng=None, sampler_st
                       f"-O3 -march=native -fopenmp; BASE-9 itself is not mounted: build's CPU oracle, parity unpinned"}
 
 
-def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_cpu: bool, n_calls: int = 5):
-    """The marginalised evaluation mode as a measured configuration of its own (one wavefront per star; every star
-    integrated over primary mass and mass ratio, 4 sub-steps per EEP interval x 4 mass ratios = 6384 nodes/star):
-    throughput through the C ABI, the kernel's fp64 VALU-issue roofline (launch time measured live with HIP events),
-    the CPU oracle's marginalised path on a bounded sample, and |delta logPost| against it on the full cluster."""
+def marg_stats(source_hash: str):
+    """Executed / live term counts of k_star_marg per star-eval from the committed stats pass (tools/marg_stats.py ->
+    profiles/<tag>_marg_stats.json: a -DB9_MARG_STATS build counting on this workload) -- or {"stale": reason}."""
+    pth = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_marg_stats.json")
+    if not os.path.exists(pth):
+        return {"stale": f"profiles/{PROFILE_TAG}_marg_stats.json is missing"}
+    doc = json.load(open(pth))
+    if doc.get("csrc_sha256") != source_hash:
+        return {"stale": f"profiles/{PROFILE_TAG}_marg_stats.json was counted on other kernel sources: dropped", "source": pth}
+    return {"source": f"profiles/{PROFILE_TAG}_marg_stats.json", "live_terms_per_star_eval": doc["live_terms_per_star_eval"],
+            "terms_evaluated_per_star_eval": doc["terms_evaluated_per_star_eval"], "live_share": doc["live_share"]}
+
+
+def marg_useful_lane_ops(n_filt: int, live_terms: float) -> dict:
+    """Algorithmic fp64 lane-operations of one marginalised star-eval: every term that ENTERS the star's sum (within 40 e-folds
+    of its largest: the committed stats pass counts them) needs its chi^2 (per filter: subtract, multiply, fma), the compare
+    that admits it, one exponential and one add; the star then needs one logarithm, and one exp + log for the field-star
+    mixture.  Terms a wave evaluates for lanes that do not need them, box tests and table building are NOT useful work."""
+    per_term = 3 * n_filt + 1 + OP_EXP + 1
+    per_star = OP_LOG + OP_EXP + OP_LOG + 4
+    return {"per_live_term": per_term, "per_star": per_star, "live_terms_per_star_eval": live_terms,
+            "mean": live_terms * per_term + per_star}
+
+
+def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_cpu: bool, n_calls: int = 20, steps: int = 200):
+    """The marginalised evaluation mode as a measured configuration of its own (every star integrated over primary mass and
+    mass ratio, 4 sub-steps per EEP interval x 4 mass ratios = 6384 nodes/star; one LANE per star, a wave walks the node
+    table for 64 photometric neighbours):  (i) b9_logpost calls through the C ABI;  (ii) the SAMPLER in this mode -- the C++
+    b9h::WalkerSampler driving device-resident blocks, two launches per step -- as MCMC steps/s, with the ensemble state
+    it ends on checked against the CPU oracle;  (iii) k_star_marg's fp64 VALU roofline, launch time measured live with HIP
+    events: issue occupancy from the committed counters and the USEFUL fraction from the committed count of terms that
+    enter a star's sum;  (iv) the CPU oracle's brute-force marginalisation on a bounded sample."""
     import numpy as np
-    from base_amd import abi, engine, synth
+    from base_amd import abi, engine, hostlib, mcmc, synth
     opts = abi.make_options(abi.MODE_MARGINALISED, 1, MARG_K, MARG_Q)
     eng = engine.Engine(pack, stars, priors, opts, device=local_rank)
     params = synth.walker_params(truth, WALKERS_PER_GPU, seed=43, scale=0.02)
@@ -320,13 +347,36 @@ def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_c
            "nodes_per_star_eval": nodes, "node_evals_per_s": evals * nodes / dt,
            "ms_per_logpost_call": 1e3 * dt, "calls": n_calls,
            "config": {"workload": f"the bench cluster ({N_STARS} stars x {N_FILT} filters x {WALKERS_PER_GPU} walkers), marginalised mode: "
-                                  f"{MARG_K} sub-steps per EEP interval x {MARG_Q} mass ratios; b9_logpost calls (derive + k_star_marg + finalize)"}}
-    roof = valu_roofline(profile_counters("k_star_marg", source_hash), launch_s if k_n else None)
+                                  f"{MARG_K} sub-steps per EEP interval x {MARG_Q} mass ratios; b9_logpost calls (derive + k_marg_table + k_star_marg + finalize)"}}
+    # ---- the sampler in this mode: the same C++ driver as the headline, two launches per step
+    free = mcmc.DEFAULT_FREE
+    smp = hostlib.HostSampler(WALKERS_PER_GPU, free, [mcmc.DEFAULT_STEP[k] for k in free], hostlib.Exchange.local(), seed=2025,
+                              block=50, engine=eng)
+    smp.initialise(synth.walker_params(truth, WALKERS_PER_GPU, seed=42, scale=0.02))
+    smp.run(100)                                            # untimed: two adaptation blocks
+    acc0 = smp.state()["accepted_local"]
+    hostlib._check(hostlib.load().b9h_device_synchronize())
+    t0 = time.perf_counter()
+    smp.run(steps)
+    hostlib._check(hostlib.load().b9h_device_synchronize())
+    dt_s = time.perf_counter() - t0
+    st = smp.state()
+    out["sampler"] = {"mcmc_steps_per_s": steps / dt_s, "ms_per_step": 1e3 * dt_s / steps, "steps": steps, "warmup_steps_untimed": 100,
+                      "value": evals * steps / dt_s, "unit": "star-likelihood evals/s", "walkers": WALKERS_PER_GPU, "mcmc_block": 50,
+                      "accept_rate": (st["accepted_local"] - acc0) / float(WALKERS_PER_GPU * steps),
+                      "driver": "C++ host library (b9h::WalkerSampler), device-resident blocks; a step = k_derive_iso (finishing the "
+                                "previous step) + k_marg_table + k_star_marg"}
+    stats = marg_stats(source_hash)
+    useful = marg_useful_lane_ops(N_FILT, stats["live_terms_per_star_eval"]) if "stale" not in stats else None
+    roof = valu_roofline(profile_counters("k_star_marg", source_hash), launch_s if k_n else None,
+                         useful["mean"] * evals if useful else None)
     roof.update({"kernel": "k_star_marg", "launches_timed": k_n, "avg_launch_us": 1e6 * launch_s if k_n else None,
-                 "star_evals_per_launch": evals,
+                 "star_evals_per_launch": evals, "useful_ops_per_star_eval": useful, "term_counts": stats,
                  "algorithmic_bytes_per_launch": evals * 152.0 / WALKERS_PER_GPU + WALKERS_PER_GPU * eng.max_eep() * (N_FILT + 1) * 8.0,
-                 "note": "no useful-work numerator is stated for this mode: its rigorous pruning skips a data-dependent share of the "
-                         "nodes, so operations per star-eval are not a fixed algorithmic count; frac is the issue-occupancy figure"})
+                 "note": "launch time measured live (HIP events around the k_marg_table + k_star_marg pair of every call); frac = issue-slot "
+                         "occupancy from the committed PMC pass; useful_frac = (terms that enter a star's sum, from the committed stats "
+                         "pass, x the lane-operations one such term needs + the star's closing logarithms) x star-evals / launch time / "
+                         "(1024 SIMDs x 16 lanes x 2.4 GHz); both null when the kernel sources differ from the measured ones"})
     out["roofline"] = roof
     if with_cpu:
         orc, cores = native_oracle(pack, stars, priors, opts)
@@ -343,6 +393,14 @@ def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_c
                                          f"oracle/b9_oracle.c star_marg_loglike (brute force over the whole grid, no pruning)",
                                "delta_logpost": d}
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        # the sampler's own numbers: the log-posteriors its walkers hold after the timed steps (formed by the block's launches)
+        got = np.asarray(st["all_logpost"], dtype=np.float64)
+        want = orc.logpost(np.asarray(st["all_params"], dtype=np.float64))
+        ds = _delta(got, want)
+        ds["what"] = ("the marginalised sampler's ensemble state after its timed steps: log-posteriors formed by the block's own launches "
+                      f"at the {WALKERS_PER_GPU} walkers' positions, full cluster, against the oracle's brute-force integral")
+        out["sampler"]["delta_logpost_sampler"] = ds
+    smp.close()
     eng.close()
     return out
 
