@@ -89,6 +89,16 @@ extern "C" int b9_debug_marg_life(unsigned long long *out) { return (int)hipMemc
 #define MLIFE_UNIT() do {} while (0)
 #endif
 
+// v_max_f64 / v_min_f64 / v_fma_f64 with a wave-uniform (SGPR) operand, as single instructions.  Written out because the
+// compiler (i) brackets every fmax / fmin of values it cannot prove quiet with two canonicalising v_max x, x -- 8 instructions
+// per filter of a box test instead of 5 -- and (ii) evaluates a Horner step whose coefficient lives in a VGPR as
+// v_mov_b64 + v_fmac (the coefficient is loop-invariant, the two-address fmac would destroy it): with the coefficient as
+// the one SGPR operand a VOP3 instruction may take, a step is one v_fma_f64.  (Operands are never signalling NaNs.)
+__device__ __forceinline__ double max_vs(double a, double s_u) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s_u)); return r; }
+__device__ __forceinline__ double min_vs(double a, double s_u) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s_u)); return r; }
+__device__ __forceinline__ double max_vv(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double fma_vvs(double a, double b, double s_u) { double r; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(s_u)); return r; }
+
 // lower bound of sum_f w_f (C_f - obs_f)^2 over every row with lo_f <= C_f <= hi_f (box = {lo[NFP], hi[NFP]}, wave-uniform)
 template <int NFP>
 __device__ __forceinline__ double box_bound(const double *__restrict__ box, const double (&obs)[NFP], const double (&wgt)[NFP])
@@ -96,7 +106,7 @@ __device__ __forceinline__ double box_bound(const double *__restrict__ box, cons
     double lb = 0.0;
 #pragma unroll
     for (int f = 0; f < NFP; ++f) {
-        const double c = __builtin_fmin(__builtin_fmax(obs[f], box[f]), box[NFP + f]);      // obs clamped into the box
+        const double c = min_vs(max_vs(obs[f], box[f]), box[NFP + f]);      // obs clamped into the box
         const double dd = obs[f] - c;
         lb = fma(wgt[f] * dd, dd, lb);
     }
@@ -113,18 +123,68 @@ __device__ __forceinline__ double row_x(const double *__restrict__ row, double n
     return x;
 }
 
+// One table row (NFP magnitudes) + its nb in SCALAR registers, loaded ASYNCHRONOUSLY: load() only issues the s_load
+// instructions, wait() is the s_waitcnt before the first use.  Written as inline assembly because the compiler waits for
+// a scalar load right where it issues it when the consumer follows (one exposed L2 round trip per table row, 54 % of the
+// kernel's wave cycles); with the next row requested BEFORE the current one is evaluated the trip hides behind ~60
+// VALU instructions.  (Scalar loads return out of order, so the only wait is lgkmcnt(0): at most one row is in flight.)
+typedef double b9_d4 __attribute__((ext_vector_type(4)));
+typedef double b9_d8 __attribute__((ext_vector_type(8)));
+template <int NFP> struct SRow;
+template <> struct SRow<4> {
+    b9_d4 m; double nb;
+    __device__ __forceinline__ void load(const double *row, const double *nbp)
+    {
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(m) : "s"(row));
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(nb) : "s"(nbp));
+    }
+    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m), "+s"(nb)); }
+    __device__ __forceinline__ double mag(int f) const { return m[f]; }
+};
+template <> struct SRow<8> {
+    b9_d8 m; double nb;
+    __device__ __forceinline__ void load(const double *row, const double *nbp)
+    {
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(m) : "s"(row));
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(nb) : "s"(nbp));
+    }
+    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m), "+s"(nb)); }
+    __device__ __forceinline__ double mag(int f) const { return m[f]; }
+};
+template <> struct SRow<16> {
+    b9_d8 m0, m1; double nb;
+    __device__ __forceinline__ void load(const double *row, const double *nbp)
+    {
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(m0) : "s"(row));
+        asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(m1) : "s"(row));
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(nb) : "s"(nbp));
+    }
+    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m0), "+s"(m1), "+s"(nb)); }
+    __device__ __forceinline__ double mag(int f) const { return f < 8 ? m0[f & 7] : m1[f & 7]; }
+};
+
+// X = nb + chi^2 of a row held in scalar registers
+template <int NFP>
+__device__ __forceinline__ double srow_x(const SRow<NFP> &r, const double (&obs)[NFP], const double (&wgt)[NFP])
+{
+    double x = r.nb;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) { const double dd = r.mag(f) - obs[f]; x = fma(wgt[f] * dd, dd, x); }
+    return x;
+}
+
 // exp(x) for |x| <= 700 to 3e-13 relative (the star's sum needs 1e-10): Cody-Waite reduction, degree-10 Horner polynomial
-// on [-ln2/2, ln2/2], v_ldexp_f64.  No clamping: the caller bounds x.
+// on [-ln2/2, ln2/2] with its coefficients in scalar registers, v_ldexp_f64.  No clamping: the caller bounds x.
 __device__ __forceinline__ double exp_marg(double x)
 {
     const double k = rint(x * 1.4426950408889634074);
     double r = fma(-k, 6.93147180369123816490e-01, x);
     r = fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 3628800.0;
-    p = fma(p, r, 1.0 / 362880.0);    p = fma(p, r, 1.0 / 40320.0);    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);       p = fma(p, r, 1.0 / 120.0);      p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);         p = fma(p, r, 0.5);              p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+    double p;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "s"(1.0 / 3628800.0), "v"(1.0 / 362880.0));
+    p = fma_vvs(p, r, 1.0 / 40320.0);   p = fma_vvs(p, r, 1.0 / 5040.0);    p = fma_vvs(p, r, 1.0 / 720.0);
+    p = fma_vvs(p, r, 1.0 / 120.0);     p = fma_vvs(p, r, 1.0 / 24.0);      p = fma_vvs(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);                 p = fma(p, r, 1.0);                 p = fma(p, r, 1.0);
     return ldexp(p, (int)k);
 }
 
@@ -138,13 +198,13 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
     const double d = t - ref;
     if (__ballot(d > 600.0) != 0ull) {
         const bool up = d > 600.0;
-        const double e = exp_fast(up ? -d : d);
+        const double e = exp_marg(max_vs(up ? -d : d, -700.0));
         sm = up ? fma(sm, e, 1.0) : sm + e;
         ref = up ? t : ref;
     } else {
         sm += exp_marg(d);
     }
-    tmax = __builtin_fmax(tmax, t);
+    tmax = max_vv(tmax, t);
 }
 
 // Waves per SIMD the instances are built for (tools/kernel_resources.py)
@@ -271,9 +331,9 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                 MLIFE_UNIT();
                 any = true;
                 const double *__restrict__ const rowp = t_rows + ((size_t)u * Q + j) * 16 * NFP;
-#pragma unroll 2
-                for (int i = 0; i < 16; ++i) {
-                    const double x = row_x<NFP>(rowp + i * NFP, nbp[i], obs, wgt);
+                // one row's term for every lane (the 64 stars), into the lanes that still count it
+                auto term = [&](const SRow<NFP> &r, int i) {
+                    const double x = srow_x<NFP>(r, obs, wgt);
                     const bool live = x < xcut;
 #ifdef B9_MARG_STATS
                     { const unsigned long long lm = __ballot(live); MSTAT(4, __popcll(lm)); }
@@ -292,6 +352,22 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                         }
                         lse_term(t, ref[kp], sm[kp], tmax[kp]);
                     }
+                };
+                // the unit's 16 rows, two at a time: row i + 1 is requested before row i is evaluated.  (The request past the
+                // unit's last row reads the next unit's first row / the word after nb's sub-chunk: inside the table, unused.)
+                SRow<NFP> ra, rb;
+                ra.load(rowp, nbp);
+                ra.wait();
+#pragma unroll 1
+                for (int i = 0; i < 16; i += 2) {
+                    rb.load(rowp + (i + 1) * NFP, nbp + i + 1);
+                    __builtin_amdgcn_sched_barrier(0);          // (the request stays AHEAD of the evaluation it is to hide behind)
+                    term(ra, i);
+                    rb.wait();
+                    ra.load(rowp + (i + 2) * NFP, nbp + i + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    term(rb, i + 1);
+                    ra.wait();
                 }
                 xcut = fma(-2.0, tmax[kp], cut2);
             }
