@@ -69,9 +69,9 @@ class b9_options(C.Structure):
 
 class b9_tuning(C.Structure):
     """Launch-plan tuning (include/base9_hip.h); all zeros = automatic."""
-    _fields_ = [(n, C.c_int32) for n in ("tiles_per_block", "derive_parts", "derive_order", "heavy_parts", "walkers_per_lane",
-                                         "contiguous_tiles", "two_launch_steps", "marg_no_pruning", "timing_group", "plan_debug", "tree_depth")] + \
-               [("reserved", C.c_int32 * 5)]
+    _fields_ = [(n, C.c_int32) for n in ("tiles_per_block", "derive_parts", "derive_order", "heavy_parts", "two_launch_steps",
+                                         "marg_no_pruning", "timing_group", "plan_debug", "tree_depth")] + \
+               [("reserved", C.c_int32 * 7)]
 
 
 class b9_mcmc_block(C.Structure):
@@ -190,7 +190,7 @@ HIP_LIB_PATH = os.path.join(REPO_ROOT, "base_amd", "csrc", "libbase9hip.so")
 #: every symbol include/base9_hip.h declares (checked by tests/test_abi.py against the header)
 ABI_SYMBOLS = [
     "b9_abi_version", "b9_ctx_create", "b9_ctx_destroy", "b9_last_error",
-    "b9_load_pack", "b9_load_stars", "b9_set_priors", "b9_set_options", "b9_set_tuning",
+    "b9_load_pack", "b9_load_stars", "b9_set_priors", "b9_set_options", "b9_set_tuning", "b9_get_tuning",
     "b9_logpost", "b9_logpost_device", "b9_mcmc_run_block", "b9_mcmc_wait", "b9_sample_mass", "b9_derive_isochrone",
     "b9_max_eep", "b9_device_id", "b9_bytes_per_star_eval", "b9_step_tiles_per_block", "b9_step_depth",
     "b9_enable_timing", "b9_kernel_time_ms", "b9_calibrate_timing",
@@ -217,6 +217,7 @@ def load_hip_library(path: Optional[str] = None) -> C.CDLL:
     lib.b9_set_priors.argtypes = [vp, C.POINTER(b9_priors)]
     lib.b9_set_options.argtypes = [vp, C.POINTER(b9_options)]
     lib.b9_set_tuning.argtypes = [vp, C.POINTER(b9_tuning)]
+    lib.b9_get_tuning.argtypes = [vp, C.POINTER(b9_tuning)]
     lib.b9_logpost.argtypes = [vp, _dp, C.c_int32, _dp, _dp]
     lib.b9_logpost_device.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
     lib.b9_mcmc_run_block.argtypes = [vp, C.POINTER(b9_mcmc_block)]

@@ -82,13 +82,12 @@ struct b9_ctx {
     int step_blocks_per_cu = 0, step_occ_key = -1;   // k_mcmc_step workgroups per CU for (nfp, n_pops, mass_cap), and the key it was queried for
     int heavy_parts = 4;       // workgroups per walker for the stars above the AGB tip (sized in check_ready)
     int n_wd_stage = 0;        // stars the catalogue marks as white dwarfs
+    b9_tuning tuning{};        // the tuning in force (b9_get_tuning): the environment's at creation, then the last b9_set_tuning
     int tiles_per_block = 0;   // 0 = auto
-    int walkers_per_lane = 1;  // WB template parameter of k_star_like (1 or 2)
     int derive_parts = 0;      // fused sampler step: workgroups per candidate isochrone (0 = one value per thread)
     int derive_order = 1;      // fused sampler step: 1 writers + derivation lead the grid and the heavy-star workgroups follow them (default),
                                // 0 heavy-star workgroups first, < 0 derivation workgroups trail the hot ones (B9_DERIVE_ORDER)
     bool two_launch_steps = false;   // b9_tuning.two_launch_steps: the derive + star launch pair per step also in given-mass mode
-    bool contiguous_tiles = false;   // b9_tuning.contiguous_tiles: a hot workgroup's tiles are consecutive even in a one-round plan
     bool plan_debug = false;         // b9_tuning.plan_debug: print the fused step's launch plan to stderr when it changes
     bool marg_prune = true;          // marginalised kernel: field floor + box pruning (b9_tuning.marg_no_pruning turns both off)
     int heavy_parts_fixed = 0;       // b9_tuning.heavy_parts: 0 = sized from the catalogue (check_ready)
@@ -425,37 +424,9 @@ int ensure_marg_table(b9_ctx *ctx, int n_walkers, int n_pops, int K, int Q)
     return B9_OK;
 }
 
-struct Plan { int tiles_per_block, n_groups; };
-
-Plan make_plan(const b9_ctx *ctx, int n_walkers, int n_pops)
+// Workgroups of the fused step resident at once for the loaded pack and options (occupancy query of that instantiation, cached)
+int step_slots(b9_ctx *ctx, int n_pops)
 {
-    Plan p;
-    const int n_tiles = ctx->st.n_pad / 256;
-    (void)n_pops;
-    int tpb = ctx->tiles_per_block;
-    if (tpb <= 0) {
-        // one tile per workgroup until there are more workgroups than ~8 per CU; beyond that
-        // amortise the per-workgroup mass-column staging over several tiles
-        long long blocks1 = (long long)n_tiles * n_walkers;
-        tpb = (int)std::max<long long>(1, std::min<long long>(8, blocks1 / 4096));
-    }
-    tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
-    p.tiles_per_block = tpb;
-    p.n_groups = (n_tiles + tpb - 1) / tpb;
-    return p;
-}
-
-// Launch plan of the fused sampler step.  The launch has three kinds of workgroups (heavy-star, candidate
-// derivation, hot); it is fastest when ALL of them are resident at once -- one occupancy round, every
-// workgroup takes the previous step's decision exactly once -- so tiles_per_block is the smallest value
-// that lets the hot workgroups fill <= 70 % of the slots, and the derivation is cut into as many
-// parts as the remaining slots allow (measured on the 50k x 8 x 8 bench shape: 3 tiles per workgroup and 8
-// parts give 21.8 us per step; 1 tile / 15 parts 26.0 us; 4 tiles 25.6 us).
-struct StepPlan { Plan plan; int derive_parts; bool strided; };
-
-StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
-{
-    StepPlan sp;
     const int key = (ctx->pk.nfp * 4 + n_pops) * 65536 + ctx->mass_cap;
     if (ctx->step_occ_key != key) {
         int per_cu = 0;
@@ -463,22 +434,69 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
         ctx->step_blocks_per_cu = per_cu;
         ctx->step_occ_key = key;
     }
+    return ctx->n_cu * std::max(1, ctx->step_blocks_per_cu);
+}
+
+// The catalogue's CANONICAL tile groups (b9_star_like.hip.h): n_groups groups of group_tiles tiles, one partial sum per
+// group and wave -- the grouping fixes how a walker's log-posterior ROUNDS, so it must not depend on how many walkers share
+// the GPU (a chain is then the same bits on 1, 2, 4 or 8 ranks).  It is a function of the catalogue, the pack, the options
+// and the device only: the tiles per workgroup the fused step wants on the REFERENCE shape of 8 walkers per GPU -- the
+// smallest value that lets the hot workgroups fill <= 70 % of one occupancy round (measured on 50k stars x 8 filters x 8
+// walkers: 3 tiles per workgroup 21.8 us per step, 1 tile 26.0, 4 tiles 25.6).  b9_tuning.tiles_per_block pins it.
+// A launch plan's only freedom is how many whole groups a workgroup takes.
+struct Groups { int group_tiles, n_groups; };
+constexpr int kReferenceWalkers = 8;
+
+Groups make_groups(b9_ctx *ctx, int n_pops)
+{
     const int n_tiles = ctx->st.n_pad / 256;
-    const int full_parts = (ctx->mass_cap * (ctx->pk.nfp + 1) + 255) / 256;
-    const int slots = ctx->n_cu * std::max(1, ctx->step_blocks_per_cu);   // workgroups resident at once (occupancy query of this instantiation)
-    int tpb = ctx->tiles_per_block;
-    if (tpb <= 0) {
-        tpb = 1;
-        while (tpb < 8 && (long long)((n_tiles + tpb - 1) / tpb) * n_walkers > (long long)(0.7 * slots)) ++tpb;
-        // (more walkers than one round can hold: 8 tiles per workgroup stays best -- every workgroup pays the
-        //  decision prologue once; measured 44.6 vs 60.2 us at 32 walkers, 83.3 vs 91.4 at 64)
+    int g = ctx->tiles_per_block;
+    if (g <= 0) {
+        const int slots = step_slots(ctx, n_pops);
+        g = 1;
+        while (g < 8 && (long long)((n_tiles + g - 1) / g) * kReferenceWalkers > (long long)(0.7 * slots)) ++g;
     }
-    tpb = std::max(1, std::min(tpb, std::max(1, n_tiles)));
-    sp.plan.tiles_per_block = tpb;
-    sp.plan.n_groups = (n_tiles + tpb - 1) / tpb;
+    g = std::max(1, std::min(g, std::max(1, n_tiles)));
+    return Groups{g, (n_tiles + g - 1) / g};
+}
+
+B9Groups with_groups_per_block(const Groups &gr, int m)
+{
+    m = std::max(1, std::min(m, gr.n_groups));
+    return B9Groups{gr.group_tiles, gr.n_groups, m, (gr.n_groups + m - 1) / m};
+}
+
+// b9_logpost's star launch (k_star_like): one group per workgroup until there are more workgroups than ~8 per CU; beyond
+// that amortise the per-workgroup mass-column staging over several groups
+B9Groups make_plan(b9_ctx *ctx, int n_walkers, int n_pops)
+{
+    const Groups gr = make_groups(ctx, n_pops);
+    const long long tiles_wanted = std::max<long long>(1, std::min<long long>(8, (long long)(ctx->st.n_pad / 256) * n_walkers / 4096));
+    return with_groups_per_block(gr, (int)(tiles_wanted / gr.group_tiles));
+}
+
+// Launch plan of the fused sampler step.  The launch has three kinds of workgroups (heavy-star, candidate
+// derivation, hot); it is fastest when ALL of them are resident at once -- one occupancy round, every
+// workgroup takes the previous step's decision exactly once -- so a workgroup takes the smallest number of canonical
+// groups that lets the hot workgroups fill <= 70 % of the slots (never more than ~8 tiles: with more walkers than one
+// round can hold that stays best -- every workgroup pays the decision prologue once; measured 44.6 vs 60.2 us at 32
+// walkers, 83.3 vs 91.4 at 64), and the derivation is cut into as many parts as the remaining slots allow.
+struct StepPlan { B9Groups plan; int derive_parts; };
+
+StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
+{
+    StepPlan sp;
+    const Groups gr = make_groups(ctx, n_pops);
+    const int slots = step_slots(ctx, n_pops);
+    const int key = (ctx->pk.nfp * 4 + n_pops) * 65536 + ctx->mass_cap;
+    const int full_parts = (ctx->mass_cap * (ctx->pk.nfp + 1) + 255) / 256;
+    const int m_max = std::max(1, 8 / gr.group_tiles);
+    int m = 1;
+    while (m < m_max && (long long)((gr.n_groups + m - 1) / m) * n_walkers > (long long)(0.7 * slots)) ++m;
+    sp.plan = with_groups_per_block(gr, m);
     int parts = ctx->derive_parts;
     if (parts <= 0) {
-        const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_groups * n_walkers - (long long)n_walkers * ctx->heavy_parts;
+        const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_blocks * n_walkers - (long long)n_walkers * ctx->heavy_parts;
         parts = (int)std::max<long long>(2, room / ((long long)n_walkers * 2 * n_pops));
         // ... but no more than ~3/8 of the CUs' worth of derivation workgroups in all: beyond that they only crowd the hot
         // ones (two populations x 8 walkers: 3 parts = 96 workgroups 21.0 us/step, 4 parts 21.8, 2 parts 23.4; one
@@ -487,12 +505,10 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
         parts = std::max(2, std::min(parts, target));
     }
     sp.derive_parts = std::max(1, std::min(parts, full_parts));
-    // one round: a workgroup's tiles are strided over the slot order (binary and single-star tiles mixed)
-    sp.strided = (long long)sp.plan.n_groups * n_walkers <= slots && !ctx->contiguous_tiles;
     if (ctx->plan_debug && ctx->plan_debug_key != key * 64 + n_walkers) {
         ctx->plan_debug_key = key * 64 + n_walkers;
-        std::fprintf(stderr, "b9 step plan: %d CUs x %d workgroups = %d slots; %d walkers x %d tile groups (%d tiles each, %s) + %d heavy + %d derivation workgroups (%d parts)\n",
-                     ctx->n_cu, ctx->step_blocks_per_cu, slots, n_walkers, sp.plan.n_groups, tpb, sp.strided ? "strided" : "contiguous",
+        std::fprintf(stderr, "b9 step plan: %d CUs x %d workgroups = %d slots; %d canonical groups of %d tiles; %d walkers x %d hot workgroups (%d groups each) + %d heavy + %d derivation workgroups (%d parts)\n",
+                     ctx->n_cu, ctx->step_blocks_per_cu, slots, gr.n_groups, gr.group_tiles, n_walkers, sp.plan.n_blocks, sp.plan.groups_per_block,
                      n_walkers * ctx->heavy_parts, n_walkers * 2 * n_pops * sp.derive_parts, sp.derive_parts);
     }
     return sp;
@@ -501,12 +517,11 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
 // b9_tuning -> the context's plan fields (0 = leave automatic)
 void apply_tuning(b9_ctx *ctx, const b9_tuning &t)
 {
+    ctx->tuning = t;
     ctx->tiles_per_block = std::max(0, t.tiles_per_block);
     ctx->derive_parts = std::max(0, t.derive_parts);
     ctx->derive_order = t.derive_order == 2 ? 0 : (t.derive_order == 3 ? -1 : 1);
     ctx->heavy_parts_fixed = std::max(0, t.heavy_parts);
-    ctx->walkers_per_lane = t.walkers_per_lane >= 2 ? 2 : 1;
-    ctx->contiguous_tiles = t.contiguous_tiles != 0;
     ctx->two_launch_steps = t.two_launch_steps != 0;
     ctx->marg_prune = t.marg_no_pruning == 0;
     ctx->timing_group = t.timing_group > 0 ? t.timing_group : 8;
@@ -530,8 +545,6 @@ bool tuning_from_env(b9_tuning *t)
     num("B9_DERIVE_PARTS", &t->derive_parts);
     num("B9_DERIVE_ORDER", &t->derive_order, true);
     num("B9_HEAVY_PARTS", &t->heavy_parts);
-    num("B9_WALKERS_PER_LANE", &t->walkers_per_lane);
-    num("B9_CONTIGUOUS_TILES", &t->contiguous_tiles);
     num("B9_TWO_LAUNCH_STEPS", &t->two_launch_steps);
     num("B9_MARG_NO_PRUNING", &t->marg_no_pruning);
     num("B9_TIMING_GROUP", &t->timing_group);
@@ -544,11 +557,11 @@ bool tuning_from_env(b9_tuning *t)
 // per walker one writer, 2^d (2^d - 1) candidate derivations in `parts` pieces, (2^d - 1) x heavy_parts heavy-star and
 // (2^d - 1) x n_groups hot workgroups -- are ALL resident in one occupancy round, with at most B9_TREE_MAX_GROUPS tile
 // groups per node (what one round trip of the walk reads).  depth 1 = none fits: the one-step fused launch runs instead.
-struct TreePlan { int depth, tiles_per_block, n_groups, derive_parts; bool strided; };
+struct TreePlan { int depth, group_tiles, n_groups, derive_parts; };
 
 TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
 {
-    TreePlan tp{1, 1, 1, 1, true};
+    TreePlan tp{1, 1, 1, 1};
     if (ctx->tree_depth == 1) return tp;
     const int key = (ctx->pk.nfp * 4 + n_pops) * 65536 + ctx->mass_cap;
     if (ctx->tree_occ_key != key) {
@@ -563,10 +576,11 @@ TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     for (int d = B9_TREE_MAX_DEPTH; d >= 2; --d) {
         if (ctx->tree_depth >= 2 && d != ctx->tree_depth) continue;          // pinned
         const long long NN = (1 << d) - 1, NO = 1 << d;
-        int tpb = ctx->tiles_per_block > 0 ? ctx->tiles_per_block : 1;
-        if (ctx->tiles_per_block <= 0) while ((n_tiles + tpb - 1) / tpb > B9_TREE_MAX_GROUPS) ++tpb;
-        const int n_groups = (n_tiles + tpb - 1) / tpb;
-        if (n_groups > B9_TREE_MAX_GROUPS) continue;         // (a PINNED grouping -- it fixes the summation order -- is never overridden: no tree then)
+        // one canonical group per hot workgroup; the walk reads a node's partials in one round trip, which bounds their number
+        // (the grouping fixes the summation order and is never changed for the tree's sake: no tree then)
+        const Groups gr = make_groups(ctx, n_pops);
+        const int tpb = gr.group_tiles, n_groups = gr.n_groups;
+        if (n_groups > B9_TREE_MAX_GROUPS) continue;
         const long long fixed = n_walkers * (1 + NN * ctx->heavy_parts + NN * 8 * ((n_groups + 7) / 8));
         const long long per_part = (long long)n_walkers * NO * NN * n_pops;
         const long long room = (long long)(0.95 * slots) - fixed;
@@ -582,20 +596,20 @@ TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
             // ~1.6 us per tile of the longest hot workgroup and ~2.2 us per tile per CU) / d; it reproduces the measured choices:
             // 1 walker x 100k stars d = 3 (10.8 vs 15.4 us/step), x 200k d = 1 (17.4 vs 18.4), x 500k d = 1 (26.2 vs 38.7),
             // 2 walkers x 50k d = 2 (8.4 vs 12.1), 1 x 10k d = 3 (4.4 vs 8.7).
-            const int tpb1 = make_step_plan(ctx, n_walkers, n_pops).plan.tiles_per_block;
+            const B9Groups p1 = make_step_plan(ctx, n_walkers, n_pops).plan;
+            const int tpb1 = p1.group_tiles * p1.groups_per_block;
             const double per_cu = 2.2 * (double)n_walkers * n_tiles / std::max(1, ctx->n_cu);
             const double est_tree = (9.0 + std::max(1.6 * tpb, per_cu * (double)NN)) / d;
             const double est_step = 9.0 + std::max(1.6 * tpb1, per_cu);
             if (est_tree >= est_step) continue;
         }
-        tp.depth = d; tp.tiles_per_block = tpb; tp.n_groups = n_groups; tp.derive_parts = std::max(1, parts);
-        tp.strided = !ctx->contiguous_tiles;
+        tp.depth = d; tp.group_tiles = tpb; tp.n_groups = n_groups; tp.derive_parts = std::max(1, parts);
         break;
     }
     if (ctx->plan_debug && ctx->plan_debug_key != key * 64 + n_walkers + 1000000 * tp.depth) {
         ctx->plan_debug_key = key * 64 + n_walkers + 1000000 * tp.depth;
         std::fprintf(stderr, "b9 tree plan: %lld slots; depth %d: %d walkers x %d nodes x %d tile groups (%d tiles each), %d derivation parts, %d heavy parts\n",
-                     slots, tp.depth, n_walkers, (1 << tp.depth) - 1, tp.n_groups, tp.tiles_per_block, tp.derive_parts, ctx->heavy_parts);
+                     slots, tp.depth, n_walkers, (1 << tp.depth) - 1, tp.n_groups, tp.group_tiles, tp.derive_parts, ctx->heavy_parts);
     }
     return tp;
 }
@@ -888,6 +902,13 @@ int b9_set_tuning(b9_ctx *ctx, const b9_tuning *t)
     return B9_OK;
 }
 
+int b9_get_tuning(const b9_ctx *ctx, b9_tuning *out)
+{
+    if (!ctx || !out) return B9_ERR_INVALID;
+    *out = ctx->tuning;
+    return B9_OK;
+}
+
 int b9_set_options(b9_ctx *ctx, const b9_options *o)
 {
     if (!ctx || !o) return B9_ERR_INVALID;
@@ -910,7 +931,7 @@ static Bufs buffer_set(const b9_ctx *ctx, int set)
 
 // number of partial sums one walker gets from the star kernel under the current plan / mode
 // (marginalised mode: one per 64-star chunk -- the star kernel sums a chunk's values in a fixed order -- and one per WD-stage star)
-static int partial_count(const b9_ctx *ctx, const Plan &plan)
+static int partial_count(const b9_ctx *ctx, const B9Groups &plan)
 {
     return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.mg_pad / 64 + ctx->st.n_wd : plan.n_groups * 4 + ctx->heavy_parts;
 }
@@ -920,7 +941,7 @@ static long long partial_stride(const b9_ctx *ctx) { return (long long)ctx->st.n
 
 // The star-likelihood launch (given-mass: hot + heavy workgroups; marginalised: one wave per star)
 // on buffer set `set`, bracketed by timing events when sampled.
-static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *d_perstar, const Plan &plan,
+static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *d_perstar, const B9Groups &plan,
                         hipStream_t stream)
 {
     const int n_pops = ctx->opt.n_pops;
@@ -947,8 +968,7 @@ static int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *
                                   n_walkers, n_pops, ctx->d_partial, partial_stride(ctx), d_perstar, K, Q, nullptr, ctx->marg_prune, ctx->d_marg_tab, stream));
     } else {
         HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                                  n_walkers, n_pops, ctx->walkers_per_lane, ctx->d_partial, partial_stride(ctx), d_perstar,
-                                  plan.tiles_per_block, plan.n_groups, ctx->heavy_parts, stream));
+                                  n_walkers, n_pops, ctx->d_partial, partial_stride(ctx), d_perstar, plan, ctx->heavy_parts, stream));
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
     return B9_OK;
@@ -960,7 +980,7 @@ static int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, doub
                           double *d_perstar, hipStream_t stream, const double *host_rows = nullptr)
 {
     const int n_pops = ctx->opt.n_pops;
-    const Plan plan = make_plan(ctx, n_walkers, n_pops);
+    const B9Groups plan = make_plan(ctx, n_walkers, n_pops);
     int rc = ensure_capacity(ctx, n_walkers, n_pops, (size_t)partial_stride(ctx) * n_walkers, false);
     if (rc) return rc;
     Bufs bf = buffer_set(ctx, 0);
@@ -1089,7 +1109,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps, n_pops = ctx->opt.n_pops;
     const bool cont = (blk->flags & B9_BLOCK_CONTINUE) != 0, async = (blk->flags & B9_BLOCK_ASYNC) != 0;
     const StepPlan sp = make_step_plan(ctx, W, n_pops);
-    const Plan &plan = sp.plan;
+    const B9Groups &plan = sp.plan;
     const int derive_parts = sp.derive_parts;
     // two slots (device block + pinned mirror + event) alternate, so that a block can be enqueued while its
     // predecessor is still running or waiting to be collected
@@ -1201,7 +1221,7 @@ static int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
             if (rc) return rc;
             t_covered = 0;
         } else if (ctx->timing > 0) ctx->launch_no++;
-        HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, sp.strided ? -plan.tiles_per_block : plan.tiles_per_block, plan.n_groups, ctx->heavy_parts, derive_parts, ctx->derive_order, s));
+        HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, plan, ctx->heavy_parts, derive_parts, ctx->derive_order, s));
         if (t_slot >= 0 && (++t_covered >= ctx->timing_group || t == S - 1)) {
             ctx->ev_count[t_slot] = t_covered;
             int rc = timing_end(ctx, s, t_slot);
@@ -1313,7 +1333,7 @@ static int run_block_tree(b9_ctx *ctx, b9_mcmc_block *blk, const TreePlan &tp)
     td.samples = n_samp ? dev + o_samp : nullptr; td.lps = n_lps ? dev + o_lps : nullptr;
     td.row_origin = dev + o_org; td.n_steps = S;
     td.step_tab = dev + o_tab; td.tab_steps = (int)tab_steps; td.block_step0 = (unsigned long long)blk->step0;
-    const int tiles_arg = tp.strided ? -tp.tiles_per_block : tp.tiles_per_block;
+    const int tiles_arg = tp.group_tiles;
     const int M = (S + depth - 1) / depth;
     {   // P: the block's first tree from the starting state -> candidates of parity 0, outcome slot 0
         td.set = 1; td.levels_prev = 0; td.levels = 0; td.derive_mode = 2; td.row = 0;
@@ -1379,7 +1399,7 @@ static int run_block_tree(b9_ctx *ctx, b9_mcmc_block *blk, const TreePlan &tp)
  * Same contract as the fused path: one pinned mirror per slot for the upload and the download, B9_BLOCK_ASYNC /
  * B9_BLOCK_CONTINUE / summary rows in HBM behind rows_ready -- a star launch here takes milliseconds, so none of this is for
  * speed; it gives a multi-GPU driver ONE way to run blocks and to read rows, whatever the evaluation mode. */
-static int run_block_two_launch(b9_ctx *ctx, b9_mcmc_block *blk, const Plan &plan)
+static int run_block_two_launch(b9_ctx *ctx, b9_mcmc_block *blk, const B9Groups &plan)
 {
     const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps, n_pops = ctx->opt.n_pops;
     const bool cont = (blk->flags & B9_BLOCK_CONTINUE) != 0, async = (blk->flags & B9_BLOCK_ASYNC) != 0;
@@ -1508,7 +1528,7 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     // (the work buffers are sized for the walker count: they must not be re-allocated under an enqueued block)
     for (const auto &sl : ctx->slot)
         if (sl.in_flight && sl.W != W) return fail(ctx, B9_ERR_STATE, "collect the outstanding block(s) before running a block with another number of walkers");
-    const Plan plan = make_plan(ctx, W, n_pops);
+    const B9Groups plan = make_plan(ctx, W, n_pops);
     rc = ensure_capacity(ctx, W, n_pops, (size_t)partial_stride(ctx) * W, false);
     if (rc) return rc;
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) {
@@ -1540,7 +1560,7 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     int rc = check_ready(ctx);
     if (rc) return rc;
-    const Plan plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
+    const B9Groups plan = make_plan(ctx, n_walkers, ctx->opt.n_pops);
     (void)plan;
     rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)partial_stride(ctx) * n_walkers, out_perstar != nullptr);
     if (rc) return rc;
@@ -1659,20 +1679,23 @@ int b9_bytes_per_star_eval(const b9_ctx *ctx)
 int b9_step_tiles_per_block(b9_ctx *ctx, int32_t n_walkers)
 {
     if (!ctx || n_walkers < 1) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     int rc = check_ready(ctx);
     if (rc) return rc;
     rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)partial_stride(ctx) * n_walkers, false);   // (the plan keys on mass_cap)
     if (rc) return rc;
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) {
         const TreePlan tp = make_tree_plan(ctx, n_walkers, ctx->opt.n_pops);
-        if (tp.depth >= 2) return tp.tiles_per_block;
+        if (tp.depth >= 2) return tp.group_tiles;
     }
-    return make_step_plan(ctx, n_walkers, ctx->opt.n_pops).plan.tiles_per_block;
+    const B9Groups p = make_step_plan(ctx, n_walkers, ctx->opt.n_pops).plan;
+    return p.group_tiles * p.groups_per_block;
 }
 
 int b9_step_depth(b9_ctx *ctx, int32_t n_walkers)
 {
     if (!ctx || n_walkers < 1) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, "a sampler block is outstanding: collect it with b9_mcmc_wait first (it owns the context's work buffers)");
     int rc = check_ready(ctx);
     if (rc) return rc;
     rc = ensure_capacity(ctx, n_walkers, ctx->opt.n_pops, (size_t)partial_stride(ctx) * n_walkers, false);

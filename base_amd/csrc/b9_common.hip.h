@@ -1,4 +1,4 @@
-// b9_common.hip.h -- constants, diagnostic stamps, interpolation / transcendental helpers, Philox, cluster prior,
+// b9_common.hip.h -- constants, interpolation / transcendental helpers, Philox, cluster prior,
 // fixed-order finish of a log-posterior and the Metropolis accept (shared by every kernel).
 // Part of the single translation unit b9_kernels.hip (included there, in this order); gfx950 only.
 #pragma once
@@ -8,71 +8,6 @@
 #define MF_SIGMA 0.67729
 #define LN10 2.302585092994045684
 #define NEG_INF (-__builtin_inf())
-
-// Diagnostic build only (-DB9_STAMPS): per-wave s_memtime stamps of the hot kernel's phases,
-// written to a buffer of their own that no kernel reads.  Never defined in the shipped library.
-#ifdef B9_STAMPS
-#define B9_NSTAMP 12
-__device__ unsigned long long g_stamps[8192 * B9_NSTAMP];
-#ifndef B9_STAMP_MASK
-#define B9_STAMP_MASK 0xFFF       // which stamps are live (bit k); the rest compile to nothing
-#endif
-#define STAMP(k)                                                                                   \
-    if ((B9_STAMP_MASK >> (k)) & 1)                                                                \
-    do {                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        unsigned long long t_;                                                                     \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        const unsigned wv_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                  \
-        if ((threadIdx.x & 63) == 0 && wv_ < 8192) g_stamps[wv_ * B9_NSTAMP + (k)] = t_;           \
-    } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
-
-// -DB9_ASM_MARKERS (diagnostic): comments in the generated assembly that delimit a role's code (tools/role_isa.py)
-#ifdef B9_ASM_MARKERS
-#define B9_MARK(name) asm volatile("; b9-mark " name)
-#else
-#define B9_MARK(name) do {} while (0)
-#endif
-
-#ifdef B9_GANTT      // diagnostic build only: per-workgroup start / end times (s_memrealtime, 100 MHz) of 8 consecutive launches
-#define B9_GANTT_WG 4096
-__device__ unsigned long long g_gantt[8 * B9_GANTT_WG * 4];
-__device__ unsigned long long g_gantt_heavy[64 * 8];          // phase stamps of the heavy role (one slot per workgroup id < 64)
-extern "C" int b9_debug_read_gantt(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt), sizeof(unsigned long long) * 8 * B9_GANTT_WG * 4);
-}
-extern "C" int b9_debug_read_gantt_heavy(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_heavy), sizeof(unsigned long long) * 64 * 8);
-}
-__device__ unsigned long long g_gantt_heavy2[64 * 16];        // stamps inside one star's evaluation (lane HS2_LANE of wave 0 of workgroups < 64)
-extern "C" int b9_debug_read_gantt_heavy2(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_heavy2), sizeof(unsigned long long) * 64 * 16);
-}
-__device__ unsigned long long g_gantt_walk[8];                 // the tree walk of workgroup 0: kernel entry | loads issued | loads landed | walk done
-extern "C" int b9_debug_read_gantt_walk(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_walk), sizeof(unsigned long long) * 8);
-}
-#define WSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_gantt_walk[7] == 1ull) g_gantt_walk[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define WSTAMP_ON(v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_gantt_walk[7] = (v); } while (0)
-#ifndef HS2_LANE
-#define HS2_LANE 0
-#endif
-#define HS2(k) do { if (threadIdx.x == HS2_LANE && blockIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_heavy2[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#define HSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_heavy[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define HS2(k) do {} while (0)
-#define HSTAMP(k) do {} while (0)
-#define WSTAMP(k) do {} while (0)
-#define WSTAMP_ON(v) do {} while (0)
-#endif
 
 __device__ __forceinline__ double lerp(double a, double b, double t) { return fma(t, b - a, a); }
 
@@ -141,11 +76,7 @@ __device__ __forceinline__ double exp_fast(double x)
 }
 
 // log(1 + exp(x)), any x (x = -inf gives 0)
-#ifdef B9_ABL_CHEAP_L1PE      // ablation build only: what the flux combine's exp + log cost (results are wrong)
-__device__ __forceinline__ double log1pexp(double x) { return fma(x, 0.01, 0.3); }
-#else
 __device__ __forceinline__ double log1pexp(double x) { return log_ge1(1.0 + exp_fast(x)); }
-#endif
 
 __device__ __forceinline__ double logaddexp(double a, double b)
 {

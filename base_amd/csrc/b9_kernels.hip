@@ -42,6 +42,7 @@
 #include <cstring>
 #include "../../include/base9_hip.h"
 
+#include "b9_diag.hip.h"
 #include "b9_common.hip.h"
 #include "b9_derive.hip.h"
 #include "b9_star.hip.h"
@@ -112,28 +113,26 @@ static size_t heavy_lds_doubles(const DevPack &pk, int n_pops, int n_cand, int m
     return 8 + (size_t)pk.hc_len + tips + (size_t)n_pops * n_cand * mass_cap + (size_t)n_cand * B9_NPARAM + 8;
 }
 
-template <int NFP, int NPOPS, int WB>
+template <int NFP, int NPOPS>
 static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                                    const double *iso_data, long long iso_stride, int mass_cap,
                                    const double *d_params, int n_walkers, double *partial, long long partial_stride,
-                                   double *perstar, int tiles_per_block, int n_groups, int heavy_parts,
-                                   hipStream_t stream)
+                                   double *perstar, const B9Groups &gr, int heavy_parts, hipStream_t stream)
 {
     // + 8: find_bracket's last stage may read up to 6 entries past a column's end (masked out)
-    const size_t lds = sizeof(double) * std::max((size_t)WB * NPOPS * mass_cap + 8, heavy_lds_doubles(pk, NPOPS, 1, mass_cap));
-    auto kern = k_star_like<NFP, NPOPS, WB>;
+    const size_t lds = sizeof(double) * std::max((size_t)NPOPS * mass_cap + 8, heavy_lds_doubles(pk, NPOPS, 1, mass_cap));
+    auto kern = k_star_like<NFP, NPOPS>;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int n_wsets = (n_walkers + WB - 1) / WB;
-    const int hot = 8 * ((n_groups + 7) / 8) * n_wsets;          // padded so every XCD sees whole walker sets
+    const int hot = 8 * ((gr.n_blocks + 7) / 8) * n_walkers;     // padded so every XCD sees whole walker sets
     const int heavy = (n_walkers * heavy_parts + 7) / 8 * 8;     // heavy-star workgroups lead the grid
     hipLaunchKernelGGL(kern, dim3(heavy + hot), dim3(256), lds, stream, pk, st, hdr, iso_data,
-                       iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, n_groups, perstar,
-                       tiles_per_block, heavy, heavy_parts);
+                       iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, gr.n_groups, gr.group_tiles,
+                       gr.groups_per_block, gr.n_blocks, perstar, heavy, heavy_parts);
     return hipGetLastError();
 }
 
@@ -147,13 +146,13 @@ static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const 
 
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
-                         const double *d_params, int n_walkers, int n_pops, int wb,
-                         double *partial, long long partial_stride, double *perstar, int tiles_per_block,
-                         int n_groups, int heavy_parts, hipStream_t stream)
+                         const double *d_params, int n_walkers, int n_pops,
+                         double *partial, long long partial_stride, double *perstar, const B9Groups &gr,
+                         int heavy_parts, hipStream_t stream)
 {
-#define SL_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, tiles_per_block, n_groups, heavy_parts, stream
-#define SL2(NFP) (wb >= 2 ? launch_star_like<NFP, 2, 2>(SL_ARGS) : launch_star_like<NFP, 2, 1>(SL_ARGS))
-#define SL1(NFP) (wb >= 2 ? launch_star_like<NFP, 1, 2>(SL_ARGS) : launch_star_like<NFP, 1, 1>(SL_ARGS))
+#define SL_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, gr, heavy_parts, stream
+#define SL2(NFP) launch_star_like<NFP, 2>(SL_ARGS)
+#define SL1(NFP) launch_star_like<NFP, 1>(SL_ARGS)
     B9_SWITCH_NFP(SL2, SL1)
 #undef SL1
 #undef SL2
@@ -229,8 +228,7 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 template <int NFP, int NPOPS>
 static size_t mcmc_step_lds(const DevPack &pk, int mass_cap)
 {
-    const size_t stage = B9_LDS_STAGE(NFP) ? (size_t)4 * (2 * NFP + 1) * 64 : 0;      // per-wave observation stage of the hot role
-    return sizeof(double) * std::max((size_t)2 * NPOPS * mass_cap + 8 + stage, heavy_lds_doubles(pk, NPOPS, 2, mass_cap));
+    return sizeof(double) * std::max((size_t)2 * NPOPS * mass_cap + 8, heavy_lds_doubles(pk, NPOPS, 2, mass_cap));
 }
 
 template <int NFP, int NPOPS>
@@ -259,7 +257,7 @@ hipError_t b9k_mcmc_step_occupancy(const DevPack &pk, int n_pops, int mass_cap, 
 
 template <int NFP, int NPOPS>
 static hipError_t launch_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr,
-                                   int tiles_per_block, int n_groups, int heavy_parts, int derive_parts, int derive_order, hipStream_t stream)
+                                   const B9Groups &gr, int heavy_parts, int derive_parts, int derive_order, hipStream_t stream)
 {
     const size_t lds = mcmc_step_lds<NFP, NPOPS>(pk, sd.mass_cap);
     auto kern = k_mcmc_step<NFP, NPOPS>;
@@ -269,21 +267,21 @@ static hipError_t launch_mcmc_step(const DevPack &pk, const DevStars &st, const 
         if (e != hipSuccess) return e;
     }
     const int W = sd.n_walkers;
-    const int hot = 8 * ((n_groups + 7) / 8) * W;
+    const int hot = 8 * ((gr.n_blocks + 7) / 8) * W;
     const int derive_first = derive_order >= 0 ? (derive_order == 1 ? 2 : 1) : 0;
     const int n_derive = W * 2 * NPOPS * derive_parts;
     const int front = (W * heavy_parts + W + (derive_first ? n_derive : 0) + 7) / 8 * 8;     // heavy, writers, (derivation), pad
     const int back = (!derive_first && sd.derive_next) ? n_derive : 0;
-    hipLaunchKernelGGL(kern, dim3(front + hot + back), dim3(256), lds, stream, pk, st, sd, pr, tiles_per_block, n_groups,
-                       front, hot, heavy_parts, derive_parts, derive_first);
+    hipLaunchKernelGGL(kern, dim3(front + hot + back), dim3(256), lds, stream, pk, st, sd, pr, gr.group_tiles, gr.n_groups,
+                       gr.groups_per_block, gr.n_blocks, front, hot, heavy_parts, derive_parts, derive_first);
     return hipGetLastError();
 }
 
 hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr,
-                         int tiles_per_block, int n_groups, int heavy_parts, int derive_parts, int derive_order, hipStream_t stream)
+                         const B9Groups &gr, int heavy_parts, int derive_parts, int derive_order, hipStream_t stream)
 {
     const int n_pops = sd.n_pops;
-#define MS_ARGS pk, st, sd, pr, tiles_per_block, n_groups, heavy_parts, derive_parts, derive_order, stream
+#define MS_ARGS pk, st, sd, pr, gr, heavy_parts, derive_parts, derive_order, stream
 #define MS2(NFP) launch_mcmc_step<NFP, 2>(MS_ARGS)
 #define MS1(NFP) launch_mcmc_step<NFP, 1>(MS_ARGS)
     B9_SWITCH_NFP(MS2, MS1)
@@ -322,7 +320,7 @@ hipError_t b9k_mcmc_tree_occupancy(const DevPack &pk, int n_pops, int mass_cap, 
 }
 
 template <int NFP, int NPOPS>
-static hipError_t launch_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int tiles_per_block,
+static hipError_t launch_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int group_tiles,
                                    int derive_parts, hipStream_t stream)
 {
     const size_t lds = mcmc_tree_lds<NFP, NPOPS>(pk, td.mass_cap);
@@ -338,16 +336,16 @@ static hipError_t launch_mcmc_tree(const DevPack &pk, const DevStars &st, const 
     const int heavy = td.levels > 0 ? W * NN * td.heavy_parts : 0;
     const int front = (writers + n_derive + heavy + 7) / 8 * 8;
     const int hot = td.levels > 0 ? 8 * ((td.n_groups + 7) / 8) * W * NN : 0;
-    hipLaunchKernelGGL(kern, dim3(front + hot), dim3(256), lds, stream, pk, st, td, pr, tiles_per_block, front, derive_parts);
+    hipLaunchKernelGGL(kern, dim3(front + hot), dim3(256), lds, stream, pk, st, td, pr, group_tiles, front, derive_parts);
     return hipGetLastError();
 }
 
-hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int tiles_per_block,
+hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int group_tiles,
                          int derive_parts, hipStream_t stream)
 {
     const int n_pops = td.n_pops;
-#define MT2(NFP) launch_mcmc_tree<NFP, 2>(pk, st, td, pr, tiles_per_block, derive_parts, stream)
-#define MT1(NFP) launch_mcmc_tree<NFP, 1>(pk, st, td, pr, tiles_per_block, derive_parts, stream)
+#define MT2(NFP) launch_mcmc_tree<NFP, 2>(pk, st, td, pr, group_tiles, derive_parts, stream)
+#define MT1(NFP) launch_mcmc_tree<NFP, 1>(pk, st, td, pr, group_tiles, derive_parts, stream)
     B9_SWITCH_NFP(MT2, MT1)
 #undef MT1
 #undef MT2

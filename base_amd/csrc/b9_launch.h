@@ -19,11 +19,16 @@ hipError_t b9k_derive_iso(const DevPack &pk, double *d_params, int n_walkers, in
 hipError_t b9k_derive_iso_rows(const DevPack &pk, const double *host_rows, double *d_params, int n_walkers, int n_pops,
                                IsoHdr *hdr, double *iso_data, long long iso_stride, int mass_cap, hipStream_t stream);
 
+// How a launch's hot workgroups take the catalogue's CANONICAL tile groups (b9_star_like.hip.h): n_groups groups of group_tiles
+// tiles are fixed by the catalogue (so is the partial-sum layout: 4 per group); a workgroup takes groups_per_block of them,
+// n_blocks workgroups per walker.
+struct B9Groups { int group_tiles, n_groups, groups_per_block, n_blocks; };
+
 hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hdr,
                          const double *iso_data, long long iso_stride, int mass_cap,
-                         const double *d_params, int n_walkers, int n_pops, int wb,
-                         double *partial, long long partial_stride, double *perstar, int tiles_per_block,
-                         int n_groups, int heavy_parts, hipStream_t stream);
+                         const double *d_params, int n_walkers, int n_pops,
+                         double *partial, long long partial_stride, double *perstar, const B9Groups &gr,
+                         int heavy_parts, hipStream_t stream);
 
 hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial, long long partial_stride,
                         int n_pops, const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
@@ -48,7 +53,7 @@ long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q);
 // fused sampler step (given-mass mode): decision of step t-1 + stars of step t + candidates of step t+1
 // (tiles_per_block < 0: a workgroup's |tiles_per_block| tiles are strided n_groups apart instead of consecutive)
 hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr,
-                         int tiles_per_block, int n_groups, int heavy_parts, int derive_parts,
+                         const B9Groups &gr, int heavy_parts, int derive_parts,
                          int derive_order /* >= 0: derivation workgroups lead the grid, < 0: they trail it */, hipStream_t stream);
 // resident workgroups per CU of k_mcmc_step's instantiation for this pack (occupancy query; no launch)
 hipError_t b9k_mcmc_step_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu);
@@ -61,7 +66,7 @@ hipError_t b9k_mcmc_continue(const double *prev_final, double *cur0, double *lp0
 hipError_t b9k_mcmc_finish(const DevPack &pk, const StepDev &sd, const DevPriors &pr, hipStream_t stream);
 
 // tree-speculative step (given-mass mode, few walkers): one launch = `depth` steps of every chain (TreeDev in b9_device.h)
-hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int tiles_per_block /* < 0: strided */,
+hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int group_tiles /* tiles of a canonical group */,
                          int derive_parts, hipStream_t stream);
 hipError_t b9k_mcmc_tree_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu);
 hipError_t b9k_tree_finish(const TreeDev &td, const DevPriors &pr, hipStream_t stream);

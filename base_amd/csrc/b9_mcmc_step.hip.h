@@ -21,9 +21,7 @@ __device__ __forceinline__ const double *step_state_in(const StepDev &sd, int w)
 // SHORTCUT: the caller only needs the 0/1 outcome -- if the walker's writer workgroup (which leads
 // the grid) has already published it for this step, take it from there and skip the sum.  Waves
 // that start before the writer is done compute it themselves: same bits either way, nobody waits.
-#ifndef B9_SHORTCUT
 #define B9_SHORTCUT true
-#endif
 #define B9_DECIDE_K 6
 struct DecideLoads {           // everything one wave's decision reads (registers)
     double lp_cur, lpr, lu, selp, h0, h1, v[B9_DECIDE_K];
@@ -87,54 +85,21 @@ __device__ __forceinline__ bool step_decide(const StepDev &sd, int w, double &lp
     return decide_finish<SHORTCUT>(sd, w, dl, lp_new);
 }
 
-// Asynchronous global -> LDS staging of one wave's 64 stars of a tile: observed magnitudes, weights, c0
-// = 2 NFP + 1 arrays of 64 doubles.  Lanes 0..31 each move 16 bytes per array (global_load_lds_dwordx4:
-// the hardware places lane l's data at dst + 16 l, so the 512 bytes land in star order); no VGPR holds
-// the data and nothing waits here -- hot_star waits (vmcnt) when it needs them, a few thousand cycles later.
-template <int NFP>
-__device__ __forceinline__ void stage_tile(const DevStars &st, int slot0 /* first slot of this wave's 64 */, double *dst)
-{
-    const int lane = threadIdx.x & 63;
-    typedef const __attribute__((address_space(1))) void *gptr;
-    typedef __attribute__((address_space(3))) void *lptr;
-    if (lane < 32) {
-#pragma unroll
-        for (int f = 0; f < NFP; ++f) {
-            __builtin_amdgcn_global_load_lds((gptr)(st.obs + B9_SIDX(NFP, f, slot0) + 2 * lane), (lptr)(dst + f * 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr)(st.w + B9_SIDX(NFP, f, slot0) + 2 * lane), (lptr)(dst + (NFP + f) * 64), 16, 0, 0);
-        }
-        __builtin_amdgcn_global_load_lds((gptr)(st.c0 + slot0 + 2 * lane), (lptr)(dst + 2 * NFP * 64), 16, 0, 0);
-    }
-}
-
-// Measured on the bench shape: 20.4 us/step with the stage vs 19.6 without (the other waves of the SIMD already
-// hide that round trip; the stage adds 17 DMA instructions and two waits per tile).  Kept as a tested
-// compile-time option (-DB9_USE_LDS_STAGE), off.
-#ifdef B9_USE_LDS_STAGE
-#define B9_LDS_STAGE(NFP) ((NFP) <= 8)        // 16 padded filters would need 68 KB per workgroup: not worth the occupancy
-#else
-#define B9_LDS_STAGE(NFP) false
-#endif
-
 // Hot role: k_star_like's body for one walker, with the mass columns and headers of BOTH candidates
 // requested before the decision is known (same round trip as the partial sums the decision needs).
 template <int NFP, int NPOPS>
 __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, const StepDev &sd, int L,
-                                         int tiles_per_block, int n_groups, double *smem)
+                                         int group_tiles, int n_groups, int groups_per_block, int n_blocks, double *smem)
 {
     const int tid = threadIdx.x, W = sd.n_walkers, mass_cap = sd.mass_cap;
     const int xcd = L & 7, s = L >> 3;
     const int w = s % W;
-    const int group = (s / W) * 8 + xcd;                 // tile group = tiles_per_block consecutive tiles
-    if (group >= n_groups) return;
-    // A workgroup's tiles are STRIDED over the slot order (group, group + n_groups, ...): binaries lead that
-    // order, so consecutive tiles would give some workgroups only expensive (binary) tiles and others only
-    // cheap ones; strided, every workgroup gets its share of both and they finish together.
-    // (Only when the launch is a single occupancy round; with several rounds the slots never idle and
-    //  contiguous tiles are faster -- measured 84 vs 94 us at 64 walkers.)
-    const bool strided = tiles_per_block < 0;
-    if (strided) tiles_per_block = -tiles_per_block;
-    const int tile0 = strided ? group : group * tiles_per_block, tile_step = strided ? n_groups : 1;
+    const int g = (s / W) * 8 + xcd;                     // this workgroup among the walker's n_blocks
+    if (g >= n_blocks) return;
+    // its canonical tile groups g, g + n_blocks, ... (TileSeq, b9_star_like.hip.h): group_tiles tiles each, strided over the
+    // slot order -- binaries lead that order, so consecutive tiles would give some workgroups only expensive (binary)
+    // tiles and others only cheap ones; strided, every workgroup gets its share of both and they finish together
+    const TileSeq seq{g, n_blocks, n_groups, group_tiles, groups_per_block, st.n_pad / 256};
     STAMP(0);
     // The decision is taken by the workgroup's first wave alone and travels through LDS behind the barrier the mass
     // columns need anyway: a quarter of the partial-sum traffic at the launch's start.  Its loads leave first.
@@ -142,12 +107,8 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     DecideLoads dl = {};
     if (first_wave) decide_issue<B9_SHORTCUT>(sd, w, dl);
-    int i = tile0 * 256 + tid;
-    int il = i < st.n_pad ? i : st.n_pad - 1;
-    double m1 = st.mass1[il], q = st.q[il], ea = st.ea[il];
-    // this wave's LDS stage for the tile's observations (behind the mass columns)
-    double *const stage_w = smem + (size_t)(2 * NPOPS) * mass_cap + 8 + (size_t)(tid >> 6) * ((2 * NFP + 1) * 64);
-    if (B9_LDS_STAGE(NFP) && tile0 * 256 < st.n_pad) stage_tile<NFP>(st, tile0 * 256 + (tid & ~63), stage_w);
+    int i = seq.tile(seq.group(0), 0) * 256 + tid;       // (a group's first tile always exists)
+    double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
     const size_t rows = (size_t)W * NPOPS;
     const size_t cb0 = (size_t)(sd.set * 2) * rows + (size_t)w * NPOPS;      // candidate 0; candidate 1 is `rows` further
     double *const lds_mass = smem;
@@ -205,42 +166,33 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     const double mod = sel ? pmod[1] : pmod[0], av = sel ? pav[1] : pav[0], lam = sel ? plam[1] : plam[0];
     const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
 
-    MixAcc acc;
-    acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;         // = 1.0
-    for (int t = 0; t < tiles_per_block; ++t) {
-        if ((tile0 + t * tile_step) * 256 >= st.n_pad) break;
-#ifndef B9_NO_TILE_PREFETCH
-        // the NEXT tile's star scalars are requested before this tile's arithmetic: one memory round
-        // trip less on every tile after the first, for 6 VGPRs
-        const int i_n = (tile0 + (t + 1) * tile_step) * 256 + tid;
-        const int il_n = i_n < st.n_pad ? i_n : st.n_pad - 1;
-        const double m1_n = st.mass1[il_n], q_n = st.q[il_n], ea_n = st.ea[il_n];
-#else
-        if (t > 0) {
-            i = (tile0 + t * tile_step) * 256 + tid;
-            il = i < st.n_pad ? i : st.n_pad - 1;
-            m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
+    for (int j = 0; j < groups_per_block; ++j) {
+        const int c = seq.group(j);
+        if (c < 0) break;
+        if (j > 0) {                                         // (a further group of this workgroup: its first tile's star scalars)
+            i = seq.tile(c, 0) * 256 + tid;
+            m1 = st.mass1[i]; q = st.q[i]; ea = st.ea[i];
         }
-#endif
-        if (valid && i < st.n_pad && !(m1 > tip_min)) {   // empty slots hold m1 = +inf
-            const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, il,
-                                                  B9_LDS_STAGE(NFP) ? stage_w + (tid & 63) : nullptr, log_lam, log_1ml);
-            mix_add(acc, ea, l);
+        MixAcc acc;
+        acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;         // = 1.0
+        for (int t = 0; t < group_tiles; ++t) {
+            if (seq.tile(c, t) < 0) break;
+            // the NEXT tile's star scalars are requested before this tile's arithmetic: one memory round
+            // trip less on every tile after the first, for 6 VGPRs
+            const int tile_n = seq.tile(c, t + 1);
+            const int i_n = (tile_n >= 0 ? tile_n : seq.tile(c, t)) * 256 + tid;
+            const double m1_n = st.mass1[i_n], q_n = st.q[i_n], ea_n = st.ea[i_n];
+            if (valid && !(m1 > tip_min)) {                  // empty slots hold m1 = +inf
+                const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, i, log_lam, log_1ml);
+                mix_add(acc, ea, l);
+            }
+            i = i_n; m1 = m1_n; q = q_n; ea = ea_n;
         }
-#ifndef B9_NO_TILE_PREFETCH
-        i = i_n; il = il_n; m1 = m1_n; q = q_n; ea = ea_n;
-#endif
-        if (B9_LDS_STAGE(NFP) && t + 1 < tiles_per_block && (tile0 + (t + 1) * tile_step) * 256 < st.n_pad) {
-            // the next tile's observations: every lane of this wave has consumed the current ones (their
-            // ds_reads have returned -- the chi^2 used them), so the stage can be overwritten
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stage_tile<NFP>(st, (tile0 + (t + 1) * tile_step) * 256 + (tid & ~63), stage_w);
-        }
+        STAMP(7);
+        const double tot = mix_wave_total(acc);
+        if ((tid & 63) == 0)
+            sd.partial[(size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) + c * 4 + (tid >> 6)] = valid ? tot : 0.0;
     }
-    STAMP(7);
-    const double tot = mix_wave_total(acc);
-    if ((tid & 63) == 0)
-        sd.partial[(size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) + group * 4 + (tid >> 6)] = valid ? tot : 0.0;
     STAMP(8);
 }
 
@@ -337,7 +289,7 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
 // Grid: [one WRITER per walker][derivation workgroups][heavy-star workgroups][pad to 8][hot workgroups]
 // (B9_DERIVE_ORDER=0: heavy-star workgroups first; < 0: the derivation workgroups trail the grid instead).
 template <int NFP, int NPOPS>
-__device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, int tiles_per_block, int n_groups,
+__device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, int group_tiles, int n_groups, int groups_per_block, int n_blocks,
                  int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first, double *smem)
 {
     const int W = sd.n_walkers, n_heavy = W * heavy_parts, n_derive = W * 2 * NPOPS * derive_parts;
@@ -370,11 +322,10 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
     }
     if (role == 0) {
         B9_MARK("hot-begin");
-        step_hot<NFP, NPOPS>(pk, st, sd, b, tiles_per_block, n_groups, smem);
+        step_hot<NFP, NPOPS>(pk, st, sd, b, group_tiles, n_groups, groups_per_block, n_blocks, smem);
         B9_MARK("hot-end");
         return role;
     }
-#ifndef B9_STEP_NO_HEAVY     // (diagnostic builds only: what the hot + derivation roles need in registers on their own)
     if (role == 1) {
         const int w = b / heavy_parts, part = b - w * heavy_parts;
         // (raising the role's wave priority -- s_setprio 3 -- was measured: no effect on its chain or on the hot waves)
@@ -404,7 +355,6 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
         B9_MARK("heavy-end");
         return role;
     }
-#endif
     if (role == 2) {       // b = ((w * 2 + cand) * NPOPS + pop) * derive_parts + part
         const int part = b % derive_parts; b /= derive_parts;
         const int pop = b % NPOPS; b /= NPOPS;
@@ -417,48 +367,15 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
     return role;
 }
 
-// (-DB9_KERNARG_WARM, measured and left off.)  The kernel's arguments are ~1 KB of structs by value; the compiler fetches
-// a field where it first needs it, and every 64-byte line of the freshly written argument buffer touched for the first
-// time is a memory round trip.  Touching every line at entry brings them in with one round trip -- 0.9 us faster on the
-// 200-star shape, 0.5 us SLOWER on the 50k-star one (3072 waves x 17 extra scalar loads at the launch's start).
-template <size_t BYTES>
-__device__ __forceinline__ void warm_kernargs()
-{
-#ifdef B9_KERNARG_WARM
-    typedef const __attribute__((address_space(4))) unsigned *kptr;
-    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned acc = 0;
-#pragma unroll
-    for (size_t i = 0; i < (BYTES + 63) / 64; ++i) acc |= ka[i * 16];
-    asm volatile("" :: "s"(acc));
-#endif
-}
-
 template <int NFP, int NPOPS>
 __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS))
-void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int tiles_per_block, int n_groups,
+void k_mcmc_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, int group_tiles, int n_groups, int groups_per_block, int n_blocks,
                  int front_blocks, int hot_blocks, int heavy_parts, int derive_parts, int derive_first)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-#ifdef B9_GANTT
-    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-#endif
-    warm_kernargs<sizeof(DevPack) + sizeof(DevStars) + sizeof(StepDev) + sizeof(DevPriors) + 7 * sizeof(int)>();
-    const int role = step_body<NFP, NPOPS>(pk, st, sd, pr, tiles_per_block, n_groups, front_blocks, hot_blocks, heavy_parts, derive_parts, derive_first, smem);
-#ifdef B9_GANTT
-    __syncthreads();          // the workgroup's last wave
-    if (threadIdx.x == 0 && blockIdx.x < B9_GANTT_WG) {
-        unsigned long long *g = g_gantt + ((sd.step & 7ull) * B9_GANTT_WG + blockIdx.x) * 4;
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned hw;                                       // HW_ID: CU (bits 8-11), SH (12), SE (13-15) of the workgroup's first wave
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        g[0] = t_in; g[1] = __builtin_amdgcn_s_memrealtime();
-        g[2] = (unsigned long long)role | ((unsigned long long)(xcc & 15u) << 8) | ((unsigned long long)(hw & 0xFFFFu) << 16); g[3] = sd.step;
-    }
-#else
-    (void)role;
-#endif
+    B9_GANTT_ENTER();
+    const int role = step_body<NFP, NPOPS>(pk, st, sd, pr, group_tiles, n_groups, groups_per_block, n_blocks, front_blocks, hot_blocks, heavy_parts, derive_parts, derive_first, smem);
+    B9_GANTT_EXIT(sd.step, role);
 }
 
 // Summary row of walker w over the block (the multi-GPU driver all-gathers these rows straight from HBM and pools
@@ -574,17 +491,6 @@ __global__ __launch_bounds__(256) void k_mcmc_begin(const double *__restrict__ h
     }
 }
 
-#ifdef B9_STAMPS
-extern "C" int b9_debug_read_stamps(unsigned long long *out, int n_waves)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * B9_NSTAMP * n_waves);
-}
-extern "C" int b9_debug_clear_stamps(void)
-{
-    static unsigned long long zeros[8192 * B9_NSTAMP];
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof zeros);
-}
-#endif
 
 
 // B9_BLOCK_CONTINUE: the next block's starting state is the previous block's final state, copied on the device

@@ -131,16 +131,10 @@ __device__ __forceinline__ TreeWalk tree_decide(const TreeDev &td, int w)
     TreeLoads tl;
     WSTAMP(1);
     tree_issue(td, w, tl);
-#ifdef B9_GANTT
-    WSTAMP(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WSTAMP(3);
+    WSTAMP_LANDED(2, 3);                 // (diagnostic build: waits for the loads and stamps both sides)
     const TreeWalk tw = tree_walk(td, tl);
     if (tw.outcome >= 0) WSTAMP(4);
     return tw;
-#else
-    return tree_walk(td, tl);
-#endif
 }
 
 // index of candidate (walker w, outcome o of the previous launch, node n) in cand_par / cand_hdr / cand_iso of parity `set`
@@ -152,7 +146,7 @@ __device__ __forceinline__ size_t tree_cand(const TreeDev &td, int set, int w, i
 
 // ---- hot role: one node's star likelihood (k_star_like's hot body on the candidate the walk selects) --------------------
 template <int NFP, int NPOPS>
-__device__ __forceinline__ void tree_hot(const DevPack &pk, const DevStars &st, const TreeDev &td, int L, int tiles_per_block, double *smem)
+__device__ __forceinline__ void tree_hot(const DevPack &pk, const DevStars &st, const TreeDev &td, int L, int group_tiles, double *smem)
 {
     const int tid = threadIdx.x, W = td.n_walkers, mass_cap = td.mass_cap, NN = (1 << td.depth) - 1, V = W * NN;
     const int xcd = L & 7, s = L >> 3;
@@ -160,14 +154,12 @@ __device__ __forceinline__ void tree_hot(const DevPack &pk, const DevStars &st, 
     if (group >= td.n_groups) return;
     const int w = v / NN, n = v - w * NN;
     if (tree_level(n) > td.levels) return;                   // (a block's last launch may evaluate fewer levels)
-    const bool strided = tiles_per_block < 0;
-    if (strided) tiles_per_block = -tiles_per_block;
-    const int tile0 = strided ? group : group * tiles_per_block, tile_step = strided ? td.n_groups : 1;
+    // one canonical tile group per workgroup (TileSeq, b9_star_like.hip.h): tiles group, group + n_groups, ...
+    const TileSeq seq{group, td.n_groups, td.n_groups, group_tiles, 1, st.n_pad / 256};
     __shared__ int s_o;
     const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
-    int i = tile0 * 256 + tid;
-    int il = i < st.n_pad ? i : st.n_pad - 1;
-    double m1 = st.mass1[il], q = st.q[il], ea = st.ea[il];
+    int i = group * 256 + tid;
+    double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
     if (first_wave) {
         const int o = tree_decide(td, w).outcome;
         if (tid == 0) s_o = o;
@@ -202,16 +194,16 @@ __device__ __forceinline__ void tree_hot(const DevPack &pk, const DevStars &st, 
     __syncthreads();                                         // the LDS mass columns
     MixAcc acc;
     acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;             // = 1.0
-    for (int t = 0; t < tiles_per_block; ++t) {
-        if ((tile0 + t * tile_step) * 256 >= st.n_pad) break;
-        const int i_n = (tile0 + (t + 1) * tile_step) * 256 + tid;
-        const int il_n = i_n < st.n_pad ? i_n : st.n_pad - 1;
-        const double m1_n = st.mass1[il_n], q_n = st.q[il_n], ea_n = st.ea[il_n];     // the next tile's star scalars: one round trip less per tile
-        if (valid && i < st.n_pad && !(m1 > tip_min)) {      // empty slots hold m1 = +inf
-            const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, il, nullptr, log_lam, log_1ml);
+    for (int t = 0; t < group_tiles; ++t) {
+        if (seq.tile(group, t) < 0) break;
+        const int tile_n = seq.tile(group, t + 1);
+        const int i_n = (tile_n >= 0 ? tile_n : seq.tile(group, t)) * 256 + tid;
+        const double m1_n = st.mass1[i_n], q_n = st.q[i_n], ea_n = st.ea[i_n];     // the next tile's star scalars: one round trip less per tile
+        if (valid && !(m1 > tip_min)) {                      // empty slots hold m1 = +inf
+            const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, i, log_lam, log_1ml);
             mix_add(acc, ea, l);
         }
-        i = i_n; il = il_n; m1 = m1_n; q = q_n; ea = ea_n;
+        i = i_n; m1 = m1_n; q = q_n; ea = ea_n;
     }
     const double tot = mix_wave_total(acc);
     if ((tid & 63) == 0)
@@ -534,19 +526,17 @@ __device__ __forceinline__ void tree_derive(const DevPack &pk, const TreeDev &td
 // Grid: [writers W][derivation][heavy][pad to 8][hot].  n_front = first hot workgroup id.
 template <int NFP, int NPOPS>
 __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS))
-void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int tiles_per_block, int n_front, int derive_parts)
+void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int group_tiles, int n_front, int derive_parts)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-#ifdef B9_GANTT
-    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-#endif
+    B9_GANTT_ENTER();
     WSTAMP_ON(td.derive_mode == 1 ? 1ull : 0ull);    // (the K launches only)
     WSTAMP(0);
     const int W = td.n_walkers, NN = (1 << td.depth) - 1, NO = td.derive_mode == 2 ? 1 : (1 << td.depth);
     int b = blockIdx.x, role = 3;                            // 0 hot, 1 heavy, 2 derivation, 3 padding, 4 writer (tools/gantt_step.py)
     const int n_writers = W;                                 // (the prologue has no tree to take a decision on: its "writers" write the block's step table)
     const int n_derive = td.derive_mode == 0 ? 0 : W * NO * NN * NPOPS * derive_parts;
-    if (b >= n_front) { role = 0; tree_hot<NFP, NPOPS>(pk, st, td, b - n_front, tiles_per_block, smem); }
+    if (b >= n_front) { role = 0; tree_hot<NFP, NPOPS>(pk, st, td, b - n_front, group_tiles, smem); }
     else if (b < n_writers) { role = 4; if (td.derive_mode == 2) tree_table(td, b); else tree_writer(td, pr, b, nullptr); }
     else if (b - n_writers < n_derive) {          // b = (((w * NO + o2) * NN + n2) * NPOPS + pop) * parts + part
         role = 2;
@@ -560,18 +550,7 @@ void k_mcmc_tree(DevPack pk, DevStars st, TreeDev td, DevPriors pr, int tiles_pe
         role = 1;
         tree_heavy<NFP, NPOPS>(pk, st, td, b - n_writers - n_derive, smem);
     }
-#ifdef B9_GANTT
-    __syncthreads();          // the workgroup's last wave
-    if (threadIdx.x == 0 && blockIdx.x < B9_GANTT_WG) {
-        const unsigned long long launch = td.step / (unsigned)td.depth;
-        unsigned long long *g = g_gantt + ((launch & 7ull) * B9_GANTT_WG + blockIdx.x) * 4;
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g[0] = t_in; g[1] = __builtin_amdgcn_s_memrealtime(); g[2] = (unsigned long long)role | ((unsigned long long)(xcc & 15u) << 8); g[3] = launch;
-    }
-#else
-    (void)role;
-#endif
+    B9_GANTT_EXIT(td.step / (unsigned)td.depth, role);
 }
 
 // the block's last walk: one workgroup per walker, writer role only (+ the block's summary rows, the host mirror)

@@ -28,15 +28,11 @@ __device__ __forceinline__ void fill(double (&out)[NFP], double v)
 // role is one long dependent chain: every instruction on it is latency.
 __device__ __forceinline__ double fdiv(double num, double den)
 {
-#ifdef B9_EXACT_DIV
-    return num / den;
-#else
     double r = __builtin_amdgcn_rcp(den);
     r = fma(fma(-den, r, 1.0), r, r);
     r = fma(fma(-den, r, 1.0), r, r);
     const double q = num * r;
     return fma(fma(-den, q, num), r, q);
-#endif
 }
 
 // Bracket of mass m in a mass column (LDS-resident in the hot roles; any pointer works): the largest i in [0, n-2] with mass[i] <= m
@@ -53,9 +49,7 @@ __device__ __forceinline__ double fdiv(double num, double den)
 // LDS round trips where one was meant (measured: a WD star's chain of ~10 searches took 7 us of its 9.7).  So: the
 // loads are unconditional (clamped index, never past the axis), written into an array before any is looked at, and
 // fenced so the scheduler keeps them together (B9_PROBE_FENCE).
-#ifndef B9_PROBE_FENCE
 #define B9_PROBE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 template <bool DESC>
 __device__ __forceinline__ int count7(const double (&v)[7], double x)
 {
@@ -126,9 +120,6 @@ __device__ __forceinline__ void find_bracket(const double *mass, int n, double m
         lo += count7_tail<false>(v, len, m);
     }
     const double a = mass[lo], d = mass[lo + 1] - a;
-#ifdef B9_EXACT_DIV
-    t_out = (d > 0.0) ? (m - a) / d : 0.0;
-#else
     // (m - a) / d by a v_rcp_f64 seed, two Newton steps and a residual correction: within 1 ulp of
     // the IEEE quotient (the weight is then off by <= 1e-16 relative -- seven orders inside the
     // stated tolerance) at a third of the instructions and latency of the exact division sequence
@@ -139,7 +130,6 @@ __device__ __forceinline__ void find_bracket(const double *mass, int n, double m
     double tq = num * r;
     tq = fma(fma(-d, tq, num), r, tq);
     t_out = (d > 0.0) ? tq : 0.0;
-#endif
     lo_out = lo;
 }
 
@@ -197,11 +187,7 @@ __device__ inline double prec_log_age_corner(const DevPack &pk, const double *ti
 {
     const int na = pk.n_age;
     const double tip0 = tips[0];
-#ifdef B9_ABL_HEAVY_CHEAPMATH
-    if (m > tip0) return log_age[0] - 2.7 * 0.43 * (m - tip0);
-#else
     if (m > tip0) return log_age[0] - 2.7 * log10(m / tip0);
-#endif
     if (m <= tips[na - 1]) return log_age[na - 1];
     const int lo = bracket8<true>(tips, na, m);              // (here tips[0] >= m > tips[na-1])
     const double a = tips[lo], b = tips[lo + 1];
@@ -469,9 +455,7 @@ __device__ __forceinline__ double chi2_system(const DevPack &pk, const WdAxes &a
 // chi2_system above (identical bits), but no per-filter arrays: the role needs a third of the registers, so it
 // neither spills nor sets the register budget of the kernel it shares with the hot role.
 // ------------------------------------------------------------------------------------------
-#ifndef B9_HEAVY_UNROLL
 #define B9_HEAVY_UNROLL 4          // filters per batch of table-row loads (a batch = one memory round trip; 8 costs 15 more VGPRs)
-#endif
 struct Comp {
     int kind;               // 0: no flux (99.999)   1: two rows, lerp t   2: four rows, lerp t then tg   3: constant -4
     const double *r0, *r1;  // kind 1: r0 = lower isochrone row (upper = r0 + NFP); kind 2: r0 / r1 = the two log g rows
@@ -513,21 +497,13 @@ __device__ __forceinline__ Comp comp_desc(const DevPack &pk, const WdAxes &ax, c
     const double log_age = par[B9_P_LOGAGE];
     if (prec >= log_age) { c.kind = 3; return c; }
     const double wd_mass = ifmr(pk.ifmr_id, par, m);
-#ifdef B9_ABL_HEAVY_CHEAPMATH      // ablation build only (wrong results): what the library transcendentals cost the chain
-    const double log_cool = fma(log_age, 0.99, -0.01 * prec);
-#else
     const double log_cool = log10(exp10(log_age) - exp10(prec));
-#endif
     HS2(4); B9_MARK("hv-explog-done");
     double tr[2];
     wd_cooling(pk, ax, par, wd_mass, log_cool, tr[0], tr[1]);
     HS2(6); B9_MARK("hv-cooling-done");
     const double log_teff = tr[0];
-#ifdef B9_ABL_HEAVY_CHEAPMATH
-    const double logg = LOG_G_PLUS_LOG_MSUN + (wd_mass - 1.0) * 0.43 - 2.0 * tr[1];
-#else
     const double logg = LOG_G_PLUS_LOG_MSUN + log10(wd_mass) - 2.0 * tr[1];
-#endif
     const int ty = (wd_type > 0 && pk.n_at_type > 1) ? 1 : 0;
     const int it = bracket8<false>(ax.at_log_teff, pk.n_at_teff, log_teff);
     c.t = fdiv(log_teff - ax.at_log_teff[it], ax.at_log_teff[it + 1] - ax.at_log_teff[it]);

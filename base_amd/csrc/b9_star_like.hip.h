@@ -3,47 +3,45 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------
-// k_star_like  (given-mass mode): the hot kernel.  One lane per star, MS/RGB branch only --
-// stars heavier than the walker's AGB tip (WD / NS-BH branch; two contiguous ranges because
-// stars are sorted by mass) are left to k_finalize so that pow/log10 and the WD tables do not
-// cost this kernel registers.
+// k_star_like  (given-mass mode): the star kernel of b9_logpost; its two roles are also the fused sampler step's
+// (k_mcmc_step) and the tree-speculative step's (k_mcmc_tree).
+//   HOT workgroups: one lane per star, MS/RGB branch only (hot_star).
+//   HEAVY workgroups (they lead the grid): the stars heavier than the walker's AGB tip -- WD branch or NS/BH -- through
+//   the general per-star code (heavy_stars), beside the hot ones, so that the WD tables and library transcendentals cost
+//   the hot role no registers.
 //
 // Workgroup -> (star tile, walker) map is XCD-aware: workgroups are dealt round-robin over the 8
 // XCDs, so linear id L runs on XCD L % 8.  All walkers of one star tile are given ids with the
 // same L % 8 and consecutive L / 8: the tile's star data is fetched from HBM once into that
 // XCD's L2 and re-read from L2 by the other walkers.  (Placement affects speed only.)
+//
+// CANONICAL TILE GROUPS.  The catalogue's tiles (256 slots each) are dealt into n_groups groups of group_tiles tiles:
+// group c = tiles c, c + n_groups, c + 2 n_groups, ... (strided over the slot order: binary tiles lead it, so every
+// group gets its share of expensive and cheap tiles).  A wave multiplies the field-star mixture factors of its 64 stars
+// of the group's tiles in that order and writes ONE partial per group: partial[c * 4 + wave].  n_groups and group_tiles
+// are functions of the catalogue, the pack and the device ONLY (make_groups in b9_capi.cpp) -- not of how many walkers
+// share the GPU -- so a walker's log-posterior is the same BITS whatever the launch plan: a workgroup takes
+// groups_per_block whole groups (g, g + n_blocks, ...), and that number is the plan's only freedom.
 // ------------------------------------------------------------------------------------------
-#ifndef B9_K1_MIN_WAVES
-#define B9_K1_MIN_WAVES 3
-#endif
-#ifndef B9_K1_MIN_WAVES_16F
-#define B9_K1_MIN_WAVES_16F 2       // 16 padded filters: the body needs ~250 VGPRs; built for three waves it spills 230-330 B per lane
-                                    // and runs 30 % slower (50k x 16 x 8 walkers: 43.9 vs 30.6 us per step)
-#endif
-// waves per SIMD the star kernels are built for (launch bounds): 3 = up to 168 VGPRs, 2 = up to 256
-#define B9_K1_WAVES(NFP, NPOPS) (((NFP) > 8 && B9_K1_MIN_WAVES > B9_K1_MIN_WAVES_16F) ? B9_K1_MIN_WAVES_16F : B9_K1_MIN_WAVES)
+// waves per SIMD the star kernels are built for (launch bounds): 3 = up to 168 VGPRs; 16 padded filters need ~250 VGPRs --
+// built for three waves that body spills 230-330 B per lane and runs 30 % slower (50k x 16 x 8 walkers: 43.9 vs 30.6 us
+// per step) -- so they are built for 2
+#define B9_K1_WAVES(NFP, NPOPS) ((NFP) > 8 ? 2 : 3)
 
-#ifndef B9_EARLY_OBS
-#define B9_LATE_OBS 1        // measured: 20.3 us vs 22.3 us (early) on the 50k x 8 x 8 bench shape
-#endif
-#ifdef B9_LATE_OBS
-#define B9_OBS_ARGS const DevStars &st, int il, const double *stage
-#else
-#define B9_OBS_ARGS double c0, const double (&obs)[NFP], const double (&wgt)[NFP]
-#endif
-// -DB9_QUAD_PASS: filters in passes of four (rows + observations of a pass requested together).
-// Measured equal to the all-at-once form (20.7 vs 20.6 us) and only 5 VGPRs leaner -- the pressure
-// comes from the unrolled exp/log temporaries, not the row arrays -- so it is off by default.
+// The tile of canonical group c that a workgroup reaches at step t of its tile sequence (group_tiles steps per group,
+// groups_per_block groups: g, g + n_blocks, ...); -1 past the end.
+struct TileSeq {
+    int g, n_blocks, n_groups, group_tiles, groups_per_block, n_tiles;
+    __device__ __forceinline__ int group(int j) const { const int c = g + j * n_blocks; return (j < groups_per_block && c < n_groups) ? c : -1; }
+    __device__ __forceinline__ int tile(int c, int t) const { const int k = c + t * n_groups; return (c >= 0 && t < group_tiles && k < n_tiles) ? k : -1; }
+};
+
 template <int NFP, int NPOPS>
 __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP> (&iso)[NPOPS],
                                            double mod, double av, double m1, double q,
-                                           B9_OBS_ARGS, double log_lam, double log_1ml)
+                                           const DevStars &st, int il, double log_lam, double log_1ml)
 {
-#ifdef B9_ABL_NOBIN
-    const bool binary = false;
-#else
     const bool binary = q > 0.0;
-#endif
     const double m2 = q * m1;
     double ll[2] = {0.0, 0.0};
     // The population loop is deliberately NOT unrolled: unrolled, the compiler overlaps the two
@@ -52,14 +50,12 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
     // The isochrone view is picked with wave-uniform selects.
 #pragma unroll 1
     for (int k = 0; k < NPOPS; ++k) {
-#ifndef B9_NO_POP_LAUNDER
         // Two populations: everything the second pass could share with the first (observations, weights, the
         // per-filter shifts, both brackets' inputs) would be hoisted out of this loop and kept in registers across
         // BOTH passes -- ~60 VGPRs, the difference between two and three waves per SIMD.  The star index and the
         // absorption are passed through an empty asm so that each pass re-derives them (the re-read observations
         // come from the L1 the first pass filled).
         if (NPOPS == 2) { asm volatile("" : "+v"(il)); asm volatile("" : "+v"(av)); }
-#endif
         const double *is_mass = (NPOPS == 2 && k) ? iso[NPOPS - 1].mass : iso[0].mass;
         const double *is_mags = (NPOPS == 2 && k) ? iso[NPOPS - 1].mags : iso[0].mags;
         const int is_n = (NPOPS == 2 && k) ? iso[NPOPS - 1].n : iso[0].n;
@@ -68,56 +64,13 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         const double mass0 = is_mass[0];                    // (read once, unconditionally: `||` made it two branches with an LDS round trip each)
         const bool dark1 = !(m1 > 0.0) | (m1 < mass0);
         const bool dark2 = !(m2 > 0.0) | (m2 < mass0);
-#ifdef B9_ABL_NOSEARCH
-        lo1 = (int)(m1 * 100.0) % (is_n - 1); t1 = m1 - (int)m1; lo2 = lo1 / 2; t2 = t1;
-#else
         find_bracket(is_mass, is_n, m1, lo1, t1);
         if (binary) find_bracket(is_mass, is_n, m2, lo2, t2);
-#endif
         STAMP(4);
         // two consecutive rows = 2*NFP contiguous doubles
         const double2 *r1 = reinterpret_cast<const double2 *>(is_mags + (size_t)lo1 * NFP);
         const double2 *r2 = reinterpret_cast<const double2 *>(is_mags + (size_t)lo2 * NFP);
         double chi2 = 0.0;
-#if defined(B9_QUAD_PASS) && defined(B9_LATE_OBS)
-        // Passes of four filters.  Each pass requests its slice of the primary rows, of the secondary
-        // rows and of the observed magnitudes / weights TOGETHER (one round trip per pass, the same
-        // two round trips as the all-at-once form at 8 filters), so only a quarter of the row and
-        // observation registers are live at a time.
-#pragma unroll 1
-        for (int h = 0; h < NFP / 4; ++h) {
-            double2 a1[4], a2[4];
-            a1[0] = r1[2 * h]; a1[1] = r1[2 * h + 1]; a1[2] = r1[NFP / 2 + 2 * h]; a1[3] = r1[NFP / 2 + 2 * h + 1];
-            if (binary) { a2[0] = r2[2 * h]; a2[1] = r2[2 * h + 1]; a2[2] = r2[NFP / 2 + 2 * h]; a2[3] = r2[NFP / 2 + 2 * h + 1]; }
-            double o[4], wv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = st.obs[B9_SIDX(NFP, 4 * h + j, il)];
-                wv[j] = st.w[B9_SIDX(NFP, 4 * h + j, il)];
-            }
-            double p[4];
-            p[0] = dark1 ? B9_MAG_NOFLUX : lerp(a1[0].x, a1[2].x, t1);
-            p[1] = dark1 ? B9_MAG_NOFLUX : lerp(a1[0].y, a1[2].y, t1);
-            p[2] = dark1 ? B9_MAG_NOFLUX : lerp(a1[1].x, a1[3].x, t1);
-            p[3] = dark1 ? B9_MAG_NOFLUX : lerp(a1[1].y, a1[3].y, t1);
-            if (binary) {
-                double s[4];
-                s[0] = dark2 ? B9_MAG_NOFLUX : lerp(a2[0].x, a2[2].x, t2);
-                s[1] = dark2 ? B9_MAG_NOFLUX : lerp(a2[0].y, a2[2].y, t2);
-                s[2] = dark2 ? B9_MAG_NOFLUX : lerp(a2[1].x, a2[3].x, t2);
-                s[3] = dark2 ? B9_MAG_NOFLUX : lerp(a2[1].y, a2[3].y, t2);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) p[j] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s[j] - p[j]));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double d = (p[j] + (mod + pk.abs_m1[4 * h + j] * av)) - o[j];
-                chi2 = fma(wv[j] * d, d, chi2);
-            }
-        }
-        const double c0 = st.c0[il];
-        STAMP(6);
-#else
         double2 a1[NFP], a2[NFP];
 #pragma unroll
         for (int j = 0; j < NFP; ++j) a1[j] = r1[j];
@@ -133,11 +86,7 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
         }
         STAMP(5);
         if (binary) {
-#ifdef B9_COMBINE_UNROLL
-#pragma unroll B9_COMBINE_UNROLL
-#else
 #pragma unroll
-#endif
             for (int j = 0; j < NFP / 2; ++j) {
                 const double s0 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].x, a2[NFP / 2 + j].x, t2);
                 const double s1 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].y, a2[NFP / 2 + j].y, t2);
@@ -146,35 +95,22 @@ __device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP>
             }
         }
         STAMP(6);
-#ifdef B9_LATE_OBS
         // observed magnitudes and weights are requested only now: they cost 32 VGPRs while live,
         // and keeping them out of the search / row / combine phases buys a wave per SIMD
         __builtin_amdgcn_sched_barrier(0);
         double obs[NFP], wgt[NFP];
         double c0;
-        if (stage) {
-            // the fused step stages this wave's observed magnitudes, weights and c0 in LDS with asynchronous
-            // global->LDS loads issued at the START of the tile (stage_tile): by now they have landed, so
-            // this phase costs LDS reads instead of a memory round trip
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int f = 0; f < NFP; ++f) { obs[f] = stage[f * 64]; wgt[f] = stage[(NFP + f) * 64]; }
-            c0 = stage[2 * NFP * 64];
-        } else {
-#pragma unroll
-            for (int f = 0; f < NFP; ++f) {
-                obs[f] = st.obs[B9_SIDX(NFP, f, il)];
-                wgt[f] = st.w[B9_SIDX(NFP, f, il)];
-            }
-            c0 = st.c0[il];
+        for (int f = 0; f < NFP; ++f) {
+            obs[f] = st.obs[B9_SIDX(NFP, f, il)];
+            wgt[f] = st.w[B9_SIDX(NFP, f, il)];
         }
-#endif
+        c0 = st.c0[il];
 #pragma unroll
         for (int f = 0; f < NFP; ++f) {
             const double d = (p[f] + (mod + pk.abs_m1[f] * av)) - obs[f];
             chi2 = fma(wgt[f] * d, d, chi2);
         }
-#endif
         const double llk = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
         if (k == 0) ll[0] = llk; else ll[1] = llk;
     }
@@ -197,11 +133,7 @@ struct MixAcc {
 
 __device__ __forceinline__ void mix_add(MixAcc &a, double ea, double l)
 {
-#ifdef B9_ABL_NOMIX
-    const bool additive = true;
-#else
     const bool additive = (ea == 0.0) || (l > 600.0);
-#endif
     const double u = additive ? 1.0 : ea + exp_fast(l);
     a.add += additive ? l : 0.0;
     const double m = a.mant * u;
@@ -352,12 +284,7 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
 #pragma unroll
     for (int c = 0; c < NC; ++c) none[c] = !(m_first > tip_min[c]);
     bool spec = false;
-#ifdef B9_HEAVY_SPECULATE      // measured: a loss (the chain does not start earlier -- the role's first round trip, not the decision, is what it
-                               // waits for -- and a heavy star under EITHER candidate now costs its chain: C2 16.5 -> 17.7 us/step)
-    if (NC == 2 && both_exist) spec = (!valid[0] || m_T <= tip_min[0]) && (!valid[NC - 1] || m_T <= tip_min[NC - 1]);
-#else
     (void)m_T; (void)both_exist;
-#endif
     const int sel = (NC == 2 && !spec) ? select() : 0;
     const int wpc = spec ? 2 : 4;                                                // waves per candidate
     const int cand = spec ? (wave >> 1) : sel;                                   // this wave's candidate
@@ -482,15 +409,15 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     }
 }
 
-template <int NFP, int NPOPS, int WB>
+template <int NFP, int NPOPS>
 __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevPack pk, DevStars st,
                                                     const IsoHdr *__restrict__ hdr,
                                                     const double *__restrict__ iso_data,
                                                     long long iso_stride, int mass_cap,
                                                     const double *__restrict__ params, int n_walkers,
-                                                    double *__restrict__ partial, long long partial_stride, int n_groups,
-                                                    double *__restrict__ perstar, int tiles_per_block,
-                                                    int hot_blocks, int heavy_parts)
+                                                    double *__restrict__ partial, long long partial_stride,
+                                                    int n_groups, int group_tiles, int groups_per_block, int n_blocks,
+                                                    double *__restrict__ perstar, int hot_blocks, int heavy_parts)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // Heavy-star workgroups come FIRST in the grid (hot_blocks = their padded count): they have the
@@ -499,132 +426,83 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevP
         const int hb = blockIdx.x;
         if (hb >= n_walkers * heavy_parts) return;            // padding to a multiple of 8
         const int w = hb / heavy_parts, part = hb - w * heavy_parts;
-#ifndef B9_ABL_NO_HEAVY
-        {
-            const IsoHdr *const h1[1] = {hdr};
-            const double *const i1[1] = {iso_data}, *const p1[1] = {params};
-            double *const o1[1] = {partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part};
-            heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, iso_stride, mass_cap, p1, [] { return 0; }, false, w, part, heavy_parts, o1, perstar, smem);
-        }
-#else
-        if (threadIdx.x == 0) partial[(size_t)w * partial_stride + (size_t)n_groups * 4 + part] = 0.0;   // ablation build
-#endif
+        const IsoHdr *const h1[1] = {hdr};
+        const double *const i1[1] = {iso_data}, *const p1[1] = {params};
+        double *const o1[1] = {partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part};
+        heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, iso_stride, mass_cap, p1, [] { return 0; }, false, w, part, heavy_parts, o1, perstar, smem);
         return;
     }
-    // LDS: the mass column of each (walker, population) isochrone this workgroup evaluates -- the binary search runs in LDS (dependent ds_reads
+    // LDS: the mass column of each population's isochrone -- the bracket search runs in LDS (dependent ds_reads
     // instead of dependent L2 round trips); the magnitude rows a star needs are then read from L2
     // (coalesced: stars are sorted by mass, so neighbouring lanes hit the same or adjacent rows).
-    // A lane keeps its star in registers and evaluates it for WB walkers in turn, so the star data
-    // crosses the L2 -> CU fabric once per WB walkers.
     const int tid = threadIdx.x;
     STAMP(0);
-    const int n_wsets = (n_walkers + WB - 1) / WB;
     const int L = blockIdx.x - hot_blocks, xcd = L & 7, s = L >> 3;      // hot_blocks is a multiple of 8
-    const int wset = s % n_wsets, w0 = wset * WB;
-    const int group = (s / n_wsets) * 8 + xcd;          // tile group = tiles_per_block consecutive tiles
-    if (group >= n_groups) return;
-    const int nwb = (n_walkers - w0) < WB ? (n_walkers - w0) : WB;   // walkers in this set
-    const int tile0 = group * tiles_per_block;
+    const int w = s % n_walkers;
+    const int g = (s / n_walkers) * 8 + xcd;            // this workgroup among the walker's n_blocks
+    if (g >= n_blocks) return;
+    const TileSeq seq{g, n_blocks, n_groups, group_tiles, groups_per_block, st.n_pad / 256};
 
     // ---- first round trip: everything that depends only on the kernel arguments ------------
-    int i = tile0 * 256 + tid;
-    int il = i < st.n_pad ? i : st.n_pad - 1;               // stay inside the padded arrays
-    double m1, q, ea;
-#ifndef B9_LATE_OBS
-    double obs[NFP], wgt[NFP], c0;
-#pragma unroll
-    for (int f = 0; f < NFP; ++f) {
-        obs[f] = st.obs[B9_SIDX(NFP, f, il)];
-        wgt[f] = st.w[B9_SIDX(NFP, f, il)];
-    }
-    c0 = st.c0[il];
-#endif
-    m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
+    int i = seq.tile(seq.group(0), 0) * 256 + tid;          // (a group's first tile always exists)
+    double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
     // the mass columns: the source address needs no header field, and copying the full capacity
     // instead of hdr.n entries costs nothing (the tail is never searched)
     double *const lds_mass = smem;
-    for (int c = 0; c < nwb * NPOPS; ++c) {
-        const double2 *sm = reinterpret_cast<const double2 *>(iso_data + (size_t)(w0 * NPOPS + c) * iso_stride);
+    for (int c = 0; c < NPOPS; ++c) {
+        const double2 *sm = reinterpret_cast<const double2 *>(iso_data + (size_t)(w * NPOPS + c) * iso_stride);
         double2 *dm = reinterpret_cast<double2 *>(lds_mass + (size_t)c * mass_cap);
         for (int j = tid; j < mass_cap / 2; j += 256) dm[j] = sm[j];
     }
     // headers and the few parameters the star loop needs (scalar loads, same round trip)
-    IsoView<NFP> iso[WB][NPOPS];
-    bool valid[WB];
-    double tip_min[WB], mod[WB], av[WB], log_lam[WB], log_1ml[WB];
+    IsoView<NFP> iso[NPOPS];
+    const double *par = params + (size_t)w * B9_NPARAM;
+    bool valid = true;
+    double tip_min = __builtin_inf();
 #pragma unroll
-    for (int b = 0; b < WB; ++b) {
-        const int w = (b < nwb) ? w0 + b : w0;
-        const double *par = params + (size_t)w * B9_NPARAM;
-        bool ok = b < nwb;
-        double tmin = __builtin_inf();
-#pragma unroll
-        for (int kp = 0; kp < NPOPS; ++kp) {
-            const IsoHdr h = hdr[w * NPOPS + kp];
-            ok = ok && h.valid;
-            iso[b][kp].n = h.n; iso[b][kp].tip = h.agb_tip;
-            iso[b][kp].i_feh = h.i_feh; iso[b][kp].i_y = h.i_y; iso[b][kp].t_feh = h.t_feh; iso[b][kp].t_y = h.t_y;
-            iso[b][kp].mass = lds_mass + (size_t)(b * NPOPS + kp) * mass_cap;
-            iso[b][kp].mags = iso_data + (size_t)(w * NPOPS + kp) * iso_stride + mass_cap;
-            tmin = h.agb_tip < tmin ? h.agb_tip : tmin;
-        }
-        valid[b] = ok; tip_min[b] = tmin;
-        mod[b] = par[B9_P_MOD]; av[b] = par[B9_P_ABS];
-        const double lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
-        log_lam[b] = NPOPS == 2 ? log(lam) : 0.0;
-        log_1ml[b] = NPOPS == 2 ? log1p(-lam) : 0.0;
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        const IsoHdr h = hdr[w * NPOPS + kp];
+        valid = valid && h.valid;
+        iso[kp].n = h.n; iso[kp].tip = h.agb_tip;
+        iso[kp].i_feh = h.i_feh; iso[kp].i_y = h.i_y; iso[kp].t_feh = h.t_feh; iso[kp].t_y = h.t_y;
+        iso[kp].mass = lds_mass + (size_t)kp * mass_cap;
+        iso[kp].mags = iso_data + (size_t)(w * NPOPS + kp) * iso_stride + mass_cap;
+        tip_min = h.agb_tip < tip_min ? h.agb_tip : tip_min;
     }
+    const double mod = par[B9_P_MOD], av = par[B9_P_ABS], lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
+    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
     STAMP(1);
     __syncthreads();
     STAMP(2);
 
-    MixAcc acc[WB];
-#pragma unroll
-    for (int b = 0; b < WB; ++b) { acc[b].mant = 0.5; acc[b].expo = 1; acc[b].add = 0.0; }   // = 1.0
-    for (int t = 0; t < tiles_per_block; ++t) {
-        if ((tile0 + t) * 256 >= st.n_pad) break;
-        if (t > 0) {
-            i = (tile0 + t) * 256 + tid;
-            il = i < st.n_pad ? i : st.n_pad - 1;
-#ifndef B9_LATE_OBS
-#pragma unroll
-            for (int f = 0; f < NFP; ++f) {
-                obs[f] = st.obs[B9_SIDX(NFP, f, il)];
-                wgt[f] = st.w[B9_SIDX(NFP, f, il)];
+    for (int j = 0; j < groups_per_block; ++j) {
+        const int c = seq.group(j);
+        if (c < 0) break;
+        MixAcc acc;
+        acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;            // = 1.0
+        for (int t = 0; t < group_tiles; ++t) {
+            const int tile = seq.tile(c, t);
+            if (tile < 0) break;
+            if (j > 0 || t > 0) {
+                i = tile * 256 + tid;
+                m1 = st.mass1[i]; q = st.q[i]; ea = st.ea[i];
             }
-            c0 = st.c0[il];
-#endif
-            m1 = st.mass1[il]; q = st.q[il]; ea = st.ea[il];
-        }
-        STAMP(3);
-#pragma unroll
-        for (int b = 0; b < WB; ++b) {
-            if (b >= nwb) continue;
-            const int w = w0 + b;
-            if (!valid[b]) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
-                if (perstar && i < st.n_pad && st.perm[i] >= 0) perstar[(size_t)w * st.n + st.perm[i]] = NEG_INF;
+            STAMP(3);
+            if (!valid) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
+                if (perstar && st.perm[i] >= 0) perstar[(size_t)w * st.n + st.perm[i]] = NEG_INF;
                 continue;
             }
-            if (i < st.n_pad && !(m1 > tip_min[b])) {     // empty slots hold m1 = +inf
-#ifdef B9_LATE_OBS
-                const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, st, il, nullptr, log_lam[b], log_1ml[b]);
-#else
-                const double l = hot_star<NFP, NPOPS>(pk, iso[b], mod[b], av[b], m1, q, c0, obs, wgt, log_lam[b], log_1ml[b]);
-#endif
-                mix_add(acc[b], ea, l);
+            if (!(m1 > tip_min)) {     // empty slots hold m1 = +inf
+                const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, i, log_lam, log_1ml);
+                mix_add(acc, ea, l);
                 if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = mix_value(ea, l);
             }
         }
-    }
-    STAMP(7);
-    // wave combine (one log per wave and walker); every wave stores its own partial -- no
-    // end-of-kernel barrier, so a cheap (single-star) wave never waits for an expensive one
-#pragma unroll
-    for (int b = 0; b < WB; ++b) {
-        const double tot = mix_wave_total(acc[b]);
-        if ((tid & 63) == 0 && b < nwb)
-            partial[(size_t)(w0 + b) * partial_stride + group * 4 + (tid >> 6)] = valid[b] ? tot : 0.0;
+        STAMP(7);
+        // wave combine (one log per wave); every wave stores its own partial -- no end-of-kernel barrier, so a cheap
+        // (single-star) wave never waits for an expensive one
+        const double tot = mix_wave_total(acc);
+        if ((tid & 63) == 0) partial[(size_t)w * partial_stride + c * 4 + (tid >> 6)] = valid ? tot : 0.0;
     }
     STAMP(8);
 }
-

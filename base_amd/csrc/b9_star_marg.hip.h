@@ -67,27 +67,6 @@ __device__ __forceinline__ double gumbel(unsigned k0, unsigned k1, unsigned long
     return -log(-log(u01(r[0], r[1])));
 }
 
-#ifdef B9_MARG_STATS      // diagnostic build only (tools/marg_stats.py): what the marginalised kernel executes per star
-__device__ unsigned long long g_marg_stats[8];
-#define MSTAT(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_marg_stats[k], (unsigned long long)(v)); } while (0)
-extern "C" int b9_debug_marg_stats(unsigned long long *out, int clear)
-{
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_marg_stats), sizeof(unsigned long long) * 8);
-    if (clear) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_marg_stats), z, sizeof z); }
-    return rc;
-}
-#else
-#define MSTAT(k, v) do {} while (0)
-#endif
-#ifdef B9_MARG_LIFE       // diagnostic build only (tools/marg_life.py): start / end of every workgroup, units evaluated by its wave 0
-__device__ unsigned long long g_marg_life[16384 * 4];
-#define MLIFE(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_marg_life[blockIdx.x * 4 + (k)] = (v); } while (0)
-#define MLIFE_UNIT() do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_marg_life[blockIdx.x * 4 + 2] += 1; } while (0)
-extern "C" int b9_debug_marg_life(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_marg_life), sizeof(unsigned long long) * 16384 * 4); }
-#else
-#define MLIFE(k, v) do {} while (0)
-#define MLIFE_UNIT() do {} while (0)
-#endif
 
 // v_max_f64 / v_min_f64 / v_fma_f64 with a wave-uniform (SGPR) operand, as single instructions.  Written out because the
 // compiler (i) brackets every fmax / fmin of values it cannot prove quiet with two canonicalising v_max x, x -- 8 instructions
@@ -335,9 +314,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                 auto term = [&](const SRow<NFP> &r, int i) {
                     const double x = srow_x<NFP>(r, obs, wgt);
                     const bool live = x < xcut;
-#ifdef B9_MARG_STATS
-                    { const unsigned long long lm = __ballot(live); MSTAT(4, __popcll(lm)); }
-#endif
+                    MSTAT_LIVE(4, live);
                     if (live) {
                         const double t = -0.5 * x;
                         if (SAMPLE) {

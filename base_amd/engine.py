@@ -88,6 +88,16 @@ class Engine:
             setattr(t, k, int(v))
         self._check(self.lib.b9_set_tuning(self._ctx, C.byref(t)))
 
+    def update_tuning(self, **fields) -> None:
+        """b9_get_tuning + b9_set_tuning: change the named fields only (the environment's overrides and earlier settings stay)."""
+        t = abi.b9_tuning()
+        self._check(self.lib.b9_get_tuning(self._ctx, C.byref(t)))
+        for k, v in fields.items():
+            if not hasattr(t, k):
+                raise AttributeError(f"b9_tuning has no field {k}")
+            setattr(t, k, int(v))
+        self._check(self.lib.b9_set_tuning(self._ctx, C.byref(t)))
+
     # -- hot path -------------------------------------------------------------------------
     def logpost(self, params: np.ndarray, perstar: bool = False):
         params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, abi.B9_NPARAM)

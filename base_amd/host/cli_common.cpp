@@ -131,10 +131,13 @@ void open_session(Session &s, int argc, char **argv, int n_pops, bool need_phot)
     }
     check(b9_set_priors(s.ctx, &s.priors));
     check(b9_set_options(s.ctx, &s.options));
-    // --tilesPerBlock n pins how a walker's star terms are grouped into partial sums (b9_tuning): with it a walker's chain
-    // is the same bits for every --gpus; left automatic, the grouping follows the number of walkers per GPU
+    // --tilesPerBlock n pins the size of the canonical tile groups a walker's star terms are summed in (b9_tuning).  A
+    // walker's chain is the same bits for every --gpus either way -- the automatic size follows the catalogue, not the
+    // number of walkers per GPU -- the option only chooses another (equally valid) rounding.  Only that field changes: the
+    // B9_* environment overrides read at the context's creation stay in force.
     if (const long tpb = st.integer("gpu.tilesPerBlock", 0)) {
         b9_tuning t{};
+        check(b9_get_tuning(s.ctx, &t));
         t.tiles_per_block = (int32_t)std::max<long>(0, tpb);
         check(b9_set_tuning(s.ctx, &t));
     }

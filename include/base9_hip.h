@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define B9_ABI_VERSION 3
+#define B9_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------ */
 typedef enum b9_status {
@@ -158,25 +158,24 @@ typedef struct b9_options {
 } b9_options;
 
 /*
- * Launch-plan tuning (ABI 3).  Every field 0 = automatic (what a context starts with); results are the same for every
+ * Launch-plan tuning (ABI 4).  Every field 0 = automatic (what a context starts with); results are the same for every
  * setting to the stated tolerance -- these only regroup the same work (tests/test_gpu_mcmc.py runs the combinations).
- * The one field with a contract is tiles_per_block: a hot workgroup sums its waves' star terms over the tiles it owns,
- * so the ROUNDING of a walker's log-posterior depends on it; the automatic choice depends on the number of walkers
- * on the GPU and on the device's occupancy.  A driver that wants a walker's chain to be the same BITS whatever the
- * number of GPUs the walkers are spread over must pin it (singlePopMcmc --tilesPerBlock n does).
+ * The one field that touches the ROUNDING of a walker's log-posterior is tiles_per_block: the catalogue's tiles are dealt
+ * into canonical groups of that many tiles and every wave forms one partial per group.  Its automatic value is a function
+ * of the catalogue, the pack, the options and the device ONLY -- not of the number of walkers on the GPU -- so a walker's
+ * chain is the same bits whatever the number of GPUs the walkers are spread over (since ABI 4; before, the automatic value
+ * followed the local walker count and a driver had to pin it).
  * The same fields can be set through the environment, read ONCE when the context is created: B9_TILES_PER_BLOCK,
  * B9_DERIVE_PARTS, B9_DERIVE_ORDER (historical coding: 1 default, 0 heavy first, < 0 derivation trails), B9_HEAVY_PARTS,
- * B9_WALKERS_PER_LANE, B9_CONTIGUOUS_TILES, B9_TWO_LAUNCH_STEPS, B9_MARG_NO_PRUNING, B9_TIMING_GROUP, B9_PLAN_DEBUG, B9_TREE_DEPTH;
+ * B9_TWO_LAUNCH_STEPS, B9_MARG_NO_PRUNING, B9_TIMING_GROUP, B9_PLAN_DEBUG, B9_TREE_DEPTH;
  * B9_STREAM_PRIORITY=default gives the context's stream the default priority instead of the lowest.
  */
 typedef struct b9_tuning {
-    int32_t tiles_per_block;   /* star tiles (256 stars) per hot workgroup of k_star_like / k_mcmc_step                    */
+    int32_t tiles_per_block;   /* star tiles (256 stars) per CANONICAL tile group of k_star_like / k_mcmc_step / k_mcmc_tree  */
     int32_t derive_parts;      /* fused step: workgroups per candidate isochrone                                         */
     int32_t derive_order;      /* fused step grid: 1 writers + derivation lead (default), 2 heavy-star workgroups lead,  */
                                /* 3 derivation workgroups trail the hot ones                                            */
     int32_t heavy_parts;       /* workgroups per walker for the stars above the AGB tip (default: sized from the catalogue) */
-    int32_t walkers_per_lane;  /* k_star_like: 2 = two walkers per lane (halves L2 traffic, doubles the chain); default 1 */
-    int32_t contiguous_tiles;  /* 1: a hot workgroup's tiles are consecutive even when the launch is one occupancy round  */
     int32_t two_launch_steps;  /* 1: the derive + star launch pair per sampler step also in given-mass mode                */
     int32_t marg_no_pruning;   /* 1: marginalised kernel evaluates every node of every star (no floor, no boxes): the      */
                                /* brute-force statement of the same sum on the GPU, for tests                            */
@@ -188,7 +187,7 @@ typedef struct b9_tuning {
                                /* workgroups are all resident at once AND whose estimated cost per step beats the one-step  */
                                /* launch's (few walkers per GPU, catalogues that leave the chip under-filled), else 1.      */
                                /* Env: B9_TREE_DEPTH                                                                        */
-    int32_t reserved[5];
+    int32_t reserved[7];
 } b9_tuning;
 
 typedef struct b9_ctx b9_ctx;
@@ -209,6 +208,9 @@ int b9_set_priors(b9_ctx *ctx, const b9_priors *priors);
 int b9_set_options(b9_ctx *ctx, const b9_options *opt);
 /* tuning NULL = everything automatic again.  Not while a block is outstanding. */
 int b9_set_tuning(b9_ctx *ctx, const b9_tuning *tuning);
+/* The tuning in force: the B9_* environment overrides read at creation, then whatever the last b9_set_tuning passed -- a
+ * caller that wants to change ONE field reads, modifies and writes back (ABI 4). */
+int b9_get_tuning(const b9_ctx *ctx, b9_tuning *out);
 
 /* ---- the hot path -------------------------------------------------------------------- */
 /*

@@ -181,38 +181,31 @@ def _two_ranks_one_gpu(pack, stars, priors, options, start, tuning, **run_kw):
     return results
 
 
-def test_rank_count_invariance_at_50k_stars_needs_the_grouping_pinned():
-    """At 50 000 stars the automatic launch plan gives 8 walkers on one GPU 3 tiles per hot workgroup and 4 walkers (the
-    same 8 spread over two ranks) 2: the per-wave partial sums group different stars, so a walker's log-posterior rounds
-    differently -- the chains agree to the tolerance, not to the bit.  With b9_tuning.tiles_per_block pinned
-    on both sides they are the same bits."""
+@pytest.mark.parametrize("n_walkers", [8, 16])
+def test_rank_count_invariance_at_50k_stars(n_walkers):
+    """A walker's chain is the same BITS whatever the number of ranks its ensemble is spread over -- with nothing pinned.
+    The star-to-partial-sum grouping (canonical tile groups: DESIGN.md section 6) is a function of the catalogue, the pack and
+    the device only; a launch plan only chooses how many whole groups a workgroup takes.  50 000 stars: 8 walkers on one GPU
+    against 4 + 4 on two ranks (same groups per workgroup, half the workgroups), and 16 walkers on one GPU -- two groups
+    = 6 tiles per hot workgroup -- against 8 + 8 at one group = 3 tiles: the plans differ, the bits do not."""
     from base_amd import engine
     cfg = synth.make_baseline_config("C2")
     pack, stars, priors, options = cfg["pack"], cfg["stars"], cfg["priors"], cfg["options"]
-    start = synth.walker_params(cfg["truth"], 8, seed=42, scale=0.02)
-    kw = dict(burn=60, main=20, block=20)
+    start = synth.walker_params(cfg["truth"], n_walkers, seed=42, scale=0.02)
+    kw = dict(n_walkers=n_walkers, burn=60, main=20, block=20)
     eng1 = engine.Engine(pack, stars, priors, options)
-    t8, t4 = eng1.step_tiles_per_block(8), eng1.step_tiles_per_block(4)
-    assert t8 != t4, "the two plans no longer differ: pick another shape for this test"
+    t_all, t_half = eng1.step_tiles_per_block(n_walkers), eng1.step_tiles_per_block(n_walkers // 2)
+    if n_walkers == 16:
+        assert t_all != t_half, "the two launch plans no longer differ: pick another shape for this case"
     st1, samples1, lps1 = _device_run(eng1, hostlib.Exchange.local(), start, **kw)
-    eng1.set_tuning(tiles_per_block=t8)
-    st1p, samples1p, lps1p = _device_run(eng1, hostlib.Exchange.local(), start, **kw)
-    np.testing.assert_array_equal(samples1p, samples1)             # (pinning the fused step's automatic value moves no walker;
-    #  the starting log-posteriors come from b9_logpost, whose own grouping the pin changes too: the last bit of a row may differ)
     eng1.close()
-    # automatic plans: equal to the tolerance
     (sa, xa, la), (sb, xb, lb) = _two_ranks_one_gpu(pack, stars, priors, options, start, None, **kw)
-    lps2 = np.concatenate([la, lb], axis=1)
-    np.testing.assert_allclose(np.concatenate([xa, xb], axis=1), samples1, rtol=1e-9, atol=1e-12)
-    assert np.max(np.abs(lps2 - lps1) / np.maximum(1.0, np.abs(lps1))) <= 1e-9
-    # pinned grouping on both sides: the same bits
-    (sa, xa, la), (sb, xb, lb) = _two_ranks_one_gpu(pack, stars, priors, options, start, dict(tiles_per_block=t8), **kw)
-    np.testing.assert_array_equal(np.concatenate([xa, xb], axis=1), samples1p)
-    np.testing.assert_array_equal(np.concatenate([la, lb], axis=1), lps1p)
+    np.testing.assert_array_equal(np.concatenate([xa, xb], axis=1), samples1)
+    np.testing.assert_array_equal(np.concatenate([la, lb], axis=1), lps1)
     for st in (sa, sb):
-        np.testing.assert_array_equal(st["chol"], st1p["chol"])
-        assert st["scale"] == st1p["scale"]
-        np.testing.assert_array_equal(st["all_logpost"], st1p["all_logpost"])
+        np.testing.assert_array_equal(st["chol"], st1["chol"])
+        assert st["scale"] == st1["scale"]
+        np.testing.assert_array_equal(st["all_logpost"], st1["all_logpost"])
 
 
 def _oracle_delta(orc, template_row, free, samples, lps):
