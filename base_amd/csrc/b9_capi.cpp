@@ -563,10 +563,12 @@ TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
 {
     TreePlan tp{1, 1, 1, 1};
     if (ctx->tree_depth == 1) return tp;
-    const int key = (ctx->pk.nfp * 4 + n_pops) * 65536 + ctx->mass_cap;
+    const Groups gr = make_groups(ctx, n_pops);
+    if (gr.n_groups > B9_TREE_MAX_GROUPS) return tp;        // more canonical groups than a walk reads: the one-step launch
+    const int key = ((ctx->pk.nfp * 4 + n_pops) * 65536 + ctx->mass_cap) * 2 + (gr.n_groups > 16 * B9_TREE_KD_SMALL ? 1 : 0);
     if (ctx->tree_occ_key != key) {
         int per_cu = 0;
-        if (b9k_mcmc_tree_occupancy(ctx->pk, n_pops, ctx->mass_cap, &per_cu) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (b9k_mcmc_tree_occupancy(ctx->pk, n_pops, ctx->mass_cap, gr.n_groups, &per_cu) != hipSuccess || per_cu < 1) per_cu = 1;
         ctx->tree_blocks_per_cu = per_cu;
         ctx->tree_occ_key = key;
     }
@@ -578,9 +580,7 @@ TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
         const long long NN = (1 << d) - 1, NO = 1 << d;
         // one canonical group per hot workgroup; the walk reads a node's partials in one round trip, which bounds their number
         // (the grouping fixes the summation order and is never changed for the tree's sake: no tree then)
-        const Groups gr = make_groups(ctx, n_pops);
         const int tpb = gr.group_tiles, n_groups = gr.n_groups;
-        if (n_groups > B9_TREE_MAX_GROUPS) continue;
         const long long fixed = n_walkers * (1 + NN * ctx->heavy_parts + NN * 8 * ((n_groups + 7) / 8));
         const long long per_part = (long long)n_walkers * NO * NN * n_pops;
         const long long room = (long long)(0.95 * slots) - fixed;

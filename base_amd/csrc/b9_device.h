@@ -255,8 +255,11 @@ struct StepDev {
 // ------------------------------------------------------------------------------------------
 #define B9_TREE_MAX_DEPTH 3
 #define B9_TREE_MAX_NODES 7
-#define B9_TREE_KD 3                 // partials per lane and node the walk reads in its one round trip: a node has at most 64 KD hot
-#define B9_TREE_MAX_GROUPS (16 * B9_TREE_KD)      // partials = this many tile groups (the launch plan raises the tiles per workgroup to stay under it)
+// partials per lane and node the walk reads in its one round trip (B9_TREE_KD of the tree kernels' two builds, b9_mcmc_tree.hip.h):
+// a node has at most 64 KD hot partials = 16 KD canonical tile groups
+#define B9_TREE_KD_SMALL 3
+#define B9_TREE_KD_LARGE 5
+#define B9_TREE_MAX_GROUPS (16 * B9_TREE_KD_LARGE)
 #define B9_TS_CUR 0              // [0..11]  state after the decision this launch took
 #define B9_TS_LP 12              // its log-posterior
 #define B9_TS_NACC 13            // proposals accepted so far in the block

@@ -48,7 +48,17 @@
 #include "b9_star.hip.h"
 #include "b9_star_like.hip.h"
 #include "b9_mcmc_step.hip.h"
+#define B9_TREE_KD B9_TREE_KD_SMALL
+namespace tree_kd3 {
 #include "b9_mcmc_tree.hip.h"
+}
+#undef B9_TREE_KD
+#undef B9_TREE_KV
+#define B9_TREE_KD B9_TREE_KD_LARGE
+namespace tree_kd5 {
+#include "b9_mcmc_tree.hip.h"
+}
+#undef B9_TREE_KD
 #include "b9_star_marg.hip.h"
 
 // ------------------------------------------------------------------------------------------
@@ -298,10 +308,10 @@ static size_t mcmc_tree_lds(const DevPack &pk, int mass_cap)
 }
 
 template <int NFP, int NPOPS>
-static hipError_t mcmc_tree_occupancy(const DevPack &pk, int mass_cap, int *blocks_per_cu)
+static hipError_t mcmc_tree_occupancy(const DevPack &pk, int mass_cap, int n_groups, int *blocks_per_cu)
 {
     const size_t lds = mcmc_tree_lds<NFP, NPOPS>(pk, mass_cap);
-    auto kern = k_mcmc_tree<NFP, NPOPS>;
+    auto kern = n_groups > 16 * B9_TREE_KD_SMALL ? tree_kd5::k_mcmc_tree<NFP, NPOPS> : tree_kd3::k_mcmc_tree<NFP, NPOPS>;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -310,10 +320,10 @@ static hipError_t mcmc_tree_occupancy(const DevPack &pk, int mass_cap, int *bloc
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(kern), 256, lds);
 }
 
-hipError_t b9k_mcmc_tree_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu)
+hipError_t b9k_mcmc_tree_occupancy(const DevPack &pk, int n_pops, int mass_cap, int n_groups, int *blocks_per_cu)
 {
-#define OC2(NFP) mcmc_tree_occupancy<NFP, 2>(pk, mass_cap, blocks_per_cu)
-#define OC1(NFP) mcmc_tree_occupancy<NFP, 1>(pk, mass_cap, blocks_per_cu)
+#define OC2(NFP) mcmc_tree_occupancy<NFP, 2>(pk, mass_cap, n_groups, blocks_per_cu)
+#define OC1(NFP) mcmc_tree_occupancy<NFP, 1>(pk, mass_cap, n_groups, blocks_per_cu)
     B9_SWITCH_NFP(OC2, OC1)
 #undef OC1
 #undef OC2
@@ -324,7 +334,7 @@ static hipError_t launch_mcmc_tree(const DevPack &pk, const DevStars &st, const 
                                    int derive_parts, hipStream_t stream)
 {
     const size_t lds = mcmc_tree_lds<NFP, NPOPS>(pk, td.mass_cap);
-    auto kern = k_mcmc_tree<NFP, NPOPS>;
+    auto kern = td.n_groups > 16 * B9_TREE_KD_SMALL ? tree_kd5::k_mcmc_tree<NFP, NPOPS> : tree_kd3::k_mcmc_tree<NFP, NPOPS>;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -353,13 +363,14 @@ hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &t
 
 hipError_t b9k_tree_finish(const TreeDev &td, const DevPriors &pr, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_tree_finish, dim3(td.n_walkers), dim3(256), 0, stream, td, pr);
+    if (td.n_groups > 16 * B9_TREE_KD_SMALL) hipLaunchKernelGGL(tree_kd5::k_tree_finish, dim3(td.n_walkers), dim3(256), 0, stream, td, pr);
+    else hipLaunchKernelGGL(tree_kd3::k_tree_finish, dim3(td.n_walkers), dim3(256), 0, stream, td, pr);
     return hipGetLastError();
 }
 
 hipError_t b9k_tree_begin(const double *host_up, double *dev, int up_words, const double *prev_final, double *state, int n_walkers, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_tree_begin, dim3(1), dim3(256), 0, stream, host_up, dev, up_words, prev_final, state, n_walkers);
+    hipLaunchKernelGGL(tree_kd3::k_tree_begin, dim3(1), dim3(256), 0, stream, host_up, dev, up_words, prev_final, state, n_walkers);
     return hipGetLastError();
 }
 

@@ -68,7 +68,7 @@ hipError_t b9k_mcmc_finish(const DevPack &pk, const StepDev &sd, const DevPriors
 // tree-speculative step (given-mass mode, few walkers): one launch = `depth` steps of every chain (TreeDev in b9_device.h)
 hipError_t b9k_mcmc_tree(const DevPack &pk, const DevStars &st, const TreeDev &td, const DevPriors &pr, int group_tiles /* tiles of a canonical group */,
                          int derive_parts, hipStream_t stream);
-hipError_t b9k_mcmc_tree_occupancy(const DevPack &pk, int n_pops, int mass_cap, int *blocks_per_cu);
+hipError_t b9k_mcmc_tree_occupancy(const DevPack &pk, int n_pops, int mass_cap, int n_groups /* of the catalogue: selects the kernel build */, int *blocks_per_cu);
 hipError_t b9k_tree_finish(const TreeDev &td, const DevPriors &pr, hipStream_t stream);
 hipError_t b9k_tree_begin(const double *host_up, double *dev, int up_words, const double *prev_final, double *state, int n_walkers, hipStream_t stream);
 

@@ -1,8 +1,10 @@
 // b9_mcmc_tree.hip.h -- k_mcmc_tree: the tree-speculative sampler step (TreeDev in b9_device.h): one launch advances
 // every chain by `depth` Metropolis steps.  For launches with few walkers, where the one-step fused launch
 // (k_mcmc_step) leaves most of the GPU idle and a chain's rate is set by the launch's latency chain, not by its work.
-// Part of the single translation unit b9_kernels.hip (included there, in this order); gfx950 only.
-#pragma once
+// Part of the single translation unit b9_kernels.hip; gfx950 only.  Included there TWICE (no include guard), inside the
+// namespaces tree_kd3 / tree_kd5 with B9_TREE_KD = 3 / 5: the walk reads a node's partial sums in one round trip, KD words
+// per lane, so KD bounds the catalogue's canonical tile groups (16 KD).  Three words serve the BASELINE single-chain shapes
+// at the registers they always had; five let a 50 000-star catalogue (66 groups) keep the tree launch at 2 - 4 walkers.
 
 
 __device__ __forceinline__ int tree_level(int n) { return 32 - __clz(n + 1); }          // floor(log2(n + 1)) + 1
