@@ -20,11 +20,15 @@
 namespace b9h {
 
 // One string per launch, shared by its ranks: the launcher's own (B9_LAUNCH_NONCE), or torchrun's run id + restart count.
+// Empty when the environment names no launch (srun / mpirun exporting only RANK): see RcclExchange.
 std::string launch_nonce()
 {
-    if (const char *n = std::getenv("B9_LAUNCH_NONCE")) return n;
-    const char *run = std::getenv("TORCHELASTIC_RUN_ID"), *restart = std::getenv("TORCHELASTIC_RESTART_COUNT");
-    std::string s = std::string(run ? run : "0") + "_" + (restart ? restart : "0");
+    std::string s;
+    if (const char *n = std::getenv("B9_LAUNCH_NONCE")) s = n;
+    else if (const char *run = std::getenv("TORCHELASTIC_RUN_ID")) {
+        const char *restart = std::getenv("TORCHELASTIC_RESTART_COUNT");
+        s = std::string(run) + "_" + (restart ? restart : "0");
+    }
     for (char &c : s) if (!(std::isalnum((unsigned char)c) || c == '_' || c == '-')) c = '_';
     return s;
 }
@@ -71,12 +75,18 @@ class RcclExchange final : public Exchange {
     RcclExchange(int rank, int world, const std::string &dir, int device, double timeout_s) : rank_(rank), world_(world), device_(device)
     {
         if (world < 1 || rank < 0 || rank >= world) fail("bad rank / world");
+        // The id file carries this LAUNCH's nonce in its name, so an id a crashed or restarted attempt left in a reused
+        // directory (torchrun elastic restart, a user-supplied B9_DIST_DIR) is never read; the directory must be ours.
+        // A launcher that names no launch (only RANK / WORLD_SIZE exported) would make every attempt share one file name,
+        // and a rank > 0 could pick up a dead attempt's id and wait in ncclCommInitRank for ever: refused.
+        const std::string nonce = launch_nonce();
+        if (nonce.empty() && world > 1)
+            fail("no launch id: export B9_LAUNCH_NONCE=<a string unique to this launch, the same on every rank> "
+                 "(our own launchers and torchrun provide one)");
         test_stall("before-init", rank);
         HIPX(hipSetDevice(device));
         ncclUniqueId id;
-        // The id file carries this LAUNCH's nonce in its name, so an id a crashed or restarted attempt left in a reused
-        // directory (torchrun elastic restart, a user-supplied B9_DIST_DIR) is never read; the directory must be ours.
-        const std::string path = dir + "/rccl_id." + launch_nonce();
+        const std::string path = dir + "/rccl_id." + (nonce.empty() ? std::string("single") : nonce);
         if (rank == 0) {
             NCCLX(ncclGetUniqueId(&id));
             if (::mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) fail("cannot create " + dir);
@@ -146,8 +156,8 @@ class RcclExchange final : public Exchange {
             }
         }
         test_stall("after-init", rank);
-        {   // ready marker for the launcher's start-up deadline
-            const std::string ready = dir + "/ready." + std::to_string(rank);
+        if (std::getenv("B9_LAUNCH_NONCE")) {   // ready marker for OUR launchers' start-up deadline (they remove it; nobody else would)
+            const std::string ready = dir + "/ready." + nonce + "." + std::to_string(rank);
             if (FILE *f = std::fopen(ready.c_str(), "w")) std::fclose(f);
         }
     }

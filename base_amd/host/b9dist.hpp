@@ -45,7 +45,9 @@ std::unique_ptr<Exchange> make_local_exchange();
 // <dir>/rccl_id.<nonce> (written under a temporary name, then renamed; the nonce names the launch -- B9_LAUNCH_NONCE, or
 // torchrun's run id and restart count -- so an id left behind by an earlier attempt is never picked up; <dir> must
 // belong to this user and not be writable by others); the others wait for the file (up to timeout_s), and every rank
-// calls ncclCommInitRank on `device`, then touches <dir>/ready.<rank> (a launcher's start-up deadline watches these).  The exchange owns a non-blocking HIP stream of the HIGHEST priority
+// calls ncclCommInitRank on `device`, then -- under OUR launchers (B9_LAUNCH_NONCE set), which watch for them and remove
+// them -- touches <dir>/ready.<nonce>.<rank>.  With world > 1 and no launch id in the environment (a launcher exporting
+// only RANK) the constructor refuses before any GPU call and asks for B9_LAUNCH_NONCE.  The exchange owns a non-blocking HIP stream of the HIGHEST priority
 // (the sampler's context stream has the lowest: the gather gets in between two of its kernels), device and pinned
 // host buffers for two slots, and reads device rows in place.  Throws std::runtime_error.
 std::unique_ptr<Exchange> make_rccl_exchange(int rank, int world, const std::string &dir, int device, double timeout_s = 120.0);
@@ -62,7 +64,8 @@ void rank_from_env(int &rank, int &world, int &local_rank);
 // the multi-rank route whatever the rank count (B9_FORCE_RANKS=1: --forceRanks / --force-ranks with one GPU)
 bool forced_ranks();
 
-// One string per launch, shared by its ranks (names the RCCL id file): B9_LAUNCH_NONCE, or torchrun's run id + restart count.
+// One string per launch, shared by its ranks (names the RCCL id file): B9_LAUNCH_NONCE, or torchrun's run id + restart
+// count; empty when the environment names no launch.
 std::string launch_nonce();
 
 // Test hook: B9_TEST_STALL="<where>:<rank>" parks that rank for ever at the named point ("start": before anything touches

@@ -123,6 +123,7 @@ const std::map<std::string, std::string> &Settings::flag_map()
         {"seed", "general.seed"}, {"verbose", "general.verbose"},
         {"walkers", "gpu.walkers"}, {"device", "gpu.device"}, {"block", "gpu.block"}, {"gpus", "gpu.gpus"},
         {"mode", "gpu.mode"}, {"marginalise", "gpu.marginalise"}, {"forceRanks", "gpu.forceRanks"}, {"tilesPerBlock", "gpu.tilesPerBlock"},
+        {"resComment", "gpu.resComment"},
         {"margIsoIncrem", "sampleMass.margIsoIncrem"}, {"nMassRatios", "sampleMass.nMassRatios"},
     };
     return m;
@@ -137,7 +138,7 @@ void Settings::parse_args(int argc, char **argv)
         std::string value;
         size_t eq = a.find('=');
         if (eq != std::string::npos) { value = a.substr(eq + 1); a = a.substr(0, eq); }
-        else if (a == "verbose" || a == "marginalise" || a == "forceRanks") value = "1";
+        else if (a == "verbose" || a == "marginalise" || a == "forceRanks" || a == "resComment") value = "1";
         else { if (i + 1 >= argc) fail("flag --" + a + " needs a value"); value = argv[++i]; }
         if (a == "config") { load_yaml(value); continue; }
         auto it = flag_map().find(a);

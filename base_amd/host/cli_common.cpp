@@ -10,6 +10,9 @@
 #include <fstream>
 #include <stdexcept>
 
+#include <cerrno>
+
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -159,9 +162,14 @@ void remove_bootstrap_dir(const std::string &dir, int n)
     // only what a launch of ours can have put there: the id file of THIS launch's nonce and the ranks' ready markers
     const char *nonce = std::getenv("B9_LAUNCH_NONCE");
     if (nonce) { std::remove((dir + "/rccl_id." + nonce).c_str()); std::remove((dir + "/rccl_id." + nonce + ".tmp").c_str()); }
-    for (int r = 0; r < n; ++r) std::remove((dir + "/ready." + std::to_string(r)).c_str());
+    if (nonce) for (int r = 0; r < n; ++r) std::remove((dir + "/ready." + nonce + "." + std::to_string(r)).c_str());
     rmdir(dir.c_str());
 }
+
+// SIGINT / SIGTERM to the launcher: the wait loop below sees the flag, forwards SIGTERM to the ranks (SIGKILL 5 s later),
+// reaps them and removes the bootstrap directory -- nothing is left parked in ncclCommInitRank
+volatile sig_atomic_t g_launcher_signal = 0;
+void on_launcher_signal(int sig) { g_launcher_signal = sig; }
 
 }  // namespace
 
@@ -188,6 +196,12 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
     // not come.  B9_RUN_TIMEOUT_S (default: none): the whole run.  Either one ends the launch: the ranks are killed and
     // the launcher exits 124.
     const double init_deadline = env_seconds("B9_LAUNCH_TIMEOUT_S", 300.0), run_deadline = env_seconds("B9_RUN_TIMEOUT_S", 0.0);
+    struct sigaction sa{}, old_int{}, old_term{};
+    sa.sa_handler = on_launcher_signal;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGINT, &sa, &old_int);
+    sigaction(SIGTERM, &sa, &old_term);
+    const pid_t launcher_pid = getpid();
     std::vector<pid_t> kids;
     for (int r = 0; r < n; ++r) {
         const pid_t pid = fork();
@@ -199,6 +213,10 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
             throw std::runtime_error("fork failed");
         }
         if (pid == 0) {
+            sigaction(SIGINT, &old_int, nullptr);
+            sigaction(SIGTERM, &old_term, nullptr);
+            prctl(PR_SET_PDEATHSIG, SIGTERM);                   // a launcher that dies without a word (SIGKILL) still ends its ranks
+            if (getppid() != launcher_pid) _exit(143);          // (it died between fork and prctl)
             setenv("B9_RANK", std::to_string(r).c_str(), 1);
             setenv("B9_WORLD_SIZE", std::to_string(n).c_str(), 1);
             setenv("B9_LOCAL_RANK", std::to_string(r).c_str(), 1);
@@ -222,8 +240,17 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
     auto end_all = [&](int sig) { for (pid_t k : kids) if (k > 0) kill(k, sig); };
     while (left > 0) {
         int status = 0;
+        if (g_launcher_signal && !killing) {
+            std::fprintf(stderr, "launcher: signal %d: ending the %zu rank(s)\n", (int)g_launcher_signal, left);
+            if (!first_fail) first_fail = 128 + (int)g_launcher_signal;
+            end_all(SIGTERM); killing = true; kill_time = std::chrono::steady_clock::now();
+        }
         const pid_t k = waitpid(-1, &status, WNOHANG);
-        if (k < 0) { if (!first_fail) first_fail = 1; break; }
+        if (k < 0) {
+            if (errno == EINTR) continue;                       // a signal arrived: the ranks are still ours to reap
+            if (!first_fail) first_fail = 1;                    // ECHILD: nothing left to wait for
+            break;
+        }
         if (k > 0) {
             auto it = std::find(kids.begin(), kids.end(), k);
             if (it == kids.end()) continue;
@@ -235,7 +262,7 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
         }
         if (!all_ready) {
             all_ready = true;
-            for (int r = 0; r < n && all_ready; ++r) all_ready = access((std::string(dir) + "/ready." + std::to_string(r)).c_str(), F_OK) == 0;
+            for (int r = 0; r < n && all_ready; ++r) all_ready = access((std::string(dir) + "/ready." + nonce + "." + std::to_string(r)).c_str(), F_OK) == 0;
         }
         const bool late_start = !all_ready && init_deadline > 0.0 && elapsed() > init_deadline;
         const bool late_run = run_deadline > 0.0 && elapsed() > run_deadline;
@@ -250,6 +277,8 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
         usleep(20000);
     }
     remove_bootstrap_dir(dir, n);
+    sigaction(SIGINT, &old_int, nullptr);
+    sigaction(SIGTERM, &old_term, nullptr);
     *exit_code = first_fail;
     return true;
 }
@@ -315,13 +344,21 @@ McmcResult run_mcmc(Session &s, Exchange &ex, const std::vector<std::string> &co
     const std::string final_path = s.output_base + ".res";
     const bool parts_route = ex.world() > 1 || forced_ranks();      // (--forceRanks: one rank still writes a part and merges it)
     const std::string my_path = parts_route ? final_path + ".part" + std::to_string(ex.rank()) : final_path;
-    // the file says what it is: which posterior was sampled (the evaluation mode decides that) and by which ABI
+    // What the run sampled -- which posterior (the evaluation mode decides that), by which ABI -- goes to the sidecar
+    // <base>.res.meta; the .res itself keeps the one-header-line layout [RECALL] that upstream's tools and
+    // np.loadtxt(skiprows=1) expect.  --resComment puts the same text into the .res as a leading "# ..." line as well.
     std::string what = "base9_hip ABI " + std::to_string(b9_abi_version()) + "; mode=" +
                        (s.options.mode == B9_MODE_MARGINALISED
                             ? "marginalised (margIsoIncrem=" + std::to_string(s.options.marg_iso_increm) + ", nMassRatios=" + std::to_string(s.options.marg_n_q) + ")"
                             : std::string("givenMass")) +
                        "; populations=" + std::to_string(s.options.n_pops) + "; walkers=" + std::to_string(W);
-    std::unique_ptr<ResultWriter> out(new ResultWriter(my_path, columns, what));
+    const bool in_file = s.settings.integer("gpu.resComment", 0) != 0;
+    if (ex.rank() == 0) {
+        std::ofstream meta(final_path + ".meta");
+        meta << what << "\n";
+        if (!meta) throw std::runtime_error("cannot write " + final_path + ".meta");
+    }
+    std::unique_ptr<ResultWriter> out(new ResultWriter(my_path, columns, in_file ? what : std::string()));
     long rows_written = 0;
     const long total = cfg.burn_iter + cfg.run_iter;
     std::vector<double> v(d);

@@ -77,6 +77,22 @@ def launch_ranks(args) -> int:
             return default
     init_deadline, run_deadline = seconds("B9_LAUNCH_TIMEOUT_S", 300.0), seconds("B9_RUN_TIMEOUT_S", 0.0)
     procs, logs = [], []
+    first_fail, live, kill_at = 0, {}, None
+    got_signal = []
+    # SIGINT / SIGTERM to the launcher: forwarded to the ranks (SIGTERM, SIGKILL 5 s later) by the wait loop; the finally
+    # block below reaps whatever is left and removes the bootstrap directory on every way out
+    old_handlers = {sig: signal.signal(sig, lambda s_, f_: got_signal.append(s_)) for sig in (signal.SIGINT, signal.SIGTERM)}
+
+    def end_all(sig):
+        for q in live.values():
+            q.send_signal(sig)
+
+    def die_with_parent():       # (child side, before exec) a launcher killed without a word still ends its ranks
+        try:
+            import ctypes
+            ctypes.CDLL(None).prctl(1, int(signal.SIGTERM))     # PR_SET_PDEATHSIG
+        except Exception:
+            pass
     try:
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), B9_DIST_DIR=dist_dir,
@@ -87,64 +103,71 @@ def launch_ranks(args) -> int:
             out = None if r == 0 else open(os.path.join(dist_dir, f"rank{r}.log"), "w")
             logs.append(out)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                          stdout=out, stderr=subprocess.STDOUT if out else None))
-    except OSError:
-        for p in procs:          # the ranks already started would wait for the missing ones
-            p.terminate()
-        for p in procs:
-            p.wait()
-        raise
-    # wait for all of them; a rank that fails takes the others with it (a peer blocked in the communicator would wait
-    # for it for ever) -- exactly the processes started above, by pid
-    t0 = time.monotonic()
-    first_fail, live, all_ready, kill_at = 0, dict(enumerate(procs)), False, None
-
-    def end_all(sig):
-        for q in live.values():
-            q.send_signal(sig)
-    while live:
-        for r, p in list(live.items()):
-            code = p.poll()
-            if code is None:
-                continue
-            del live[r]
-            if code != 0 and not first_fail:
-                first_fail = code if code > 0 else 128 - code
-            if code != 0 and kill_at is None:
+                                          stdout=out, stderr=subprocess.STDOUT if out else None, preexec_fn=die_with_parent))
+        # wait for all of them; a rank that fails takes the others with it (a peer blocked in the communicator would wait
+        # for it for ever) -- exactly the processes started above, by pid
+        t0 = time.monotonic()
+        live, all_ready = dict(enumerate(procs)), False
+        while live:
+            if got_signal and kill_at is None:
+                sys.stderr.write("bench.py launcher: signal %d: ending the %d rank(s)\n" % (got_signal[0], len(live)))
+                first_fail = first_fail or 128 + int(got_signal[0])
                 end_all(signal.SIGTERM)
                 kill_at = time.monotonic()
-        if not live:
-            break
-        if not all_ready:
-            all_ready = all(os.path.exists(os.path.join(dist_dir, f"ready.{r}")) for r in range(args.gpus))
-        late_start = not all_ready and init_deadline > 0 and time.monotonic() - t0 > init_deadline
-        late_run = run_deadline > 0 and time.monotonic() - t0 > run_deadline
-        if (late_start or late_run) and kill_at is None:
-            sys.stderr.write("bench.py launcher: %s after %.0f s (%s): ending the %d remaining rank(s)\n" % (
-                "not every rank brought its RCCL communicator up" if late_start else "the run did not finish",
-                time.monotonic() - t0, "B9_LAUNCH_TIMEOUT_S" if late_start else "B9_RUN_TIMEOUT_S", len(live)))
-            first_fail = first_fail or 124
-            end_all(signal.SIGTERM)
-            kill_at = time.monotonic()
-        if kill_at is not None and time.monotonic() - kill_at > 5.0:
-            end_all(signal.SIGKILL)
-        time.sleep(0.02)
-    for r, f in enumerate(logs):
-        if f:
-            f.close()
-            txt = open(f.name).read()
-            if txt.strip() and first_fail:
-                sys.stderr.write(f"---- rank {r} ----\n{txt}\n")
-            os.unlink(f.name)
-    for name in [f"rccl_id.{nonce}", f"rccl_id.{nonce}.tmp"] + [f"ready.{r}" for r in range(args.gpus)]:
+            for r, p in list(live.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del live[r]
+                if code != 0 and not first_fail:
+                    first_fail = code if code > 0 else 128 - code
+                if code != 0 and kill_at is None:
+                    end_all(signal.SIGTERM)
+                    kill_at = time.monotonic()
+            if not live:
+                break
+            if not all_ready:
+                all_ready = all(os.path.exists(os.path.join(dist_dir, f"ready.{nonce}.{r}")) for r in range(args.gpus))
+            late_start = not all_ready and init_deadline > 0 and time.monotonic() - t0 > init_deadline
+            late_run = run_deadline > 0 and time.monotonic() - t0 > run_deadline
+            if (late_start or late_run) and kill_at is None:
+                sys.stderr.write("bench.py launcher: %s after %.0f s (%s): ending the %d remaining rank(s)\n" % (
+                    "not every rank brought its RCCL communicator up" if late_start else "the run did not finish",
+                    time.monotonic() - t0, "B9_LAUNCH_TIMEOUT_S" if late_start else "B9_RUN_TIMEOUT_S", len(live)))
+                first_fail = first_fail or 124
+                end_all(signal.SIGTERM)
+                kill_at = time.monotonic()
+            if kill_at is not None and time.monotonic() - kill_at > 5.0:
+                end_all(signal.SIGKILL)
+            time.sleep(0.02)
+    finally:
+        for p in procs:          # any way out (an OSError while starting ranks, an exception in the loop): no rank is left behind
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=5.0)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        for r, f in enumerate(logs):
+            if f:
+                f.close()
+                txt = open(f.name).read()
+                if txt.strip() and first_fail:
+                    sys.stderr.write(f"---- rank {r} ----\n{txt}\n")
+                os.unlink(f.name)
+        for name in [f"rccl_id.{nonce}", f"rccl_id.{nonce}.tmp"] + [f"ready.{nonce}.{r}" for r in range(args.gpus)]:
+            try:
+                os.unlink(os.path.join(dist_dir, name))
+            except OSError:
+                pass
         try:
-            os.unlink(os.path.join(dist_dir, name))
+            os.rmdir(dist_dir)
         except OSError:
             pass
-    try:
-        os.rmdir(dist_dir)
-    except OSError:
-        pass
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
     return first_fail
 
 

@@ -16,11 +16,14 @@ HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 
 def _res_head(path):
-    """(the leading "# ..." comment, the column names) of a .res file."""
+    """(the provenance note of the sidecar <path>.meta, the column names) of a .res file -- which by default starts with
+    its ONE header line, the [RECALL] layout (a consumer that skips exactly one line reads data next)."""
     with open(path) as f:
-        lines = [f.readline(), f.readline()]
-    assert lines[0].startswith("# base9_hip ABI "), lines[0]
-    return lines[0], lines[1].split()
+        first = f.readline()
+    assert not first.startswith("#"), first
+    note = open(path + ".meta").read()
+    assert note.startswith("base9_hip ABI "), note
+    return note, first.split()
 
 
 @pytest.fixture(scope="module")
@@ -169,7 +172,7 @@ def test_mcmc_cli_runs_and_recovers_truth(hostlib, tmp_path, prog, n_pops, n_y):
     assert r.returncode == 0, r.stderr
     assert "star-likelihood evals/s" in r.stderr
     note, head = _res_head(str(tmp_path / "run.res"))
-    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=2)
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
     assert "mode=givenMass" in note and f"populations={n_pops}" in note and "walkers=4" in note
     assert head[0] == "logAge" and head[-2:] == ["logPost", "stage"] and res.shape == (5500 * 4, len(head))
     main = res[res[:, -1] == 3]
@@ -226,7 +229,7 @@ def test_samplemass_cli_matches_oracle(hostlib, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "star draws/s" in r.stderr
     note, head = _res_head(str(tmp_path / "run.res"))
-    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=2)
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
     main = res[res[:, -1] == 3]
     ms = np.loadtxt(str(tmp_path / "run.massSamples"), skiprows=1)
     mb = np.loadtxt(str(tmp_path / "run.membership"), skiprows=1)
@@ -312,8 +315,14 @@ def test_mcmc_cli_marginalised_mode(hostlib, tmp_path):
     assert "marginalised mode" in r.stderr
     note, head = _res_head(str(tmp_path / "run.res"))
     assert "mode=marginalised (margIsoIncrem=2, nMassRatios=2)" in note and "walkers=2" in note
-    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=2)
+    res = np.loadtxt(str(tmp_path / "run.res"), skiprows=1)
     assert res.shape == (30 * 2, len(head))
+    # --resComment: the same note as a leading "# ..." line of the .res itself, nothing else changes
+    plain = open(str(tmp_path / "run.res")).read()
+    r = _cli("singlePopMcmc", "--config", y, "--marginalise", "--margIsoIncrem", "2", "--nMassRatios", "2", "--block", "10", "--resComment")
+    assert r.returncode == 0, r.stderr
+    noted = open(str(tmp_path / "run.res")).read()
+    assert noted == "# " + note + plain
     cl2 = dict(cl0)
     lo, hi = np.where(np.asarray(cl["sigma"]) > 0, cl["obs"], np.inf).min(axis=0), np.where(np.asarray(cl["sigma"]) > 0, cl["obs"], -np.inf).max(axis=0)
     cl2["filter_prior_min"], cl2["filter_prior_max"] = lo, hi

@@ -64,6 +64,51 @@ def test_exit_code_is_the_first_failure_not_the_sigterm_of_its_peers(which):
     assert _dist_dirs() == before
 
 
+@pytest.mark.parametrize("which", ["cli", "bench"])
+def test_sigterm_to_the_launcher_ends_its_ranks_and_cleans_up(which):
+    """SIGTERM (or ^C) to the launcher is forwarded to the ranks, they are reaped, the bootstrap directory is
+    removed, and the exit code says which signal it was -- no rank is left parked in ncclCommInitRank."""
+    import signal
+    before = _dist_dirs()
+    cmd = [EXE, "--gpus", "1", "--forceRanks"] if which == "cli" else [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-ranks"]
+    env = dict(os.environ, B9_TEST_STALL="start:0", B9_LAUNCH_TIMEOUT_S="100")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "B9_RANK"):
+        env.pop(k, None)
+    env["B9_TEST_STALL"] = "start:0"
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.monotonic() + 60.0
+    kids = []
+    while time.monotonic() < deadline and len(kids) < 1:      # the rank has started (a child of the launcher)
+        kids = [int(x) for x in subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()]
+        time.sleep(0.05)
+    assert len(kids) == 1, kids
+    time.sleep(1.0)                                           # (parked in the test hook by now)
+    t0 = time.monotonic()
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert time.monotonic() - t0 < 20.0
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err[-2000:])
+    assert "signal 15" in err
+    for k in kids:                                           # reaped, not orphaned
+        assert not os.path.exists(f"/proc/{k}"), k
+    assert _dist_dirs() == before, "the launcher left its bootstrap directory behind"
+
+
+def test_rccl_bootstrap_refuses_a_launch_without_an_id(tmp_path):
+    """ranks started by a launcher that names no launch (only RANK exported) would all use one id-file name, so
+    a rank > 0 could read a dead attempt's id and hang: the exchange refuses before touching a GPU and says what to export."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from base_amd import hostlib\n"
+            "try:\n"
+            "    hostlib.Exchange.rccl(1, 2, 0, %r)\n"
+            "except Exception as e:\n"
+            "    print('REFUSED', e); sys.exit(0)\n"
+            "sys.exit(3)\n") % (ROOT, str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if k not in ("B9_LAUNCH_NONCE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "REFUSED" in r.stdout and "B9_LAUNCH_NONCE" in r.stdout, (r.returncode, r.stdout, r.stderr[-1500:])
+
+
 def test_a_profile_of_other_sources_drops_the_counters(tmp_path, monkeypatch):
     """bench.py divides the profile's per-launch counters by the LIVE launch time: when the kernel sources have changed
     since the profile was taken, the counters are dropped (with the reason) instead of silently mixing two builds."""
