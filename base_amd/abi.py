@@ -193,7 +193,7 @@ ABI_SYMBOLS = [
     "b9_load_pack", "b9_load_stars", "b9_set_priors", "b9_set_options", "b9_set_tuning", "b9_get_tuning",
     "b9_logpost", "b9_logpost_device", "b9_mcmc_run_block", "b9_mcmc_wait", "b9_sample_mass", "b9_derive_isochrone",
     "b9_max_eep", "b9_device_id", "b9_bytes_per_star_eval", "b9_step_tiles_per_block", "b9_step_depth",
-    "b9_enable_timing", "b9_kernel_time_ms", "b9_calibrate_timing",
+    "b9_enable_timing", "b9_kernel_time_ms", "b9_calibrate_timing", "b9_clock_stamp", "b9_clock_mhz",
 ]
 
 
@@ -232,4 +232,6 @@ def load_hip_library(path: Optional[str] = None) -> C.CDLL:
     lib.b9_enable_timing.argtypes = [vp, C.c_int]
     lib.b9_kernel_time_ms.argtypes = [vp, C.c_int, _dp, _ip]
     lib.b9_calibrate_timing.argtypes = [vp, _dp]
+    lib.b9_clock_stamp.argtypes = [vp, C.c_int32]
+    lib.b9_clock_mhz.argtypes = [vp, _dp, _dp, _dp, _dp]
     return lib

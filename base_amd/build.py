@@ -40,16 +40,31 @@ def _run(cmd: List[str]) -> None:
         sys.stderr.write(r.stderr)
 
 
+HIP_SOURCES = ("b9_kernels.hip", "b9_capi_ctx.cpp", "b9_capi_stage.cpp", "b9_capi_plan.cpp", "b9_capi_eval.cpp", "b9_capi_blocks.cpp")
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-    srcs = [os.path.join(CSRC, f) for f in ("b9_kernels.hip", "b9_capi.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-        [os.path.join(ROOT, "include", "base9_hip.h")]
-    if not force and _newer(HIP_LIB, deps):
+    """One object per source under build/obj/ (recompiled when it or any header is newer), compiled in parallel, then linked."""
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "base9_hip.h")]
+    if not force and _newer(HIP_LIB, srcs + hdrs):
         return HIP_LIB
-    cmd = [HIPCC] + HIP_FLAGS + ["-shared", "-o", HIP_LIB, "-x", "hip"] + srcs
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    _run(cmd)
+    obj_dir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = [os.path.join(obj_dir, os.path.basename(s) + ".o") for s in srcs]
+
+    def compile_one(so):
+        src, obj = so
+        if not force and _newer(obj, [src] + hdrs):
+            return
+        cmd = [HIPCC] + HIP_FLAGS + ["-c", "-o", obj, "-x", "hip", src]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        _run(cmd)
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        list(ex.map(compile_one, zip(srcs, objs)))
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
     return HIP_LIB
 
 

@@ -423,3 +423,21 @@ hipError_t b9k_noop(hipStream_t stream)
     return hipGetLastError();
 }
 
+// (shader clock, 100 MHz reference clock) of every XCD, stamped by whichever of the launch's workgroups landed there: two
+// such stamps bracket a stretch of stream work, and delta(s_memtime) / delta(s_memrealtime) x 100 MHz is the clock the
+// shader engines actually ran at over it (MI355X_MICROARCH.md: the in-kernel clock, not pp_dpm_sclk).  out[xcd] = {t, tr}.
+__global__ void k_clock_stamp(unsigned long long *out)
+{
+    if (threadIdx.x != 0) return;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long t, tr;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(tr) :: "memory");
+    out[2 * (xcc & 7u)] = t;
+    out[2 * (xcc & 7u) + 1] = tr;
+}
+hipError_t b9k_clock_stamp(unsigned long long *d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_clock_stamp, dim3(64), dim3(64), 0, stream, d_out);
+    return hipGetLastError();
+}

@@ -77,3 +77,4 @@ hipError_t b9k_chain_rows(const StepDev &sd, const double *cur_fin, const double
 
 hipError_t b9k_noop(hipStream_t stream);
 hipError_t b9k_spin(double microseconds, hipStream_t stream);
+hipError_t b9k_clock_stamp(unsigned long long *d_out /* [8 XCDs][2] */, hipStream_t stream);

@@ -19,7 +19,7 @@
 // group c = tiles c, c + n_groups, c + 2 n_groups, ... (strided over the slot order: binary tiles lead it, so every
 // group gets its share of expensive and cheap tiles).  A wave multiplies the field-star mixture factors of its 64 stars
 // of the group's tiles in that order and writes ONE partial per group: partial[c * 4 + wave].  n_groups and group_tiles
-// are functions of the catalogue, the pack and the device ONLY (make_groups in b9_capi.cpp) -- not of how many walkers
+// are functions of the catalogue, the pack and the device ONLY (make_groups in b9_capi_plan.cpp) -- not of how many walkers
 // share the GPU -- so a walker's log-posterior is the same BITS whatever the launch plan: a workgroup takes
 // groups_per_block whole groups (g, g + n_blocks, ...), and that number is the plan's only freedom.
 // ------------------------------------------------------------------------------------------

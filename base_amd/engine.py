@@ -214,6 +214,16 @@ class Engine:
         self._check(self.lib.b9_calibrate_timing(self._ctx, C.byref(ms)))
         return ms.value
 
+    def clock_stamp(self, which: int) -> None:
+        """Enqueue the opening (0) / closing (1) shader-clock stamp on the context's stream."""
+        self._check(self.lib.b9_clock_stamp(self._ctx, int(which)))
+
+    def clock_mhz(self) -> Dict:
+        """Shader clock between the two stamps: median over the XCDs, extremes, length of the stretch (reference clock)."""
+        m, lo, hi, sec = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        self._check(self.lib.b9_clock_mhz(self._ctx, C.byref(m), C.byref(lo), C.byref(hi), C.byref(sec)))
+        return {"mhz": m.value, "mhz_min_xcd": lo.value, "mhz_max_xcd": hi.value, "ref_seconds": sec.value}
+
     def kernel_time_ms(self, reset: bool = True) -> Tuple[float, int]:
         ms, n = C.c_double(0), C.c_int32(0)
         self._check(self.lib.b9_kernel_time_ms(self._ctx, 1 if reset else 0, C.byref(ms), C.byref(n)))

@@ -43,6 +43,32 @@ void test_stall(const char *where, int rank)
         for (;;) std::this_thread::sleep_for(std::chrono::seconds(3600));
 }
 
+// What a multi-rank run must be able to say about itself: the communicator has exactly `world` ranks and they sit on
+// `world` DISTINCT GPUs (PCI bus ids gathered through the communicator).  Empty string = fine.
+std::string group_error(int world, int comm_ranks, const std::string &devices_csv)
+{
+    if (world <= 1) return "";
+    if (comm_ranks != world)
+        return "the RCCL communicator reports " + std::to_string(comm_ranks) + " rank(s), the launch has " + std::to_string(world);
+    std::vector<std::string> ids;
+    size_t a = 0;
+    while (a <= devices_csv.size()) {
+        const size_t b = devices_csv.find(',', a);
+        const std::string id = devices_csv.substr(a, b == std::string::npos ? std::string::npos : b - a);
+        if (!id.empty()) ids.push_back(id);
+        if (b == std::string::npos) break;
+        a = b + 1;
+    }
+    if ((int)ids.size() != world)
+        return "the communicator gathered " + std::to_string(ids.size()) + " device id(s) for " + std::to_string(world) + " rank(s): " + devices_csv;
+    for (size_t i = 0; i < ids.size(); ++i)
+        for (size_t j = i + 1; j < ids.size(); ++j)
+            if (ids[i] == ids[j])
+                return "ranks " + std::to_string(i) + " and " + std::to_string(j) + " share the GPU " + ids[i] +
+                       ": a --gpus " + std::to_string(world) + " run needs " + std::to_string(world) + " distinct devices (" + devices_csv + ")";
+    return "";
+}
+
 namespace {
 
 [[noreturn]] void fail(const std::string &msg) { throw std::runtime_error("b9dist: " + msg); }
@@ -154,6 +180,10 @@ class RcclExchange final : public Exchange {
                 all[(size_t)L * r + L - 1] = '\0';
                 devices_ += (r ? "," : "") + std::string(&all[(size_t)L * r]);
             }
+        }
+        {
+            const std::string bad = group_error(world, comm_count_, devices_);
+            if (!bad.empty()) fail(bad);
         }
         test_stall("after-init", rank);
         if (std::getenv("B9_LAUNCH_NONCE")) {   // ready marker for OUR launchers' start-up deadline (they remove it; nobody else would)

@@ -68,6 +68,11 @@ bool forced_ranks();
 // count; empty when the environment names no launch.
 std::string launch_nonce();
 
+// "" when a communicator of `comm_ranks` ranks on the GPUs `devices_csv` (PCI bus ids, comma-separated, in rank order) is
+// what a launch of `world` ranks must have: that many ranks on that many DISTINCT devices; else what is wrong.  The RCCL
+// exchange's constructor throws it; bench.py checks its own line with it.
+std::string group_error(int world, int comm_ranks, const std::string &devices_csv);
+
 // Test hook: B9_TEST_STALL="<where>:<rank>" parks that rank for ever at the named point ("start": before anything touches
 // a GPU; "before-init" / "after-init": around ncclCommInitRank), so the launchers' deadlines can be exercised.
 void test_stall(const char *where, int rank);

@@ -103,6 +103,12 @@ int b9h_exchange_devices(void *e, char *out, int cap)
     return 0;
 }
 int b9h_forced_ranks(void) { return b9h::forced_ranks() ? 1 : 0; }
+int b9h_group_check(int world, int comm_ranks, const char *devices_csv, char *msg, int cap)
+{
+    const std::string bad = b9h::group_error(world, comm_ranks, devices_csv ? devices_csv : "");
+    if (msg && cap > 0) { std::strncpy(msg, bad.c_str(), (size_t)cap - 1); msg[cap - 1] = '\0'; }
+    return bad.empty() ? 0 : 1;
+}
 void b9h_test_stall(const char *where, int rank) { b9h::test_stall(where, rank); }
 
 // ---- sampler --------------------------------------------------------------------------------------------------------

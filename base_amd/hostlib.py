@@ -31,7 +31,7 @@ HOST_SYMBOLS = [
     "b9h_last_error", "b9h_rank_from_env", "b9h_device_synchronize",
     "b9h_exchange_local", "b9h_exchange_rccl", "b9h_exchange_callback", "b9h_exchange_free", "b9h_exchange_barrier",
     "b9h_exchange_max", "b9h_exchange_world", "b9h_exchange_name", "b9h_exchange_comm_ranks", "b9h_exchange_devices",
-    "b9h_forced_ranks", "b9h_test_stall",
+    "b9h_group_check", "b9h_forced_ranks", "b9h_test_stall",
     "b9h_sampler_create", "b9h_sampler_create_callback", "b9h_sampler_free", "b9h_sampler_initialise", "b9h_sampler_run",
     "b9h_sampler_n_local", "b9h_sampler_state", "b9h_summary_rows",
     "b9h_load_pack", "b9h_free_pack", "b9h_read_phot", "b9h_free_phot", "b9h_settings_dump", "b9h_merge_parts",
@@ -64,6 +64,7 @@ def load() -> C.CDLL:
     lib.b9h_exchange_comm_ranks.argtypes = [vp]
     lib.b9h_exchange_devices.argtypes = [vp, C.c_char_p, C.c_int]
     lib.b9h_test_stall.argtypes = [C.c_char_p, C.c_int]
+    lib.b9h_group_check.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     lib.b9h_test_stall.restype = None
     lib.b9h_sampler_create.argtypes = [vp, C.c_int, C.c_int, _ip, _dp, C.c_int, C.c_uint64, C.c_int, vp, C.POINTER(vp)]
     lib.b9h_sampler_create_callback.argtypes = [BLOCK_FN, LOGPOST_FN, vp, C.c_int, _ip, _dp, C.c_int, C.c_uint64, C.c_int, vp, C.POINTER(vp)]

@@ -33,6 +33,11 @@ cpu_baseline = the CPU oracle ("port"; the reference itself is not mounted, see 
                box's host cores on a bounded sample of the same workload (rank 0, N=1); with it, |delta logPost| of
                the HIP path against that CPU path: of b9_logpost on 128 random rows AND of the timed sampler's own
                ensemble state after the timed region (delta_logpost_sampler).
+sustained    = the same loop over 5000 further steps, timed the same way (its own value / ms_per_step; `value` stays the
+               K steps'), with the shader clock observed in-kernel over that stretch (`clock_mhz_observed`): the roofline
+               peaks are quoted at the 2.4 GHz maximum, `roofline.*_at_observed_clock` rescale them.
+groups       = with N > 1 ranks the line is refused (exit 3) unless the RCCL communicator itself reports N ranks on N
+               DISTINCT GPUs (PCI bus ids gathered through it).
 marginalised_mode = the same three objects (value, roofline, cpu_baseline + delta) for the marginalised evaluation mode.
 
 Prints ONE JSON line on rank 0.
@@ -58,6 +63,7 @@ MCMC_BLOCK = 100        # steps between adaptation points (= between all-gathers
 TIMING_EVERY = 25       # a HIP-event bracket opens at every 25th launch of the dominant kernel in the timed region and spans 8 launches
 PREWARM_STEPS = 1000    # untimed, BEFORE the W warm-up steps: clocks, first touch of every buffer, RCCL channels, and the sampler's
                         # own burn-in (10 adaptation blocks: the timed steps run with the adapted proposal, as a real run's do)
+SUSTAINED_STEPS = 5000  # the `sustained` leg: timed like the K steps (barrier + synchronize on both sides), long enough for clocks to show
 PROFILE_TAG = "r04"     # profiles/<tag>_summary.json: rocprofv3 PMC passes of this command (tools/profile_round.sh)
 MARG_K = MARG_Q = 4     # marginalised leg: sub-steps per EEP interval x mass ratios
 
@@ -169,6 +175,17 @@ def launch_ranks(args) -> int:
         for sig, h in old_handlers.items():
             signal.signal(sig, h)
     return first_fail
+
+
+def check_group(world: int, rccl_ranks: int, devices) -> None:
+    """A multi-rank line must come from `world` ranks on `world` DISTINCT GPUs: exits non-zero (3) otherwise.  The verdict
+    is the C++ library's (b9h::group_error), the same one the RCCL exchange applies to itself at start-up."""
+    import ctypes as C
+    from base_amd import hostlib
+    msg = C.create_string_buffer(512)
+    if hostlib.load().b9h_group_check(int(world), int(rccl_ranks), ",".join(devices).encode(), msg, len(msg)) != 0:
+        sys.stderr.write("bench.py: " + msg.value.decode() + "\n")
+        raise SystemExit(3)
 
 
 # ---- algorithmic fp64 work per star-eval (DESIGN.md section 3, "Algorithmic operations") ---------------------------------
@@ -439,6 +456,7 @@ def main():
     ap.add_argument("--no-marginalised", action="store_true", help="diagnostic: skip the marginalised-mode leg")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the HIP-event bracketing of k_mcmc_step")
     ap.add_argument("--no-prewarm", action="store_true", help="diagnostic: skip the untimed pre-warm block")
+    ap.add_argument("--no-sustained", action="store_true", help="diagnostic: skip the 5000-step sustained leg")
     args = ap.parse_args()
 
     is_rank = "RANK" in os.environ or "B9_RANK" in os.environ
@@ -489,7 +507,25 @@ def main():
     eng.enable_timing(0)
     bracket_ms = eng.calibrate_timing()     # event bracket around an empty kernel, same stream
     dt = exchange.max(dt_local)             # max over ranks (RCCL all-reduce)
-    st = sampler.state()
+    st = sampler.state()                    # (the state the parity check below reads: right after the K timed steps)
+    if world > 1:
+        check_group(world, exchange.comm_ranks, exchange.devices)
+    # ---- sustained leg: the same loop over >= 5000 steps, timed the same way, with the shader clock stamped on the stream at
+    # both ends (in-kernel s_memtime against the 100 MHz s_memrealtime: what the chip ran at, not what sysfs says)
+    sustained = None
+    if not args.no_sustained:
+        barrier()
+        t0 = time.perf_counter()
+        eng.clock_stamp(0)
+        sampler.run(SUSTAINED_STEPS)
+        eng.clock_stamp(1)
+        barrier()
+        dts = exchange.max(time.perf_counter() - t0)
+        sustained = {"steps": SUSTAINED_STEPS, "ms_per_step": 1e3 * dts / SUSTAINED_STEPS, "mcmc_steps_per_s": SUSTAINED_STEPS / dts,
+                     "value": float(N_STARS) * WALKERS_PER_GPU * world * SUSTAINED_STEPS / dts, "unit": "star-likelihood evals/s",
+                     "seconds": dts, "clock": eng.clock_mhz(),
+                     "note": "same sampler, same blocks, directly after the K timed steps; timed between barrier + device synchronize "
+                             "on both sides, max over ranks; the two clock stamps are inside the timed stretch"}
 
     if rank == 0:
         source_hash = build.source_hash()
@@ -515,6 +551,10 @@ def main():
                              "committed rocprofv3 PMC passes of this command (counters.source / .commit; null when the kernel sources "
                              "differ from the profiled ones); useful_frac = algorithmic fp64 lane-operations (DESIGN.md section 3) "
                              "x star-evals / launch time / (1024 SIMDs x 16 lanes x 2.4 GHz) -- needs no counter"})
+        if sustained and sustained["clock"]["mhz"] > 0:
+            scale = CLOCK_GHZ * 1e3 / sustained["clock"]["mhz"]
+            roof["frac_at_observed_clock"] = roof["frac"] * scale if roof.get("frac") is not None else None
+            roof["useful_frac_at_observed_clock"] = roof["useful_frac"] * scale if roof.get("useful_frac") is not None else None
         out = {
             "metric": "star-likelihood evals/sec", "value": evals / dt, "unit": "star-likelihood evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -542,6 +582,10 @@ def main():
             "timed_region_breakdown": {"kernel_ms": kernel_ms, "host_and_block_fixed_ms": (1e3 * dt - kernel_ms) if kernel_ms else None,
                                        "wall_ms": 1e3 * dt, "ms_per_step_over_launch_period": (1e3 * dt / args.steps) / (1e3 * k_avg_s) if k_n else None},
             "accept_rate": (st["accepted_local"] - acc0) / float(WALKERS_PER_GPU * args.steps),
+            "sustained": sustained,
+            "clock_mhz_observed": sustained["clock"]["mhz"] if sustained else None,
+            "clock_note": "shader clock over the sustained leg (median over XCDs of delta s_memtime / delta s_memrealtime x 100 MHz); the "
+                          "roofline peaks are quoted at the 2.4 GHz maximum -- roofline.frac_at_observed_clock rescales them",
             "parity": "vs this repo's CPU oracle (BASE-9 parity unpinned: reference source not mounted)",
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define B9_ABI_VERSION 4
+#define B9_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------------------ */
 typedef enum b9_status {
@@ -343,6 +343,13 @@ int b9_kernel_time_ms(b9_ctx *ctx, int reset, double *total_ms, int32_t *n_launc
 /* Mean elapsed ms of the same event bracket around an EMPTY kernel: what the bracket adds to a
  * kernel's own duration (one dispatch boundary + event processing).  Reported, never applied. */
 int b9_calibrate_timing(b9_ctx *ctx, double *bracket_overhead_ms);
+/* Shader clock observed over a stretch of the context's stream (ABI 5).  b9_clock_stamp(ctx, 0) / (ctx, 1) enqueue a small
+ * kernel that records, per XCD, the shader-cycle counter (s_memtime) and the 100 MHz reference counter (s_memrealtime);
+ * b9_clock_mhz waits for the stream and returns delta(shader cycles) / delta(reference) x 100 MHz between the two stamps:
+ * the median over the XCDs both stamps reached (and, when the pointers are not NULL, the extremes and the length of the
+ * stretch in seconds of the reference clock).  What a roofline's clock-dependent peak should be read against. */
+int b9_clock_stamp(b9_ctx *ctx, int32_t which);
+int b9_clock_mhz(b9_ctx *ctx, double *mhz, double *mhz_min, double *mhz_max, double *ref_seconds);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,10 @@ int b9h_exchange_comm_ranks(void *exchange);
 /* ... and the PCI bus ids of the ranks' GPUs in rank order, comma-separated, all-gathered through the communicator
  * ("" without one).  Returns 0, or -1 when `cap` is too small. */
 int b9h_exchange_devices(void *exchange, char *out, int cap);
+/* 0 when a communicator of `comm_ranks` ranks on the GPUs `devices_csv` (as b9h_exchange_devices returns them) is what a launch
+ * of `world` ranks must have -- that many ranks on that many DISTINCT devices -- else 1 with the reason in msg[cap].  The RCCL
+ * exchange refuses such a group itself (b9h_exchange_rccl fails); launchers check their own report with it. */
+int b9h_group_check(int world, int comm_ranks, const char *devices_csv, char *msg, int cap);
 /* 1 when this process is a rank of a --forceRanks / --force-ranks launch (B9_FORCE_RANKS): one GPU, full multi-rank route */
 int b9h_forced_ranks(void);
 /* Test hook of the launchers' deadlines: parks the calling rank for ever when B9_TEST_STALL == "<where>:<rank>". */

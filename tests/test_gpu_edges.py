@@ -343,3 +343,26 @@ def test_heavy_role_staging_variants(case):
     assert dev[4] == host[4]
     np.testing.assert_allclose(dev[2], host[2], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(dev[3], host[3], rtol=1e-10)
+
+
+def test_shader_clock_between_two_stamps():
+    """b9_clock_stamp / b9_clock_mhz (ABI 5): the shader clock observed in-kernel over a stretch of the context's stream --
+    delta(s_memtime) / delta(s_memrealtime) x 100 MHz, median over the XCDs -- is a plausible MI355X clock; asking before
+    any stamp is a state error."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=20000, small=False)
+    eng = engine.Engine(pack, stars, priors, options)
+    with pytest.raises(engine.B9Error) as e:
+        eng.clock_mhz()
+    assert e.value.code == abi.B9_ERR_STATE
+    params = synth.walker_params(cl["truth"], 8)
+    eng.logpost(params)
+    eng.clock_stamp(0)
+    for _ in range(200):
+        eng.logpost(params)
+    eng.clock_stamp(1)
+    c = eng.clock_mhz()
+    assert 300.0 < c["mhz_min_xcd"] <= c["mhz"] <= c["mhz_max_xcd"] < 2600.0, c
+    assert c["ref_seconds"] > 1e-3
+    with pytest.raises(engine.B9Error):
+        eng.clock_stamp(2)

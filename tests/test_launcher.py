@@ -109,6 +109,26 @@ def test_rccl_bootstrap_refuses_a_launch_without_an_id(tmp_path):
     assert r.returncode == 0 and "REFUSED" in r.stdout and "B9_LAUNCH_NONCE" in r.stdout, (r.returncode, r.stdout, r.stderr[-1500:])
 
 
+def test_a_multi_rank_line_needs_distinct_gpus():
+    """two ranks that report the same PCI bus id (or a communicator with another rank count) make
+    bench.py exit non-zero instead of printing a line that looks like a 2-GPU result; the C++ exchange applies the same
+    check to itself (b9h::group_error)."""
+    import ctypes as C
+    from base_amd import hostlib
+    lib = hostlib.load()
+    msg = C.create_string_buffer(512)
+    assert lib.b9h_group_check(2, 2, b"0000:05:00.0,0000:15:00.0", msg, 512) == 0 and msg.value == b""
+    assert lib.b9h_group_check(2, 2, b"0000:05:00.0,0000:05:00.0", msg, 512) == 1 and b"share the GPU 0000:05:00.0" in msg.value
+    assert lib.b9h_group_check(2, 1, b"0000:05:00.0,0000:15:00.0", msg, 512) == 1 and b"1 rank(s)" in msg.value
+    assert lib.b9h_group_check(4, 4, b"a,b,c", msg, 512) == 1
+    assert lib.b9h_group_check(1, 0, b"", msg, 512) == 0                      # one rank: nothing to check
+    code = "import sys; sys.path.insert(0, %r); import bench; bench.check_group(2, 2, ['0000:05:00.0', '0000:05:00.0'])" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "share the GPU" in r.stderr, (r.returncode, r.stderr[-1000:])
+    code = "import sys; sys.path.insert(0, %r); import bench; bench.check_group(2, 2, ['0000:05:00.0', '0000:15:00.0'])" % ROOT
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).returncode == 0
+
+
 def test_a_profile_of_other_sources_drops_the_counters(tmp_path, monkeypatch):
     """bench.py divides the profile's per-launch counters by the LIVE launch time: when the kernel sources have changed
     since the profile was taken, the counters are dropped (with the reason) instead of silently mixing two builds."""

@@ -8,6 +8,6 @@ name, flags = sys.argv[1], sys.argv[2:]
 out_dir = os.path.join(b.ROOT, "build", "variants")
 os.makedirs(out_dir, exist_ok=True)
 out = os.path.join(out_dir, f"lib_{name}.so")
-srcs = [os.path.join(b.CSRC, f) for f in ("b9_kernels.hip", "b9_capi.cpp")]
+srcs = [os.path.join(b.CSRC, f) for f in b.HIP_SOURCES]
 subprocess.run([b.HIPCC] + b.HIP_FLAGS + flags + ["-shared", "-o", out, "-x", "hip"] + srcs, check=True)
 print(out)
