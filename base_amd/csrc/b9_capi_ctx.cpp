@@ -323,11 +323,11 @@ int b9_clock_stamp(b9_ctx *ctx, int32_t which)
 {
     if (!ctx || (which != 0 && which != 1)) return B9_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!ctx->d_clock) {
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_clock, sizeof(unsigned long long) * 32));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_clock, 0, sizeof(unsigned long long) * 32, ctx->stream));
-    }
-    HIPCHK(ctx, b9k_clock_stamp(ctx->d_clock + 16 * which, ctx->stream));
+    const size_t per = (size_t)B9_CLOCK_SLOTS * 2;
+    if (!ctx->d_clock) HIPCHK(ctx, hipMalloc((void **)&ctx->d_clock, sizeof(unsigned long long) * per * 2));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_clock + per * which, 0, sizeof(unsigned long long) * per, ctx->stream));
+    if (which == 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_clock + per, 0, sizeof(unsigned long long) * per, ctx->stream));
+    HIPCHK(ctx, b9k_clock_stamp(ctx->d_clock + per * which, ctx->stream));
     return B9_OK;
 }
 
@@ -337,17 +337,18 @@ int b9_clock_mhz(b9_ctx *ctx, double *mhz, double *mhz_min, double *mhz_max, dou
     if (!ctx->d_clock) return fail(ctx, B9_ERR_STATE, "b9_clock_mhz: no stamps (call b9_clock_stamp(ctx, 0) and (ctx, 1) first)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h[32];
-    HIPCHK(ctx, hipMemcpy(h, ctx->d_clock, sizeof h, hipMemcpyDeviceToHost));
+    const size_t per = (size_t)B9_CLOCK_SLOTS * 2;
+    std::vector<unsigned long long> h(per * 2);
+    HIPCHK(ctx, hipMemcpy(h.data(), ctx->d_clock, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
     std::vector<double> v;
     double ref = 0.0;
-    for (int x = 0; x < 8; ++x) {
-        const unsigned long long t0 = h[2 * x], r0 = h[2 * x + 1], t1 = h[16 + 2 * x], r1 = h[16 + 2 * x + 1];
-        if (!t0 || !t1 || r1 <= r0 || t1 <= t0) continue;           // no workgroup of one of the two launches landed on this XCD
+    for (int x = 0; x < B9_CLOCK_SLOTS; ++x) {
+        const unsigned long long t0 = h[2 * x], r0 = h[2 * x + 1], t1 = h[per + 2 * x], r1 = h[per + 2 * x + 1];
+        if (!t0 || !t1 || r1 <= r0 || t1 <= t0) continue;           // no workgroup of one of the two launches landed on this CU
         v.push_back((double)(t1 - t0) / (double)(r1 - r0) * 100.0);  // s_memrealtime ticks at 100 MHz
         ref = std::max(ref, (double)(r1 - r0) * 1e-8);
     }
-    if (v.empty()) return fail(ctx, B9_ERR_STATE, "b9_clock_mhz: the two stamps share no XCD");
+    if (v.empty()) return fail(ctx, B9_ERR_STATE, "b9_clock_mhz: the two stamps share no compute unit");
     std::sort(v.begin(), v.end());
     *mhz = v.size() % 2 ? v[v.size() / 2] : 0.5 * (v[v.size() / 2 - 1] + v[v.size() / 2]);
     if (mhz_min) *mhz_min = v.front();

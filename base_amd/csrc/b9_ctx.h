@@ -107,7 +107,7 @@ struct b9_ctx {
     int timing_group = 8;            // fused step: a bracket spans this many consecutive launches (B9_TIMING_GROUP)
     double ms_accum = 0.0;
     int launches = 0;
-    unsigned long long *d_clock = nullptr;   // b9_clock_stamp: [2 stamps][8 XCDs]{s_memtime, s_memrealtime}
+    unsigned long long *d_clock = nullptr;   // b9_clock_stamp: [2 stamps][B9_CLOCK_SLOTS]{s_memtime, s_memrealtime}
 };
 
 namespace b9i {

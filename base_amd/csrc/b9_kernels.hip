@@ -423,21 +423,25 @@ hipError_t b9k_noop(hipStream_t stream)
     return hipGetLastError();
 }
 
-// (shader clock, 100 MHz reference clock) of every XCD, stamped by whichever of the launch's workgroups landed there: two
-// such stamps bracket a stretch of stream work, and delta(s_memtime) / delta(s_memrealtime) x 100 MHz is the clock the
-// shader engines actually ran at over it (MI355X_MICROARCH.md: the in-kernel clock, not pp_dpm_sclk).  out[xcd] = {t, tr}.
+// (shader-cycle counter, 100 MHz reference counter) stamped per COMPUTE UNIT by whichever of the launch's workgroups landed
+// there: two such stamps bracket a stretch of stream work, and delta(s_memtime) / delta(s_memrealtime) x 100 MHz of one CU
+// is the clock its shader engine actually ran at over it (MI355X_MICROARCH.md: the in-kernel clock, not pp_dpm_sclk).
+// The cycle counters of different CUs are offset against each other by arbitrary amounts (measured: tens of millions of
+// cycles), so a difference is only ever formed between two stamps of the SAME CU.  out[cu slot] = {t, tr}.
 __global__ void k_clock_stamp(unsigned long long *out)
 {
     if (threadIdx.x != 0) return;
-    unsigned xcc;
+    unsigned xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     unsigned long long t, tr;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(tr) :: "memory");
-    out[2 * (xcc & 7u)] = t;
-    out[2 * (xcc & 7u) + 1] = tr;
+    const unsigned slot = ((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu);      // HW_ID[15:8] = shader engine, shader array, CU
+    out[2 * slot] = t;
+    out[2 * slot + 1] = tr;
 }
 hipError_t b9k_clock_stamp(unsigned long long *d_out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_clock_stamp, dim3(64), dim3(64), 0, stream, d_out);
+    hipLaunchKernelGGL(k_clock_stamp, dim3(2048), dim3(64), 0, stream, d_out);
     return hipGetLastError();
 }

@@ -77,4 +77,5 @@ hipError_t b9k_chain_rows(const StepDev &sd, const double *cur_fin, const double
 
 hipError_t b9k_noop(hipStream_t stream);
 hipError_t b9k_spin(double microseconds, hipStream_t stream);
-hipError_t b9k_clock_stamp(unsigned long long *d_out /* [8 XCDs][2] */, hipStream_t stream);
+constexpr int B9_CLOCK_SLOTS = 8 * 256;      // (XCD, HW_ID[15:8]) -> one slot per compute unit
+hipError_t b9k_clock_stamp(unsigned long long *d_out /* [B9_CLOCK_SLOTS][2] */, hipStream_t stream);

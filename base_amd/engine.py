@@ -219,10 +219,10 @@ class Engine:
         self._check(self.lib.b9_clock_stamp(self._ctx, int(which)))
 
     def clock_mhz(self) -> Dict:
-        """Shader clock between the two stamps: median over the XCDs, extremes, length of the stretch (reference clock)."""
+        """Shader clock between the two stamps: median over the compute units, extremes, length of the stretch (reference clock)."""
         m, lo, hi, sec = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
         self._check(self.lib.b9_clock_mhz(self._ctx, C.byref(m), C.byref(lo), C.byref(hi), C.byref(sec)))
-        return {"mhz": m.value, "mhz_min_xcd": lo.value, "mhz_max_xcd": hi.value, "ref_seconds": sec.value}
+        return {"mhz": m.value, "mhz_min_cu": lo.value, "mhz_max_cu": hi.value, "ref_seconds": sec.value}
 
     def kernel_time_ms(self, reset: bool = True) -> Tuple[float, int]:
         ms, n = C.c_double(0), C.c_int32(0)

@@ -584,7 +584,7 @@ def main():
             "accept_rate": (st["accepted_local"] - acc0) / float(WALKERS_PER_GPU * args.steps),
             "sustained": sustained,
             "clock_mhz_observed": sustained["clock"]["mhz"] if sustained else None,
-            "clock_note": "shader clock over the sustained leg (median over XCDs of delta s_memtime / delta s_memrealtime x 100 MHz); the "
+            "clock_note": "shader clock over the sustained leg (median over compute units of delta s_memtime / delta s_memrealtime x 100 MHz); the "
                           "roofline peaks are quoted at the 2.4 GHz maximum -- roofline.frac_at_observed_clock rescales them",
             "parity": "vs this repo's CPU oracle (BASE-9 parity unpinned: reference source not mounted)",
         }

@@ -344,10 +344,11 @@ int b9_kernel_time_ms(b9_ctx *ctx, int reset, double *total_ms, int32_t *n_launc
  * kernel's own duration (one dispatch boundary + event processing).  Reported, never applied. */
 int b9_calibrate_timing(b9_ctx *ctx, double *bracket_overhead_ms);
 /* Shader clock observed over a stretch of the context's stream (ABI 5).  b9_clock_stamp(ctx, 0) / (ctx, 1) enqueue a small
- * kernel that records, per XCD, the shader-cycle counter (s_memtime) and the 100 MHz reference counter (s_memrealtime);
- * b9_clock_mhz waits for the stream and returns delta(shader cycles) / delta(reference) x 100 MHz between the two stamps:
- * the median over the XCDs both stamps reached (and, when the pointers are not NULL, the extremes and the length of the
- * stretch in seconds of the reference clock).  What a roofline's clock-dependent peak should be read against. */
+ * kernel that records, per compute unit, the shader-cycle counter (s_memtime) and the 100 MHz reference counter
+ * (s_memrealtime); b9_clock_mhz waits for the stream and returns delta(shader cycles) / delta(reference) x 100 MHz between
+ * the two stamps: the median over the compute units both stamps reached (differences are formed per CU: the cycle counters
+ * of different CUs are offset against each other) and, when the pointers are not NULL, the extremes and the length of the
+ * stretch in seconds of the reference clock.  What a roofline's clock-dependent peak should be read against. */
 int b9_clock_stamp(b9_ctx *ctx, int32_t which);
 int b9_clock_mhz(b9_ctx *ctx, double *mhz, double *mhz_min, double *mhz_max, double *ref_seconds);
 
