@@ -74,10 +74,11 @@ int check_ready(b9_ctx *ctx)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->stars_dirty) { int rc = build_stars(ctx); if (rc) return rc; }
     {   // Workgroups per walker for the stars above the AGB tip (WD branch / NS-BH).  Their number depends on the walker's
-        // age; the catalogue's WD-stage stars plus 2 % of the rest is the estimate.  A star takes 2 n_pops lanes
-        // (star_value_lanes) and the role is a latency chain, so there is one 256-lane workgroup per 256 lanes of them:
-        // a lane evaluates one descriptor, rarely two.
-        const int est = (ctx->n_wd_stage + ctx->hs.n / 50) * 2 * ctx->opt.n_pops;
+        // age; the catalogue's WD-stage stars plus 2 % of the rest is the estimate (1 % with two populations: what lies
+        // between the two populations' tips is a thinner slice, and the launch has fewer slots to spare -- 30k stars x 2
+        // populations x 8 walkers: 5 parts 20.6 us per step, 10 parts 22.0).  A star takes a lane pair of its population's
+        // two (one population: four) waves and the role is a latency chain, so there is one workgroup per 64 n_pops stars.
+        const int est = (ctx->n_wd_stage + ctx->hs.n / (50 * ctx->opt.n_pops)) * 2 * ctx->opt.n_pops;
         ctx->heavy_parts = std::max(4, std::min(16, (est + 255) / 256));
         if (ctx->heavy_parts_fixed > 0) ctx->heavy_parts = std::max(1, std::min(64, ctx->heavy_parts_fixed));
     }

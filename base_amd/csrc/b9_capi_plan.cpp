@@ -33,7 +33,8 @@ Groups make_groups(b9_ctx *ctx, int n_pops)
     if (g <= 0) {
         const int slots = step_slots(ctx, n_pops);
         g = 1;
-        while (g < 8 && (long long)((n_tiles + g - 1) / g) * kReferenceWalkers > (long long)(0.7 * slots)) ++g;
+        // (two populations: a hot workgroup covers half of every tile of its groups, once per population -- n_pops per block)
+        while (g < 8 && (long long)((n_tiles + g - 1) / g) * n_pops * kReferenceWalkers > (long long)(0.7 * slots)) ++g;
     }
     g = std::max(1, std::min(g, std::max(1, n_tiles)));
     return Groups{g, (n_tiles + g - 1) / g};
@@ -70,11 +71,11 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     const int full_parts = (ctx->mass_cap * (ctx->pk.nfp + 1) + 255) / 256;
     const int m_max = std::max(1, 8 / gr.group_tiles);
     int m = 1;
-    while (m < m_max && (long long)((gr.n_groups + m - 1) / m) * n_walkers > (long long)(0.7 * slots)) ++m;
+    while (m < m_max && (long long)((gr.n_groups + m - 1) / m) * n_pops * n_walkers > (long long)(0.7 * slots)) ++m;
     sp.plan = with_groups_per_block(gr, m);
     int parts = ctx->derive_parts;
     if (parts <= 0) {
-        const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_blocks * n_walkers - (long long)n_walkers * ctx->heavy_parts;
+        const long long room = (long long)(0.9 * slots) - (long long)sp.plan.n_blocks * n_pops * n_walkers - (long long)n_walkers * ctx->heavy_parts;
         parts = (int)std::max<long long>(2, room / ((long long)n_walkers * 2 * n_pops));
         // ... but no more than ~3/8 of the CUs' worth of derivation workgroups in all: beyond that they only crowd the hot
         // ones (two populations x 8 walkers: 3 parts = 96 workgroups 21.0 us/step, 4 parts 21.8, 2 parts 23.4; one
@@ -86,7 +87,7 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     if (ctx->plan_debug && ctx->plan_debug_key != key * 64 + n_walkers) {
         ctx->plan_debug_key = key * 64 + n_walkers;
         std::fprintf(stderr, "b9 step plan: %d CUs x %d workgroups = %d slots; %d canonical groups of %d tiles; %d walkers x %d hot workgroups (%d groups each) + %d heavy + %d derivation workgroups (%d parts)\n",
-                     ctx->n_cu, ctx->step_blocks_per_cu, slots, gr.n_groups, gr.group_tiles, n_walkers, sp.plan.n_blocks, sp.plan.groups_per_block,
+                     ctx->n_cu, ctx->step_blocks_per_cu, slots, gr.n_groups, gr.group_tiles, n_walkers, sp.plan.n_blocks * n_pops, sp.plan.groups_per_block,
                      n_walkers * ctx->heavy_parts, n_walkers * 2 * n_pops * sp.derive_parts, sp.derive_parts);
     }
     return sp;
@@ -158,7 +159,7 @@ TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
         // one canonical group per hot workgroup; the walk reads a node's partials in one round trip, which bounds their number
         // (the grouping fixes the summation order and is never changed for the tree's sake: no tree then)
         const int tpb = gr.group_tiles, n_groups = gr.n_groups;
-        const long long fixed = n_walkers * (1 + NN * ctx->heavy_parts + NN * 8 * ((n_groups + 7) / 8));
+        const long long fixed = n_walkers * (1 + NN * ctx->heavy_parts + NN * 8 * ((n_groups * n_pops + 7) / 8));
         const long long per_part = (long long)n_walkers * NO * NN * n_pops;
         const long long room = (long long)(0.95 * slots) - fixed;
         // (the derivation is the launch's longest chain -- decision, parameters, three dependent table round trips -- and more
@@ -175,7 +176,7 @@ TreePlan make_tree_plan(b9_ctx *ctx, int n_walkers, int n_pops)
             // 2 walkers x 50k d = 2 (8.4 vs 12.1), 1 x 10k d = 3 (4.4 vs 8.7).
             const B9Groups p1 = make_step_plan(ctx, n_walkers, n_pops).plan;
             const int tpb1 = p1.group_tiles * p1.groups_per_block;
-            const double per_cu = 2.2 * (double)n_walkers * n_tiles / std::max(1, ctx->n_cu);
+            const double per_cu = 2.2 * (double)n_walkers * n_tiles * n_pops / std::max(1, ctx->n_cu);
             const double est_tree = (9.0 + std::max(1.6 * tpb, per_cu * (double)NN)) / d;
             const double est_step = 9.0 + std::max(1.6 * tpb1, per_cu);
             if (est_tree >= est_step) continue;

@@ -313,3 +313,10 @@ __device__ __forceinline__ void draw_z(const McmcDev &mc, int w, unsigned long l
     }
 }
 
+// A double that is the same in every lane of the wave, said so: it then lives in a scalar register pair.
+__device__ __forceinline__ double wave_uniform(double x)
+{
+    const unsigned long long b = __double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}

@@ -138,7 +138,7 @@ static hipError_t launch_star_like(const DevPack &pk, const DevStars &st, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int hot = 8 * ((gr.n_blocks + 7) / 8) * n_walkers;     // padded so every XCD sees whole walker sets
+    const int hot = 8 * ((gr.n_blocks * NPOPS + 7) / 8) * n_walkers;     // padded so every XCD sees whole walker sets (two populations: a workgroup per half tile)
     const int heavy = (n_walkers * heavy_parts + 7) / 8 * 8;     // heavy-star workgroups lead the grid
     hipLaunchKernelGGL(kern, dim3(heavy + hot), dim3(256), lds, stream, pk, st, hdr, iso_data,
                        iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, gr.n_groups, gr.group_tiles,
@@ -277,7 +277,7 @@ static hipError_t launch_mcmc_step(const DevPack &pk, const DevStars &st, const 
         if (e != hipSuccess) return e;
     }
     const int W = sd.n_walkers;
-    const int hot = 8 * ((gr.n_blocks + 7) / 8) * W;
+    const int hot = 8 * ((gr.n_blocks * NPOPS + 7) / 8) * W;
     const int derive_first = derive_order >= 0 ? (derive_order == 1 ? 2 : 1) : 0;
     const int n_derive = W * 2 * NPOPS * derive_parts;
     const int front = (W * heavy_parts + W + (derive_first ? n_derive : 0) + 7) / 8 * 8;     // heavy, writers, (derivation), pad
@@ -345,7 +345,7 @@ static hipError_t launch_mcmc_tree(const DevPack &pk, const DevStars &st, const 
     const int n_derive = td.derive_mode == 0 ? 0 : W * NO * NN * NPOPS * derive_parts;
     const int heavy = td.levels > 0 ? W * NN * td.heavy_parts : 0;
     const int front = (writers + n_derive + heavy + 7) / 8 * 8;
-    const int hot = td.levels > 0 ? 8 * ((td.n_groups + 7) / 8) * W * NN : 0;
+    const int hot = td.levels > 0 ? 8 * ((td.n_groups * NPOPS + 7) / 8) * W * NN : 0;
     hipLaunchKernelGGL(kern, dim3(front + hot), dim3(256), lds, stream, pk, st, td, pr, group_tiles, front, derive_parts);
     return hipGetLastError();
 }

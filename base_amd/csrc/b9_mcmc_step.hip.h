@@ -94,12 +94,12 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     const int tid = threadIdx.x, W = sd.n_walkers, mass_cap = sd.mass_cap;
     const int xcd = L & 7, s = L >> 3;
     const int w = s % W;
-    const int g = (s / W) * 8 + xcd;                     // this workgroup among the walker's n_blocks
-    if (g >= n_blocks) return;
+    const int g = (s / W) * 8 + xcd;                     // this workgroup among the walker's n_blocks * NPOPS
+    if (g >= n_blocks * NPOPS) return;
     // its canonical tile groups g, g + n_blocks, ... (TileSeq, b9_star_like.hip.h): group_tiles tiles each, strided over the
     // slot order -- binaries lead that order, so consecutive tiles would give some workgroups only expensive (binary)
     // tiles and others only cheap ones; strided, every workgroup gets its share of both and they finish together
-    const TileSeq seq{g, n_blocks, n_groups, group_tiles, groups_per_block, st.n_pad / 256};
+    const TileSeq seq = make_tile_seq<NPOPS>(g, n_blocks, n_groups, group_tiles, groups_per_block, st.n_pad / 256);
     STAMP(0);
     // The decision is taken by the workgroup's first wave alone and travels through LDS behind the barrier the mass
     // columns need anyway: a quarter of the partial-sum traffic at the launch's start.  Its loads leave first.
@@ -107,8 +107,8 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     DecideLoads dl = {};
     if (first_wave) decide_issue<B9_SHORTCUT>(sd, w, dl);
-    int i = seq.tile(seq.group(0), 0) * 256 + tid;       // (a group's first tile always exists)
-    double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
+    const int i = seq.slot(seq.tile(seq.group(0), 0));       // (a group's first tile always exists)
+    const double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
     const size_t rows = (size_t)W * NPOPS;
     const size_t cb0 = (size_t)(sd.set * 2) * rows + (size_t)w * NPOPS;      // candidate 0; candidate 1 is `rows` further
     double *const lds_mass = smem;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
     }
     STAMP(2);
     __syncthreads();                                     // the LDS mass columns, the decision
-    const int sel = s_sel;
+    const int sel = __builtin_amdgcn_readfirstlane(s_sel);       // (wave-uniform: the selected candidate's view lives in scalar registers)
     STAMP(3);
     IsoView<NFP> iso[NPOPS];
     bool valid = true;
@@ -164,35 +164,11 @@ __device__ __forceinline__ void step_hot(const DevPack &pk, const DevStars &st, 
         tip_min = hh.agb_tip < tip_min ? hh.agb_tip : tip_min;
     }
     const double mod = sel ? pmod[1] : pmod[0], av = sel ? pav[1] : pav[0], lam = sel ? plam[1] : plam[0];
-    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+    const double log_lam = NPOPS == 2 ? wave_uniform(log(lam)) : 0.0, log_1ml = NPOPS == 2 ? wave_uniform(log1p(-lam)) : 0.0;
 
-    for (int j = 0; j < groups_per_block; ++j) {
-        const int c = seq.group(j);
-        if (c < 0) break;
-        if (j > 0) {                                         // (a further group of this workgroup: its first tile's star scalars)
-            i = seq.tile(c, 0) * 256 + tid;
-            m1 = st.mass1[i]; q = st.q[i]; ea = st.ea[i];
-        }
-        MixAcc acc;
-        acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;         // = 1.0
-        for (int t = 0; t < group_tiles; ++t) {
-            if (seq.tile(c, t) < 0) break;
-            // the NEXT tile's star scalars are requested before this tile's arithmetic: one memory round
-            // trip less on every tile after the first, for 6 VGPRs
-            const int tile_n = seq.tile(c, t + 1);
-            const int i_n = (tile_n >= 0 ? tile_n : seq.tile(c, t)) * 256 + tid;
-            const double m1_n = st.mass1[i_n], q_n = st.q[i_n], ea_n = st.ea[i_n];
-            if (valid && !(m1 > tip_min)) {                  // empty slots hold m1 = +inf
-                const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, i, log_lam, log_1ml);
-                mix_add(acc, ea, l);
-            }
-            i = i_n; m1 = m1_n; q = q_n; ea = ea_n;
-        }
-        STAMP(7);
-        const double tot = mix_wave_total(acc);
-        if ((tid & 63) == 0)
-            sd.partial[(size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2) + c * 4 + (tid >> 6)] = valid ? tot : 0.0;
-    }
+    double *const prow = sd.partial + (size_t)w * sd.partial_stride + (size_t)sd.set * (sd.partial_stride / 2);
+    hot_groups<NFP, NPOPS, true>(pk, st, seq, iso, valid, tip_min, mod, av, log_lam, log_1ml, i, m1, q, ea, nullptr,
+                           [&](int c, int k, double tot) { prow[c * 4 + k] = tot; });
     STAMP(8);
 }
 

@@ -152,16 +152,16 @@ __device__ __forceinline__ void tree_hot(const DevPack &pk, const DevStars &st, 
 {
     const int tid = threadIdx.x, W = td.n_walkers, mass_cap = td.mass_cap, NN = (1 << td.depth) - 1, V = W * NN;
     const int xcd = L & 7, s = L >> 3;
-    const int v = s % V, group = (s / V) * 8 + xcd;          // every node of every walker re-reads a star tile from one XCD's L2
-    if (group >= td.n_groups) return;
+    const int v = s % V, gb = (s / V) * 8 + xcd;             // every node of every walker re-reads a star tile from one XCD's L2
+    if (gb >= td.n_groups * NPOPS) return;
     const int w = v / NN, n = v - w * NN;
     if (tree_level(n) > td.levels) return;                   // (a block's last launch may evaluate fewer levels)
     // one canonical tile group per workgroup (TileSeq, b9_star_like.hip.h): tiles group, group + n_groups, ...
-    const TileSeq seq{group, td.n_groups, td.n_groups, group_tiles, 1, st.n_pad / 256};
+    const TileSeq seq = make_tile_seq<NPOPS>(gb, td.n_groups, td.n_groups, group_tiles, 1, st.n_pad / 256);
     __shared__ int s_o;
     const bool first_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
-    int i = group * 256 + tid;
-    double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
+    const int i = seq.slot(seq.g);                           // (the group's first tile is tile number `group`)
+    const double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
     if (first_wave) {
         const int o = tree_decide(td, w).outcome;
         if (tid == 0) s_o = o;
@@ -192,24 +192,11 @@ __device__ __forceinline__ void tree_hot(const DevPack &pk, const DevStars &st, 
     }
     const double *par = td.cand_par + cb * B9_NPARAM;
     const double mod = par[B9_P_MOD], av = par[B9_P_ABS], lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
-    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+    const double log_lam = NPOPS == 2 ? wave_uniform(log(lam)) : 0.0, log_1ml = NPOPS == 2 ? wave_uniform(log1p(-lam)) : 0.0;
     __syncthreads();                                         // the LDS mass columns
-    MixAcc acc;
-    acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;             // = 1.0
-    for (int t = 0; t < group_tiles; ++t) {
-        if (seq.tile(group, t) < 0) break;
-        const int tile_n = seq.tile(group, t + 1);
-        const int i_n = (tile_n >= 0 ? tile_n : seq.tile(group, t)) * 256 + tid;
-        const double m1_n = st.mass1[i_n], q_n = st.q[i_n], ea_n = st.ea[i_n];     // the next tile's star scalars: one round trip less per tile
-        if (valid && !(m1 > tip_min)) {                      // empty slots hold m1 = +inf
-            const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, i, log_lam, log_1ml);
-            mix_add(acc, ea, l);
-        }
-        i = i_n; m1 = m1_n; q = q_n; ea = ea_n;
-    }
-    const double tot = mix_wave_total(acc);
-    if ((tid & 63) == 0)
-        td.partial[(((size_t)td.set * W + w) * NN + n) * td.part_stride + group * 4 + (tid >> 6)] = valid ? tot : 0.0;
+    double *const prow = td.partial + (((size_t)td.set * W + w) * NN + n) * td.part_stride;
+    hot_groups<NFP, NPOPS, true>(pk, st, seq, iso, valid, tip_min, mod, av, log_lam, log_1ml, i, m1, q, ea, nullptr,
+                           [&](int c, int k, double tot) { prow[c * 4 + k] = tot; });
 }
 
 // ---- heavy role: the stars above a node's AGB tip (k_star_like's heavy role on the selected candidate) -----------------

@@ -264,7 +264,19 @@ __device__ __forceinline__ void wd_cooling_tracks(const DevPack &pk, const WdAxe
             vr[k] = lerp(pk.wc_log_radius[b], pk.wc_log_radius[b + 1], ta);
         }
     } else {
-        bracket8_lockstep<NT>(axes, n, log_cool, ia);
+        if constexpr (NT == 4) {
+            // one track after the other: four columns' probes at once are 56 registers, the peak of the whole role (it
+            // spilled there); a pack with a carbonicity axis pays the extra LDS search rounds on its WD stars
+#pragma unroll 1
+            for (int k = 0; k < NT; ++k) {
+                const double *a = (k & 2) ? ((k & 1) ? axes[NT - 1] : axes[NT - 2]) : ((k & 1) ? axes[1] : axes[0]);
+                const int nk = (k & 2) ? ((k & 1) ? n[NT - 1] : n[NT - 2]) : ((k & 1) ? n[1] : n[0]);
+                const int r = bracket8<false>(a, nk, log_cool);
+                if (k == 0) ia[0] = r; else if (k == 1) ia[1] = r; else if (k == 2) ia[NT - 2] = r; else ia[NT - 1] = r;
+            }
+        } else {
+            bracket8_lockstep<NT>(axes, n, log_cool, ia);
+        }
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const double a0 = axes[k][ia[k]], a1 = axes[k][ia[k] + 1];
@@ -541,14 +553,14 @@ struct LaneView {
     WdAxes ax;                        // WD axes (LDS) with the (candidate, population)'s AGB-tip columns
 };
 
-// One star through the descriptors, spread over 2 NPOPS neighbouring lanes: lane `sub` of the star's group evaluates
-// component (sub & 1) in population (sub >> 1).  The heavy role is a latency chain (a WD descriptor is ~30 dependent LDS
-// search steps, three library transcendentals and two memory round trips); laid end to end in one lane a two-population
-// binary cost four of them (22-30 us measured), side by side they cost one.  The lanes meet by wave shuffles: the pair
-// of a population swaps component descriptors and then splits the FILTERS (each lane forms both components' magnitudes in
-// half of them), and the populations swap log-likelihoods.  Every magnitude is formed by star_value's operations; the
-// chi^2 is the sum of two half-sums instead of one chain over the filters (a 1e-16 relative difference).  All lanes of a
-// group must call (full EXEC); the result is valid in every lane of the group.
+// One star of ONE population through the descriptors, spread over a PAIR of neighbouring lanes: lane `comp` of the pair
+// evaluates component `comp`.  The heavy role is a latency chain (a WD descriptor is ~30 dependent LDS search steps, three
+// library transcendentals and two memory round trips); laid end to end in one lane a binary cost two of them, side by side
+// one.  The pair swaps component descriptors by wave shuffles and then splits the FILTERS (each lane forms both
+// components' magnitudes in half of them).  Every magnitude is formed by star_value's operations; the chi^2 is the sum of two
+// half-sums instead of one chain over the filters (a 1e-16 relative difference).  Both lanes of a pair must call (full
+// EXEC); the result -- the star's log-likelihood in this population, c0 included -- is valid in both.  Two populations are
+// two WAVES (heavy_stars), not more lanes: the lane view stays wave-uniform.
 // What the HEAD of a heavy star's chain needs (heavy-order arrays, DevStars::hv_*): nothing here depends on the
 // candidate, so the caller requests the first chunk's at the role's entry.  Everything else of the star -- the
 // observations and weights, its two constants -- is used at the chain's END and requested there, together with the
@@ -566,12 +578,11 @@ __device__ __forceinline__ HeavyStar load_heavy_star(const DevStars &st, int j /
     return h;
 }
 
-template <int NFP, int NPOPS>
-__device__ __forceinline__ double star_value_lanes(const DevPack &pk, const LaneView<NFP> &lv, const DevStars &st,
-                                                   int j /* index in the descending-mass list */, const HeavyStar &hs, int sub)
+template <int NFP>
+__device__ __forceinline__ double star_ll_lanes(const DevPack &pk, const LaneView<NFP> &lv, const DevStars &st,
+                                                int j /* index in the descending-mass list */, const HeavyStar &hs, int comp)
 {
-    const int comp = sub & 1;
-    constexpr int HF = NFP / 2;                                       // filters per lane of a (population) pair
+    constexpr int HF = NFP / 2;                                       // filters per lane of the pair
     const double m1 = hs.m1, q = hs.q;
     const int wd_type = hs.flags & 1;
     const bool binary = q > 0.0;
@@ -591,7 +602,7 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const Lane
     c2.kind = comp ? d.kind : o.kind; c2.r0 = comp ? d.r0 : o.r0; c2.r1 = comp ? d.r1 : o.r1; c2.t = comp ? d.t : o.t; c2.tg = comp ? d.tg : o.tg;
     // 3. ... and each takes HALF of the filters (the secondary's lane is not idle through the flux combines; a single
     //    star's second lane, idle until now, takes half of the primary's filters)
-    const double c0 = st.hv_c0[j], la = st.hv_la[j];
+    const double c0 = st.hv_c0[j];
     const double mod = lv.par[B9_P_MOD], av = lv.par[B9_P_ABS];      // (LDS; read here, not carried through the chain)
     double obs[HF], wgt[HF];
 #pragma unroll
@@ -611,15 +622,7 @@ __device__ __forceinline__ double star_value_lanes(const DevPack &pk, const Lane
     }
     HS2(8);
     chi2 += __shfl_xor(chi2, 1, 64);                                  // (the sum of the two halves: the same bits in both lanes)
-    const double ll = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
-    double l = ll;
-    if (NPOPS == 2) {
-        const double lam = lv.par[B9_P_LAMBDA];
-        const double ll_o = __shfl_xor(ll, 2, 64);                    // the other population's (every lane takes part in the shuffle)
-        const double ll_a = (sub >> 1) ? ll_o : ll, ll_b = (sub >> 1) ? ll : ll_o;
-        l = logaddexp(log(lam) + ll_a, log1p(-lam) + ll_b);
-    }
-    return logaddexp(la, l);
+    return c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
 }
 
 // one star, all populations, field-star mixture: log( (1-p) fsLike + p L_i )

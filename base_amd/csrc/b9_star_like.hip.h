@@ -29,94 +29,83 @@
 #define B9_K1_WAVES(NFP, NPOPS) ((NFP) > 8 ? 2 : 3)
 
 // The tile of canonical group c that a workgroup reaches at step t of its tile sequence (group_tiles steps per group,
-// groups_per_block groups: g, g + n_blocks, ...); -1 past the end.
+// groups_per_block groups: g, g + n_blocks, ...); -1 past the end.  `lane_slot` is the lane's slot within a tile: the
+// thread id with one population; with two, a workgroup covers HALF of every tile -- slots half * 128 + (tid & 127) -- once
+// per population (hot_groups).  A walker has n_blocks * NPOPS hot workgroups: id gb -> block gb / NPOPS, half gb % NPOPS.
 struct TileSeq {
-    int g, n_blocks, n_groups, group_tiles, groups_per_block, n_tiles;
+    int g, n_blocks, n_groups, group_tiles, groups_per_block, n_tiles, half, lane_slot;
     __device__ __forceinline__ int group(int j) const { const int c = g + j * n_blocks; return (j < groups_per_block && c < n_groups) ? c : -1; }
     __device__ __forceinline__ int tile(int c, int t) const { const int k = c + t * n_groups; return (c >= 0 && t < group_tiles && k < n_tiles) ? k : -1; }
+    __device__ __forceinline__ int slot(int tile_) const { return tile_ * 256 + lane_slot; }
 };
+template <int NPOPS>
+__device__ __forceinline__ TileSeq make_tile_seq(int gb, int n_blocks, int n_groups, int group_tiles, int groups_per_block, int n_tiles)
+{
+    const int tid = threadIdx.x, half = NPOPS == 2 ? (gb & 1) : 0;
+    return TileSeq{NPOPS == 2 ? (gb >> 1) : gb, n_blocks, n_groups, group_tiles, groups_per_block, n_tiles, half,
+                   NPOPS == 2 ? half * 128 + (tid & 127) : tid};
+}
 
-template <int NFP, int NPOPS>
-__device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP> (&iso)[NPOPS],
-                                           double mod, double av, double m1, double q,
-                                           const DevStars &st, int il, double log_lam, double log_1ml)
+// One star (slot il) on the MS/RGB branch of ONE population's isochrone: log p_i L_i without the mixtures.
+template <int NFP>
+__device__ __forceinline__ double hot_star(const DevPack &pk, const IsoView<NFP> &iso, double mod, double av, double m1, double q,
+                                           const DevStars &st, int il)
 {
     const bool binary = q > 0.0;
     const double m2 = q * m1;
-    double ll[2] = {0.0, 0.0};
-    // The population loop is deliberately NOT unrolled: unrolled, the compiler overlaps the two
-    // populations' row loads and transcendental temporaries and spills (324 B of scratch per lane,
-    // 5x slower per star-eval); rolled, the body keeps the single-population register footprint.
-    // The isochrone view is picked with wave-uniform selects.
-#pragma unroll 1
-    for (int k = 0; k < NPOPS; ++k) {
-        // Two populations: everything the second pass could share with the first (observations, weights, the
-        // per-filter shifts, both brackets' inputs) would be hoisted out of this loop and kept in registers across
-        // BOTH passes -- ~60 VGPRs, the difference between two and three waves per SIMD.  The star index and the
-        // absorption are passed through an empty asm so that each pass re-derives them (the re-read observations
-        // come from the L1 the first pass filled).
-        if (NPOPS == 2) { asm volatile("" : "+v"(il)); asm volatile("" : "+v"(av)); }
-        const double *is_mass = (NPOPS == 2 && k) ? iso[NPOPS - 1].mass : iso[0].mass;
-        const double *is_mags = (NPOPS == 2 && k) ? iso[NPOPS - 1].mags : iso[0].mags;
-        const int is_n = (NPOPS == 2 && k) ? iso[NPOPS - 1].n : iso[0].n;
-        int lo1, lo2 = 0;
-        double t1, t2 = 0.0;
-        const double mass0 = is_mass[0];                    // (read once, unconditionally: `||` made it two branches with an LDS round trip each)
-        const bool dark1 = !(m1 > 0.0) | (m1 < mass0);
-        const bool dark2 = !(m2 > 0.0) | (m2 < mass0);
-        find_bracket(is_mass, is_n, m1, lo1, t1);
-        if (binary) find_bracket(is_mass, is_n, m2, lo2, t2);
-        STAMP(4);
-        // two consecutive rows = 2*NFP contiguous doubles
-        const double2 *r1 = reinterpret_cast<const double2 *>(is_mags + (size_t)lo1 * NFP);
-        const double2 *r2 = reinterpret_cast<const double2 *>(is_mags + (size_t)lo2 * NFP);
-        double chi2 = 0.0;
-        double2 a1[NFP], a2[NFP];
+    int lo1, lo2 = 0;
+    double t1, t2 = 0.0;
+    const double mass0 = iso.mass[0];                       // (read once, unconditionally: `||` made it two branches with an LDS round trip each)
+    const bool dark1 = !(m1 > 0.0) | (m1 < mass0);
+    const bool dark2 = !(m2 > 0.0) | (m2 < mass0);
+    find_bracket(iso.mass, iso.n, m1, lo1, t1);
+    if (binary) find_bracket(iso.mass, iso.n, m2, lo2, t2);
+    STAMP(4);
+    // two consecutive rows = 2*NFP contiguous doubles
+    const double2 *r1 = reinterpret_cast<const double2 *>(iso.mags + (size_t)lo1 * NFP);
+    const double2 *r2 = reinterpret_cast<const double2 *>(iso.mags + (size_t)lo2 * NFP);
+    double chi2 = 0.0;
+    double2 a1[NFP], a2[NFP];
 #pragma unroll
-        for (int j = 0; j < NFP; ++j) a1[j] = r1[j];
-        if (binary) {
+    for (int j = 0; j < NFP; ++j) a1[j] = r1[j];
+    if (binary) {
 #pragma unroll
-            for (int j = 0; j < NFP; ++j) a2[j] = r2[j];
-        }
-        double p[NFP];
+        for (int j = 0; j < NFP; ++j) a2[j] = r2[j];
+    }
+    double p[NFP];
+#pragma unroll
+    for (int j = 0; j < NFP / 2; ++j) {
+        p[2 * j] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].x, a1[NFP / 2 + j].x, t1);
+        p[2 * j + 1] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].y, a1[NFP / 2 + j].y, t1);
+    }
+    STAMP(5);
+    if (binary) {
 #pragma unroll
         for (int j = 0; j < NFP / 2; ++j) {
-            p[2 * j] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].x, a1[NFP / 2 + j].x, t1);
-            p[2 * j + 1] = dark1 ? B9_MAG_NOFLUX : lerp(a1[j].y, a1[NFP / 2 + j].y, t1);
+            const double s0 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].x, a2[NFP / 2 + j].x, t2);
+            const double s1 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].y, a2[NFP / 2 + j].y, t2);
+            p[2 * j] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s0 - p[2 * j]));
+            p[2 * j + 1] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s1 - p[2 * j + 1]));
         }
-        STAMP(5);
-        if (binary) {
-#pragma unroll
-            for (int j = 0; j < NFP / 2; ++j) {
-                const double s0 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].x, a2[NFP / 2 + j].x, t2);
-                const double s1 = dark2 ? B9_MAG_NOFLUX : lerp(a2[j].y, a2[NFP / 2 + j].y, t2);
-                p[2 * j] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s0 - p[2 * j]));
-                p[2 * j + 1] -= (2.5 / LN10) * log1pexp((-0.4 * LN10) * (s1 - p[2 * j + 1]));
-            }
-        }
-        STAMP(6);
-        // observed magnitudes and weights are requested only now: they cost 32 VGPRs while live,
-        // and keeping them out of the search / row / combine phases buys a wave per SIMD
-        __builtin_amdgcn_sched_barrier(0);
-        double obs[NFP], wgt[NFP];
-        double c0;
-#pragma unroll
-        for (int f = 0; f < NFP; ++f) {
-            obs[f] = st.obs[B9_SIDX(NFP, f, il)];
-            wgt[f] = st.w[B9_SIDX(NFP, f, il)];
-        }
-        c0 = st.c0[il];
-#pragma unroll
-        for (int f = 0; f < NFP; ++f) {
-            const double d = (p[f] + (mod + pk.abs_m1[f] * av)) - obs[f];
-            chi2 = fma(wgt[f] * d, d, chi2);
-        }
-        const double llk = c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
-        if (k == 0) ll[0] = llk; else ll[1] = llk;
     }
-    double l = ll[0];
-    if (NPOPS == 2) l = logaddexp(log_lam + ll[0], log_1ml + ll[1]);
-    return l;       // log p_i L_i ; the field-star mixture is applied by the caller in product form
+    STAMP(6);
+    // observed magnitudes and weights are requested only now: they cost 32 VGPRs while live,
+    // and keeping them out of the search / row / combine phases buys a wave per SIMD
+    __builtin_amdgcn_sched_barrier(0);
+    double obs[NFP], wgt[NFP];
+    double c0;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) {
+        obs[f] = st.obs[B9_SIDX(NFP, f, il)];
+        wgt[f] = st.w[B9_SIDX(NFP, f, il)];
+    }
+    c0 = st.c0[il];
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) {
+        const double d = (p[f] + (mod + pk.abs_m1[f] * av)) - obs[f];
+        chi2 = fma(wgt[f] * d, d, chi2);
+    }
+    return c0 - 0.5 * (isfinite(chi2) ? chi2 : __builtin_inf());
 }
 
 // Field-star mixture in PRODUCT form.  sum_i log(A_i + e^{l_i}) = log prod_i (A_i + e^{l_i}),
@@ -166,6 +155,82 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
     return (log_ge1(a.mant + a.mant) + (double)(a.expo - 1) * 0.693147180559945309417) + a.add;
 }
 
+// The hot role's star loop (k_star_like, k_mcmc_step and k_mcmc_tree share it): the workgroup's canonical groups, tile after
+// tile (TileSeq), one lane per star and population.  AHEAD (the sampler's kernels): the NEXT tile's star scalars are
+// requested before this tile's arithmetic -- across group boundaries too: one memory round trip less on every tile after
+// the first, for 6 VGPRs (k_star_like, which also carries the per-star output, has none to spare).  At a
+// group's end every wave combines its 64 products (one log per wave) and lane 0 hands the partial of its chunk k (the
+// 64-slot quarter of a tile) to store(c, k, total) -- no end-of-kernel barrier with one population, so a cheap
+// (single-star) wave never waits for an expensive one.  (i, m1, q, ea) are the first tile's scalars, requested by the caller
+// at its entry.  `valid` is uniform over the workgroup (the walker's candidate is inside the grid).
+//
+// TWO POPULATIONS are laid over the workgroup's WAVES, not looped over in a lane: the workgroup covers half of every tile
+// (TileSeq), waves 0-1 evaluate its 128 stars on population A's isochrone, waves 2-3 the same stars on population B's.  A
+// wave's isochrone is wave-uniform and the body keeps the one-population register footprint and instruction stream; B's
+// value crosses through LDS (two buffers, one barrier per tile) and the A lane, which owns the star, forms the one
+// logaddexp, the field-star factor and the partial.  Which lane multiplies which star into which partial is the
+// one-population mapping: partial (c, k) is the product over chunk k of the group's tiles, whoever computes it.
+__device__ __forceinline__ double *hot_lds_cross() { __shared__ double s_ll[2][128]; return &s_ll[0][0]; }
+
+template <int NFP, int NPOPS, bool AHEAD, class Store>
+__device__ __forceinline__ void hot_groups(const DevPack &pk, const DevStars &st, const TileSeq &seq, const IsoView<NFP> (&iso)[NPOPS],
+                                           bool valid, double tip_min, double mod, double av, double log_lam, double log_1ml,
+                                           int i, double m1, double q, double ea, double *__restrict__ perstar_row, Store store)
+{
+    const int tid = threadIdx.x;
+    const bool pop_b = NPOPS == 2 && __builtin_amdgcn_readfirstlane(tid >> 7) != 0;      // (owner lanes: population A's)
+    const int k = NPOPS == 2 ? seq.half * 2 + ((tid >> 6) & 1) : (tid >> 6);            // this wave's chunk of a tile
+    if (!valid) {                                           // outside the grid: the walker's log-posterior is -inf
+        for (int j = 0; j < seq.groups_per_block; ++j) {
+            const int c = seq.group(j);
+            if (c < 0) break;
+            if (perstar_row && !pop_b)
+                for (int t = 0; t < seq.group_tiles && seq.tile(c, t) >= 0; ++t) {
+                    const int s = st.perm[seq.slot(seq.tile(c, t))];
+                    if (s >= 0) perstar_row[s] = NEG_INF;
+                }
+            if ((tid & 63) == 0 && !pop_b) store(c, k, 0.0);
+        }
+        return;
+    }
+    IsoView<NFP> mine = iso[0];
+    if (pop_b) mine = iso[NPOPS - 1];
+    int j = 0, t = 0, c = seq.group(0), n = 0;
+    MixAcc acc;
+    acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;            // = 1.0
+    while (c >= 0) {
+        int jn = j, tn = t + 1, cn = c;                     // the workgroup's next tile, across the group boundary
+        if (seq.tile(c, tn) < 0) { jn = j + 1; tn = 0; cn = seq.group(jn); }
+        const int i_n = seq.slot(cn >= 0 ? seq.tile(cn, tn) : seq.tile(c, t));
+        double m1_n, q_n, ea_n;
+        if (AHEAD) { m1_n = st.mass1[i_n]; q_n = st.q[i_n]; ea_n = st.ea[i_n]; }
+        STAMP(3);
+        const bool live = !(m1 > tip_min);                  // (else: heavier than the AGB tip -- the heavy role's -- or an empty slot, +inf)
+        double l = 0.0;
+        if (live) l = hot_star<NFP>(pk, mine, mod, av, m1, q, st, i);
+        if constexpr (NPOPS == 2) {
+            double *const cross = hot_lds_cross() + (n & 1) * 128;
+            if (pop_b) cross[tid & 127] = l;
+            __syncthreads();
+            if (!pop_b) l = logaddexp(log_lam + l, log_1ml + cross[tid & 127]);
+        }
+        if (live && !pop_b) {
+            mix_add(acc, ea, l);
+            if (perstar_row) perstar_row[st.perm[i]] = mix_value(ea, l);
+        }
+        if (cn != c) {                                      // the group is complete
+            STAMP(7);
+            if (!pop_b) {
+                const double tot = mix_wave_total(acc);
+                if ((tid & 63) == 0) store(c, k, tot);
+            }
+            acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;
+        }
+        if (!AHEAD) { m1_n = st.mass1[i_n]; q_n = st.q[i_n]; ea_n = st.ea[i_n]; }
+        i = i_n; m1 = m1_n; q = q_n; ea = ea_n; j = jn; t = tn; c = cn; ++n;
+    }
+}
+
 // The stars the hot path skips -- primary heavier than the walker's AGB tip (IFMR -> WD cooling -> WD
 // atmosphere, or NS/BH) -- are evaluated by extra workgroups of the SAME launch (`parts` per walker), through the
 // general per-star code.  The role is ONE long dependent chain per star (~10 us: precursor age -> cooling age ->
@@ -181,7 +246,11 @@ __device__ __forceinline__ double mix_wave_total(MixAcc a)
 //     entry, segment by segment, all loads independent: one memory round trip (it used to be 6 + 4 NPOPS dependent ones).
 //   * It is short of REGISTERS (it wants ~190 VGPRs under the kernel's cap of 168): what the chain does not need until
 //     its end is requested there, and with one population the lane view lives in scalar registers.
-// A star occupies G = 2 NPOPS neighbouring lanes: (population, component) -- star_value_lanes.
+// A star occupies a PAIR of neighbouring lanes (its two components: star_ll_lanes).  TWO POPULATIONS are two wave pairs:
+// waves 0-1 walk the chunks on population A's isochrone, waves 2-3 the SAME chunks on population B's, so a wave's lane view
+// is uniform (scalar registers) and a star between the two populations' AGB tips has its WD chain in one wave and its MS/RGB
+// bracket in another instead of both, serialised, in every wave.  B's log-likelihood crosses through LDS; the A lane forms
+// the mixtures.  The chunk loop's trip count is then agreed by the whole workgroup (__syncthreads_or).
 template <int NFP, int NPOPS, int NC, class SelectFn>
 __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *const (&hdr)[NC],
                                             const double *const (&iso_data)[NC], long long iso_stride, int mass_cap,
@@ -255,43 +324,50 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
             for (int e = tid + 256 * rc(g); e < len; e += 256) s_axes[seg_off[g] + e] = seg_src[g][e];     // very long segments only
         }
     };
-    // the first chunk's stars (which chunk is a matter of part / wave / lane and of the mode below), also requested now:
-    // chunks of PER stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over
-    // the waves second
-    constexpr int G = 2 * NPOPS, PER = 64 / G;
-    const int sub2 = lane % G;
-    const int j_a = (part + parts * wave) * PER + lane / G, j_b = (part + parts * (wave & 1)) * PER + lane / G;
-    const HeavyStar cur_a = load_heavy_star(st, j_a < st.n ? j_a : st.n - 1);
-    const HeavyStar cur_b = NC == 2 ? load_heavy_star(st, j_b < st.n ? j_b : st.n - 1) : cur_a;
+    // the first chunk's stars, also requested now: chunks of PER stars of the descending-mass list are dealt round-robin
+    // over the walker's workgroups first and over a population's waves second
+    constexpr int PER = 32, WPP = NPOPS == 2 ? 2 : 4;           // stars per chunk (a lane pair each); waves per population
+    const int comp = lane & 1;
+    const int wv = NPOPS == 2 ? (wave & 1) : wave;               // this wave among its population's
+    const bool pop_b = NPOPS == 2 && __builtin_amdgcn_readfirstlane(wave >> 1) != 0;
+    const int j_a = (part + parts * wv) * PER + lane / 2;
+    const int jj_a = j_a < st.n ? j_a : st.n - 1;
+    const double cur_m1_a = st.heavy_mass[jj_a], cur_q_a = st.hv_q[jj_a];
+    const int cur_flags_a = st.hv_flags[jj_a];
     // (both candidates' headers are requested BEFORE the selection is known -- one round trip fewer on the chain; a
     //  candidate that does not exist yet, in the first launch of a block, holds anything: its fields are only used once
     //  selected, and it never is)
-    IsoView<NFP> iso[NC][NPOPS];
+    // A wave keeps ONE population's view per candidate (its own), and of the other population only what decides
+    // validity and the smaller tip: four full views would not fit the scalar registers.
+    IsoView<NFP> mine[NC];
     bool valid[NC];
     double tip_min[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) valid[c] = load_iso_views<NFP, NPOPS>(hdr[c], iso_data[c], iso_stride, mass_cap, w, iso[c], tip_min[c]);
-    // How long a candidate's heavy list is needs no search: the list descends, so "at most T stars above the tip" is
-    // heavy_mass[T] <= tip -- one load at an address known at entry.
-    // SPECULATIVE mode (the sampler step, both candidates derived): when each candidate's heavy stars fit one round of
-    // HALF the workgroups' waves (T = parts * 2 * PER), waves 0-1 evaluate candidate 0 and waves 2-3 candidate 1 side by
-    // side, and the role never waits for the decision (the next launch's decision picks the partial of the candidate
-    // that counted).  Longer lists wait for the decision and evaluate that candidate alone with all four waves
-    // (evaluating both would double the rounds).
-    const int T = parts * 2 * PER;
-    const double m_first = st.heavy_mass[0], m_T = T < st.n ? st.heavy_mass[T] : -__builtin_inf();
+    for (int c = 0; c < NC; ++c) {
+        valid[c] = true; tip_min[c] = __builtin_inf();
+#pragma unroll
+        for (int kp = 0; kp < NPOPS; ++kp) {
+            const IsoHdr h = hdr[c][w * NPOPS + kp];
+            valid[c] = valid[c] && h.valid;
+            tip_min[c] = h.agb_tip < tip_min[c] ? h.agb_tip : tip_min[c];
+            if (kp == 0 || pop_b) {                          // (wave-uniform: population B's waves overwrite A's view with their own)
+                const double *g = iso_data[c] + (size_t)(w * NPOPS + kp) * iso_stride;
+                mine[c].n = h.n; mine[c].tip = h.agb_tip; mine[c].i_feh = h.i_feh; mine[c].i_y = h.i_y;
+                mine[c].t_feh = h.t_feh; mine[c].t_y = h.t_y; mine[c].mass = g; mine[c].mags = g + mass_cap;
+            }
+        }
+    }
+    // Whether a candidate has a heavy star at all needs no search: the list descends, so "none" is heavy_mass[0] <= tip --
+    // one load at an address known at entry.  The role waits for the decision and evaluates that candidate alone
+    // (evaluating both cost more than it saved: usually only one of them has heavy stars at all).
+    const double m_first = st.heavy_mass[0];
     bool none[NC];                                                               // no star above the candidate's tip
 #pragma unroll
     for (int c = 0; c < NC; ++c) none[c] = !(m_first > tip_min[c]);
-    bool spec = false;
-    (void)m_T; (void)both_exist;
-    const int sel = (NC == 2 && !spec) ? select() : 0;
-    const int wpc = spec ? 2 : 4;                                                // waves per candidate
-    const int cand = spec ? (wave >> 1) : sel;                                   // this wave's candidate
-    if (!spec) {
+    (void)both_exist;
+    const int sel = NC == 2 ? select() : 0;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) if (c != sel) { valid[c] = false; tip_min[c] = __builtin_inf(); }
-    }
+    for (int c = 0; c < NC; ++c) if (c != sel) { valid[c] = false; tip_min[c] = __builtin_inf(); }
     {   // nothing to do: no valid candidate, or no heavy star under any candidate this workgroup evaluates
         bool any = false;
 #pragma unroll
@@ -313,38 +389,24 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
         for (int e = tid; e < 4 * NPOPS * NC * na; e += 256) {
             const int col = e / na, j = e - col * na, q = col & 3, ck = col >> 2, c = ck / NPOPS, kp = ck - c * NPOPS;
             const int df = q >> 1, dy = q & 1;
-            int v_feh = 0, v_y = 0;
-#pragma unroll
-            for (int cc = 0; cc < NC; ++cc)
-#pragma unroll
-                for (int kk = 0; kk < NPOPS; ++kk) {
-                    const bool me = (valid[c] ? c : safe) == cc && kp == kk;
-                    v_feh = me ? iso[cc][kk].i_feh : v_feh; v_y = me ? iso[cc][kk].i_y : v_y;
-                }
+            const IsoHdr *hp = (valid[c] ? c : safe) ? hdr[NC - 1] : hdr[0];     // (re-read: this path runs on large grids only)
+            const int v_feh = hp[w * NPOPS + kp].i_feh, v_y = hp[w * NPOPS + kp].i_y;
             s_axes[tip_lo + e] = pk.tips[(size_t)((v_feh + df) * pk.n_y + (v_y + (dy < ny ? dy : 0))) * na + j];
         }
     }
     __syncthreads();
     HSTAMP(3); B9_MARK("hv-stars-begin");
-    // this lane's (candidate, population, component)
-    // A star occupies G = 2 NPOPS neighbouring lanes (population, component) of the evaluated candidate's chain.
-    const int pop = sub2 >> 1;
-    // With one population and the decision taken, everything the lane view holds is the same in every lane of the wave:
-    // say so (readfirstlane), and it lives in scalar registers -- ~25 VGPRs in a role that spills for want of them.
-    auto uni_i = [](int x) { return (NPOPS == 1) ? __builtin_amdgcn_readfirstlane(x) : x; };
-    auto uni_d = [](double x) {
-        if (NPOPS != 1) return x;
-        const unsigned long long b = __double_as_longlong(x);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-        return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-    };
+    // Everything the lane view holds is the same in every lane of the wave (one candidate, one population per wave): say
+    // so (readfirstlane), and it lives in scalar registers -- ~25 VGPRs in a role that is short of them.
+    auto uni_i = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    auto uni_d = [](double x) { return wave_uniform(x); };
     LaneView<NFP> lv;
     {
-        const int cs = uni_i((cand ? valid[NC - 1] : valid[0]) ? cand : safe);   // the candidate whose views this lane reads
-        const bool B = NPOPS == 2 && pop;
+        const int cs = uni_i((sel ? valid[NC - 1] : valid[0]) ? sel : safe);     // the candidate whose views this wave reads
+        const bool B = pop_b;
         const bool C = cs != 0;
         // (field-by-field selects with constant indices: a run-time index would put the views in scratch memory)
-#define B9_PICK(field) (C ? (B ? iso[NC - 1][NPOPS - 1].field : iso[NC - 1][0].field) : (B ? iso[0][NPOPS - 1].field : iso[0][0].field))
+#define B9_PICK(field) (C ? mine[NC - 1].field : mine[0].field)
         lv.is_mags = B9_PICK(mags); lv.is_n = uni_i(B9_PICK(n)); lv.is_tip = uni_d(B9_PICK(tip));
         lv.t_feh = uni_d(B9_PICK(t_feh)); lv.t_y = uni_d(B9_PICK(t_y));
         const int v_feh = uni_i(B9_PICK(i_feh)), v_y = uni_i(B9_PICK(i_y));
@@ -363,34 +425,46 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
             lv.ax.tips[q] = s_axes + tip_lo + col * na;
         }
     }
-    const bool my_valid = uni_i((cand ? valid[NC - 1] : valid[0]) ? 1 : 0) != 0;
-    const double my_tip = uni_d(cand ? tip_min[NC - 1] : tip_min[0]);
+    const bool my_valid = uni_i((sel ? valid[NC - 1] : valid[0]) ? 1 : 0) != 0;
+    const double my_tip = uni_d(sel ? tip_min[NC - 1] : tip_min[0]);             // (the smaller of the populations' tips: the same in every wave)
     double acc = 0.0;
-    // chunks of PER stars of the descending-mass list are dealt round-robin over the walker's workgroups first and over a
-    // candidate's waves second (a short list spreads over as many CUs as there are parts); a wave stops at its first chunk
-    // without a heavy star (masses descend).  Wave-uniform trip count: the shuffles see full EXEC.  The next chunk's star data
-    // are requested before this chunk is evaluated.
-    int c = part + parts * (spec ? (wave & 1) : wave);
-    int j = c * PER + lane / G, jj = j < st.n ? j : st.n - 1;
-    HeavyStar cur = spec ? cur_b : cur_a;
-    while (c * PER < st.n) {
-        const bool live = j < st.n && my_valid && cur.m1 > my_tip;
-        if (__ballot(live) == 0ull) break;
+    // A wave stops at its first chunk without a heavy star (masses descend) -- with two populations, when no wave of the
+    // workgroup has one (the pairs exchange through LDS behind the barrier that also takes that vote).  Wave-uniform trip
+    // count: the shuffles see full EXEC.  The next chunk's star data are requested before this chunk is evaluated.
+    int c = part + parts * wv;
+    int j = c * PER + lane / 2, jj = j < st.n ? j : st.n - 1;
+    double cur_m1 = cur_m1_a, cur_q = cur_q_a;                                   // (scalars, not a HeavyStar: a copied struct left a dead stack slot)
+    int cur_flags = cur_flags_a;
+    for (int it = 0; ; ++it) {
+        const bool live = c * PER < st.n && j < st.n && my_valid && cur_m1 > my_tip;
+        const bool any = __ballot(live) != 0ull;
+        if (NPOPS == 1 && !any) break;
         // (the lanes of a star that is NOT above the tip -- most of a short list's last chunk -- present mass 0: "no star",
         //  the shortest path; left alone they would walk the MS/RGB branch, serialised with the live lanes' WD branch)
-        HeavyStar hs = cur;
-        hs.m1 = live ? cur.m1 : 0.0;
-        const double v = star_value_lanes<NFP, NPOPS>(pk, lv, st, jj, hs, sub2);
-        if (live && sub2 == 0) {
+        HeavyStar hs;
+        hs.m1 = live ? cur_m1 : 0.0; hs.q = cur_q; hs.flags = cur_flags;
+        double l = 0.0;
+        if (any) l = star_ll_lanes<NFP>(pk, lv, st, jj, hs, comp);
+        if constexpr (NPOPS == 2) {
+            __shared__ double s_cross[2][128];
+            double *const cross = s_cross[it & 1];
+            if (pop_b) cross[wv * 64 + lane] = l;
+            if (!__syncthreads_or(any ? 1 : 0)) break;                          // (no wave of the workgroup has a heavy star left)
+            if (!pop_b) {                                                        // (log lambda is formed here, after the chain: nothing rides through it)
+                const double lam = lv.par[B9_P_LAMBDA];
+                l = logaddexp(log(lam) + l, log1p(-lam) + cross[wv * 64 + lane]);
+            }
+        }
+        if (live && comp == 0 && !pop_b) {
+            const double v = logaddexp(st.hv_la[jj], l);
             if (perstar) perstar[(size_t)w * st.n + st.hv_perm[jj]] = v;
             acc += v;
         }
-        c += parts * wpc; j = c * PER + lane / G; jj = j < st.n ? j : st.n - 1;
-        cur = load_heavy_star(st, jj);
+        c += parts * WPP; j = c * PER + lane / 2; jj = j < st.n ? j : st.n - 1;
+        cur_m1 = st.heavy_mass[jj]; cur_q = st.hv_q[jj]; cur_flags = st.hv_flags[jj];
     }
     HSTAMP(4); B9_MARK("hv-stars-end");
-    // the partials: fixed-order sums over the waves (decision first: the evaluated candidate's, 0 in the other slot;
-    // speculative: each candidate's two waves)
+    // the partial: a fixed-order sum over the waves -- the evaluated candidate's, 0 in the other slot
     {
         const double sum = wave_sum(acc);
         if (lane == 0) s_red[wave] = sum;
@@ -398,14 +472,9 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     __syncthreads();
     HSTAMP(5);
     if (tid == 0) {
-        if (spec) {
-            *out_partial[0] = s_red[0] + s_red[1];
-            *out_partial[NC - 1] = s_red[2] + s_red[3];
-        } else {
-            const double tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        const double tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) *out_partial[c] = c == sel ? tot : 0.0;
-        }
+        for (int c2 = 0; c2 < NC; ++c2) *out_partial[c2] = c2 == sel ? tot : 0.0;
     }
 }
 
@@ -439,13 +508,13 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevP
     STAMP(0);
     const int L = blockIdx.x - hot_blocks, xcd = L & 7, s = L >> 3;      // hot_blocks is a multiple of 8
     const int w = s % n_walkers;
-    const int g = (s / n_walkers) * 8 + xcd;            // this workgroup among the walker's n_blocks
-    if (g >= n_blocks) return;
-    const TileSeq seq{g, n_blocks, n_groups, group_tiles, groups_per_block, st.n_pad / 256};
+    const int g = (s / n_walkers) * 8 + xcd;            // this workgroup among the walker's n_blocks * NPOPS
+    if (g >= n_blocks * NPOPS) return;
+    const TileSeq seq = make_tile_seq<NPOPS>(g, n_blocks, n_groups, group_tiles, groups_per_block, st.n_pad / 256);
 
     // ---- first round trip: everything that depends only on the kernel arguments ------------
-    int i = seq.tile(seq.group(0), 0) * 256 + tid;          // (a group's first tile always exists)
-    double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
+    const int i = seq.slot(seq.tile(seq.group(0), 0));      // (a group's first tile always exists)
+    const double m1 = st.mass1[i], q = st.q[i], ea = st.ea[i];
     // the mass columns: the source address needs no header field, and copying the full capacity
     // instead of hdr.n entries costs nothing (the tail is never searched)
     double *const lds_mass = smem;
@@ -470,39 +539,13 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevP
         tip_min = h.agb_tip < tip_min ? h.agb_tip : tip_min;
     }
     const double mod = par[B9_P_MOD], av = par[B9_P_ABS], lam = NPOPS == 2 ? par[B9_P_LAMBDA] : 1.0;
-    const double log_lam = NPOPS == 2 ? log(lam) : 0.0, log_1ml = NPOPS == 2 ? log1p(-lam) : 0.0;
+    const double log_lam = NPOPS == 2 ? wave_uniform(log(lam)) : 0.0, log_1ml = NPOPS == 2 ? wave_uniform(log1p(-lam)) : 0.0;
     STAMP(1);
     __syncthreads();
     STAMP(2);
-
-    for (int j = 0; j < groups_per_block; ++j) {
-        const int c = seq.group(j);
-        if (c < 0) break;
-        MixAcc acc;
-        acc.mant = 0.5; acc.expo = 1; acc.add = 0.0;            // = 1.0
-        for (int t = 0; t < group_tiles; ++t) {
-            const int tile = seq.tile(c, t);
-            if (tile < 0) break;
-            if (j > 0 || t > 0) {
-                i = tile * 256 + tid;
-                m1 = st.mass1[i]; q = st.q[i]; ea = st.ea[i];
-            }
-            STAMP(3);
-            if (!valid) {   // outside the grid: the walker's log-posterior is -inf (k_finalize)
-                if (perstar && st.perm[i] >= 0) perstar[(size_t)w * st.n + st.perm[i]] = NEG_INF;
-                continue;
-            }
-            if (!(m1 > tip_min)) {     // empty slots hold m1 = +inf
-                const double l = hot_star<NFP, NPOPS>(pk, iso, mod, av, m1, q, st, i, log_lam, log_1ml);
-                mix_add(acc, ea, l);
-                if (perstar) perstar[(size_t)w * st.n + st.perm[i]] = mix_value(ea, l);
-            }
-        }
-        STAMP(7);
-        // wave combine (one log per wave); every wave stores its own partial -- no end-of-kernel barrier, so a cheap
-        // (single-star) wave never waits for an expensive one
-        const double tot = mix_wave_total(acc);
-        if ((tid & 63) == 0) partial[(size_t)w * partial_stride + c * 4 + (tid >> 6)] = valid ? tot : 0.0;
-    }
+    double *const prow = partial + (size_t)w * partial_stride;
+    hot_groups<NFP, NPOPS, false>(pk, st, seq, iso, valid, tip_min, mod, av, log_lam, log_1ml, i, m1, q, ea,
+                           perstar ? perstar + (size_t)w * st.n : nullptr,
+                           [&](int c, int k, double tot) { prow[c * 4 + k] = tot; });
     STAMP(8);
 }
