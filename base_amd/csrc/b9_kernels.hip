@@ -201,10 +201,16 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     hipLaunchKernelGGL((k_marg_table<NFP>), dim3(n_walkers * NPOPS, L.n_chunks), dim3(256), lds, stream, pk, hdr, iso_data,
                        iso_stride, mass_cap, NPOPS, d_params, K, Q, tab, L);
     // the stars: one workgroup (four waves sharing the node table's sub-chunks) per (64-star chunk, walker), dispatched in DevStars::marg_order
-    const int cpx = (st.mg_pad / 64 + 7) / 8;
+    // XCD placement (k_star_marg's head): two walker groups x four star-chunk groups.  Each XCD's L2 fetches its group's node
+    // tables and its share of the stars once: 8 x (tables / wsplit) + wsplit x (star copy) bytes in all -- 50k stars x 8
+    // walkers, 4 x 4 grid: 42.5 MB per launch at wsplit 1, 35.2 at 2, 41.3 at 4 (rocprofv3 FETCH_SIZE; the launch time is the
+    // same for all three: 164 us -- the kernel is VALU-bound, the placement only decides how much crosses the fabric)
+    const int wsplit = n_walkers % 2 == 0 ? 2 : 1;
+    const int csplit = 8 / wsplit, n_chunks = st.mg_pad / 64;
+    const int per_xcd = ((n_chunks + csplit - 1) / csplit) * (n_walkers / wsplit);
     const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
-    hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE>), dim3(8 * cpx * n_walkers), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
-                       mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2);
+    hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
+                       mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit);
     if (st.n_wd > 0)          // the catalogue's WD-stage stars: their own (register-hungry) kernel, beside the main one's tail
         hipLaunchKernelGGL((k_star_marg_wd<NFP, NPOPS, SAMPLE>), dim3((st.n_wd + 3) / 4, n_walkers), dim3(256), 0, stream, pk, st, hdr,
                            iso_data, iso_stride, mass_cap, d_params, partial, partial_stride, perstar, K, ms);

@@ -205,7 +205,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                  int mass_cap, const double *__restrict__ params,
                  double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
                  int K, int Q, MargSample ms, const double *__restrict__ tab, MargLayout L,
-                 int n_walkers, double cut2)
+                 int n_walkers, double cut2, int wsplit)
 {
     __shared__ double s_tmax[NPOPS][4][64], s_ref[NPOPS][4][64], s_sm[NPOPS][4][64];
     __shared__ unsigned long long s_mask[NPOPS][B9_MARG_MASK_WORDS];
@@ -213,14 +213,19 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     __shared__ int s_bpop[SAMPLE ? 4 : 1][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     MLIFE(0, __builtin_amdgcn_s_memrealtime());
-    // 1-D grid of ceil(chunks / 8) * 8 * n_walkers workgroups; ids are dealt round-robin over the 8 XCDs.  Dispatch position
-    // p = id / n_walkers' share -> star chunk marg_order[p]: most expensive chunks first, neighbours in the order on different
-    // XCDs (a contiguous share per XCD left the XCD holding the giants working alone for the launch's second half), and
-    // inside an XCD the walkers of one star chunk are neighbours in dispatch order: the chunk's star data is fetched from
-    // HBM once.  (Speed only; any placement is correct.)
+    // 1-D grid; ids are dealt round-robin over the 8 XCDs.  An XCD takes one of `wsplit` (1, 2, 4 or 8, dividing the walker
+    // count) walker groups and one of 8 / wsplit star-chunk groups: its L2 then holds n_walkers / wsplit node tables and
+    // fetches 1 / (8 / wsplit) of the star data per walker of its group -- the split trades table re-fetches against star
+    // re-fetches (b9k_star_marg picks it).  Dispatch position p -> star chunk marg_order[p]: most expensive chunks first,
+    // neighbours in the order on different XCD groups (a contiguous share per XCD left the XCD holding the giants working
+    // alone for the launch's second half), and inside an XCD the walkers of one star chunk are neighbours in dispatch
+    // order: the chunk's star data is fetched from HBM once per group.  (Speed only; any placement is correct.)
     const int xcd = blockIdx.x & 7, i_x = blockIdx.x >> 3;
-    const int p_local = i_x / n_walkers, w = i_x - p_local * n_walkers;
-    const int pos = p_local * 8 + xcd;
+    const int csplit = 8 / wsplit, wg_n = n_walkers / wsplit;           // chunk groups; walkers per group
+    const int a = xcd % wsplit, b = xcd / wsplit;
+    const int p_local = i_x / wg_n, wl = i_x - p_local * wg_n;
+    const int w = wl * wsplit + a;
+    const int pos = p_local * csplit + b;
     if (pos * 64 >= st.mg_pad) return;
     const int sc = st.marg_order[pos];
     const int slot = sc * 64 + lane;                                // (slot of the marginalised mode's own copy: DevStars::mg_*)
