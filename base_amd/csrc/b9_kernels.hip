@@ -35,7 +35,7 @@
 //
 // No MFMA anywhere: there is no dense contraction on this path (BASELINE.json north_star).
 // Diagnostic-only macros (never defined in the shipped library): B9_STAMPS (per-phase s_memtime
-// stamps), B9_ABL_* (ablation builds used for the attribution in DESIGN.md section 8).
+// stamps), B9_ABL_* (ablation builds used for the attribution in docs/LABNOTES.md section 8).
 #include "b9_device.h"
 #include "b9_launch.h"
 #include <algorithm>

@@ -184,7 +184,7 @@ def _two_ranks_one_gpu(pack, stars, priors, options, start, tuning, **run_kw):
 @pytest.mark.parametrize("n_walkers", [8, 16])
 def test_rank_count_invariance_at_50k_stars(n_walkers):
     """A walker's chain is the same BITS whatever the number of ranks its ensemble is spread over -- with nothing pinned.
-    The star-to-partial-sum grouping (canonical tile groups: DESIGN.md section 6) is a function of the catalogue, the pack and
+    The star-to-partial-sum grouping (canonical tile groups: DESIGN.md section 3) is a function of the catalogue, the pack and
     the device only; a launch plan only chooses how many whole groups a workgroup takes.  50 000 stars: 8 walkers on one GPU
     against 4 + 4 on two ranks (same groups per workgroup, half the workgroups), and 16 walkers on one GPU -- two groups
     = 6 tiles per hot workgroup -- against 8 + 8 at one group = 3 tiles: the plans differ, the bits do not."""
