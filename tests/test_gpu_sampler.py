@@ -380,3 +380,19 @@ def test_bench_forced_ranks_on_one_gpu():
     assert line["n_gpus"] == 1 and cfg["ranks"] == 1 and cfg["forced_ranks"] is True
     assert "RCCL" in cfg["collective"] and cfg["rccl_ranks"] == 1 and len(cfg["devices"]) == 1 and ":" in cfg["devices"][0]
     assert line["value"] > 0 and line["roofline"]["useful_frac"] > 0
+
+
+def test_bench_under_torchrun_with_an_rccl_communicator():
+    """The driver's own launch form -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- with N = 1 and
+    the multi-rank route forced (B9_FORCE_RANKS): the rank takes RANK / WORLD_SIZE / LOCAL_RANK from torchrun, names the
+    RCCL id file after torchrun's run id (no B9_LAUNCH_NONCE here), brings a communicator up and gathers device rows."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "B9_RANK", "B9_LAUNCH_NONCE", "B9_DIST_DIR")}
+    env["B9_FORCE_RANKS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline", "--no-marginalised", "--no-sustained"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["ranks"] == 1 and "RCCL" in cfg["collective"] and cfg["rccl_ranks"] == 1 and len(cfg["devices"]) == 1
+    assert line["value"] > 0 and line["sustained"] is None
