@@ -160,7 +160,11 @@ class RcclExchange final : public Exchange {
         HIPX(hipMalloc((void **)&d_scalar_, sizeof(double) * 2));
         HIPX(hipHostMalloc((void **)&h_scalar_, sizeof(double) * 2, hipHostMallocDefault));
         barrier();                                            // everyone has read the id
-        if (rank == 0) std::remove(path.c_str());
+        if (rank == 0) {
+            std::remove(path.c_str());
+            // (under a launcher that is not ours -- torchrun -- nobody else would remove the directory: it is empty now)
+            if (!std::getenv("B9_LAUNCH_NONCE")) (void)::rmdir(dir.c_str());
+        }
         // what the communicator itself says about the group: its rank count, and every rank's GPU (PCI bus id),
         // all-gathered through it -- a record that N distinct devices took part, not an echo of the arguments
         NCCLX(ncclCommCount(comm_, &comm_count_));
