@@ -224,8 +224,11 @@ int build_stars(b9_ctx *ctx)
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return spread[a] > spread[b]; });
         st.mg_pad = mg_pad;
-        if ((rc = upload(ctx, ctx->star_allocs, mg_obs.data(), mg_obs.size(), &st.mg_obs))) return rc;
-        if ((rc = upload(ctx, ctx->star_allocs, mg_w.data(), mg_w.size(), &st.mg_w))) return rc;
+        // what the kernel reads is the SCALED pair (sqrt(w), sqrt(w) obs): a term's chi^2 is then sum_f fma(sw, C_f, -so)^2 --
+        // two instructions per filter instead of three (sqrt(w)^2 = w to 1 ulp; an unused filter has sw = so = 0)
+        for (size_t k = 0; k < mg_w.size(); ++k) { const double sw = std::sqrt(mg_w[k]); mg_obs[k] = sw * mg_obs[k]; mg_w[k] = sw; }
+        if ((rc = upload(ctx, ctx->star_allocs, mg_obs.data(), mg_obs.size(), &st.mg_so))) return rc;
+        if ((rc = upload(ctx, ctx->star_allocs, mg_w.data(), mg_w.size(), &st.mg_sw))) return rc;
         if ((rc = upload(ctx, ctx->star_allocs, mg_c0m.data(), mg_c0m.size(), &st.mg_c0m))) return rc;
         if ((rc = upload(ctx, ctx->star_allocs, mg_la.data(), mg_la.size(), &st.mg_la))) return rc;
         if ((rc = upload(ctx, ctx->star_allocs, mg_perm.data(), mg_perm.size(), &st.mg_perm))) return rc;

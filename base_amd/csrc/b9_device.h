@@ -80,7 +80,7 @@ struct DevStars {
     // union's size: neighbours in brightness share their windows (neighbours in catalogue mass do not: a binary sits with
     // singles of another brightness, and the catalogue's masses are only hints in this mode).  Speed only.
     int mg_pad;                      // slots of the copy (whole chunks)
-    const double *mg_obs, *mg_w;     // [mg_pad / 64][nfp][64]
+    const double *mg_so, *mg_sw;     // [mg_pad / 64][nfp][64]: sqrt(w) obs, sqrt(w) (w = 1 / sigma^2; 0 = unused filter)
     const double *mg_c0m, *mg_la;    // [mg_pad]
     const int *mg_perm;              // [mg_pad] original index of the star, -1 = empty
     // ... and the order in which the chunks are dispatched: widest photometric spread (= largest union) first, so that the

@@ -78,27 +78,35 @@ __device__ __forceinline__ double min_vs(double a, double s_u) { double r; asm("
 __device__ __forceinline__ double max_vv(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double fma_vvs(double a, double b, double s_u) { double r; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(s_u)); return r; }
 
-// lower bound of sum_f w_f (C_f - obs_f)^2 over every row with lo_f <= C_f <= hi_f (box = {lo[NFP], hi[NFP]}, wave-uniform)
+// The star enters every chi^2 as the SCALED pair so_f = sqrt(w_f) obs_f, sw_f = sqrt(w_f) (staged at load): a row's
+// contribution sqrt(w_f) (C_f - obs_f) is ONE fma(sw_f, C_f, -so_f) with the magnitude as the scalar operand, its square
+// one more -- two VALU instructions per filter where w (C - obs)^2 took three (subtract, multiply, fma).
+
+// lower bound of sum_f w_f (C_f - obs_f)^2 over every row with lo_f <= C_f <= hi_f (box = {lo[NFP], hi[NFP]}, wave-uniform):
+// the scaled distance of obs_f to the interval is max(sw lo - so, so - sw hi, 0)
 template <int NFP>
-__device__ __forceinline__ double box_bound(const double *__restrict__ box, const double (&obs)[NFP], const double (&wgt)[NFP])
+__device__ __forceinline__ double box_bound(const double *__restrict__ box, const double (&so)[NFP], const double (&sw)[NFP])
 {
     double lb = 0.0;
 #pragma unroll
     for (int f = 0; f < NFP; ++f) {
-        const double c = min_vs(max_vs(obs[f], box[f]), box[NFP + f]);      // obs clamped into the box
-        const double dd = obs[f] - c;
-        lb = fma(wgt[f] * dd, dd, lb);
+        double a, b;
+        asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(a) : "v"(sw[f]), "s"(box[f]), "v"(so[f]));          // sw lo - so
+        asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(b) : "v"(sw[f]), "s"(box[NFP + f]), "v"(so[f]));   // so - sw hi
+        double m = max_vv(a, b);
+        asm("v_max_f64 %0, %1, 0" : "=v"(m) : "v"(m));
+        lb = fma(m, m, lb);
     }
     return lb;
 }
 
 // X = nb + chi^2 of one table row (wave-uniform row, per-lane star)
 template <int NFP>
-__device__ __forceinline__ double row_x(const double *__restrict__ row, double nb, const double (&obs)[NFP], const double (&wgt)[NFP])
+__device__ __forceinline__ double row_x(const double *__restrict__ row, double nb, const double (&so)[NFP], const double (&sw)[NFP])
 {
     double x = nb;
 #pragma unroll
-    for (int f = 0; f < NFP; ++f) { const double dd = row[f] - obs[f]; x = fma(wgt[f] * dd, dd, x); }
+    for (int f = 0; f < NFP; ++f) { const double dd = fma(sw[f], row[f], -so[f]); x = fma(dd, dd, x); }
     return x;
 }
 
@@ -144,11 +152,11 @@ template <> struct SRow<16> {
 
 // X = nb + chi^2 of a row held in scalar registers
 template <int NFP>
-__device__ __forceinline__ double srow_x(const SRow<NFP> &r, const double (&obs)[NFP], const double (&wgt)[NFP])
+__device__ __forceinline__ double srow_x(const SRow<NFP> &r, const double (&so)[NFP], const double (&sw)[NFP])
 {
     double x = r.nb;
 #pragma unroll
-    for (int f = 0; f < NFP; ++f) { const double dd = r.mag(f) - obs[f]; x = fma(wgt[f] * dd, dd, x); }
+    for (int f = 0; f < NFP; ++f) { const double dd = fma(sw[f], r.mag(f), -so[f]); x = fma(dd, dd, x); }
     return x;
 }
 
@@ -187,7 +195,7 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
 }
 
 // Waves per SIMD the instances are built for (tools/kernel_resources.py)
-#define B9_MARG_WAVES(NFP, NPOPS, SAMPLE) (((NFP) >= 16 || (SAMPLE)) ? 4 : 6)
+#define B9_MARG_WAVES(NFP, NPOPS, SAMPLE) (((NFP) >= 16 || (SAMPLE)) ? 4 : ((NPOPS) == 2 ? 6 : 7))
 
 // A workgroup = FOUR waves holding the SAME 64 stars; wave k takes sub-chunk k of every 64-node chunk (a quarter of every
 // star's window, wherever it lies) and the four partial log-sum-exps are merged through LDS at the end.  (With one wave
@@ -242,9 +250,9 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
         return;
     }
     const bool dead = orig < 0;
-    double obs[NFP], wgt[NFP];
+    double so[NFP], sw[NFP];                                       // the star, scaled: sqrt(w) obs, sqrt(w)
 #pragma unroll
-    for (int f = 0; f < NFP; ++f) { obs[f] = st.mg_obs[B9_SIDX(NFP, f, slot)]; wgt[f] = st.mg_w[B9_SIDX(NFP, f, slot)]; }
+    for (int f = 0; f < NFP; ++f) { so[f] = st.mg_so[B9_SIDX(NFP, f, slot)]; sw[f] = st.mg_sw[B9_SIDX(NFP, f, slot)]; }
     const double c0m = st.mg_c0m[slot], la = st.mg_la[slot];
     // the field floor (in the units of the terms: the star's constant c0m is added at the end)
     const double floor_t = (SAMPLE || !(cut2 < __builtin_inf())) ? NEG_INF : la - c0m;
@@ -262,7 +270,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
             const int n_units = (((iso_g[kp].n - 1) * K + 63) >> 6) * 4;
             double xmin = __builtin_inf();
             for (int u = wave; u < n_units; u += 4) {
-                const double x = row_x<NFP>(t_wp + L.o_rows + (size_t)u * Q * 16 * NFP, t_wp[L.o_nb + u * 16], obs, wgt);
+                const double x = row_x<NFP>(t_wp + L.o_rows + (size_t)u * Q * 16 * NFP, t_wp[L.o_nb + u * 16], so, sw);
                 xmin = __builtin_fmin(xmin, x);
             }
             if (!dead && tmax[kp] == NEG_INF) { ref[kp] = -0.5 * xmin; tmax[kp] = ref[kp]; }
@@ -278,7 +286,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
         const double xcut = fma(-2.0, tmax[kp], cut2);
         const int c_end = n_chunks < 64 * B9_MARG_MASK_WORDS ? n_chunks : 64 * B9_MARG_MASK_WORDS;
         for (int c = wave; c < c_end; c += 4) {
-            const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, obs, wgt);
+            const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, so, sw);
             MSTAT(0, 1);
             if (__ballot(lb1 + t_wp[L.o_nbmin64 + c] < xcut) != 0ull && lane == 0) atomicOr(&s_mask[kp][c >> 6], 1ull << (c & 63));
         }
@@ -308,7 +316,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
             bool any = false;
             for (int j = 0; j < Q; ++j) {
                 // level 2: this wave's 16 nodes x one mass ratio
-                const double lb2 = box_bound<NFP>(t_box2 + ((size_t)u * Q + j) * 2 * NFP, obs, wgt);
+                const double lb2 = box_bound<NFP>(t_box2 + ((size_t)u * Q + j) * 2 * NFP, so, sw);
                 MSTAT(2, 1);
                 if (__ballot(lb2 + nbm < xcut) == 0ull) continue;
                 MSTAT(3, 1);
@@ -317,7 +325,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                 const double *__restrict__ const rowp = t_rows + ((size_t)u * Q + j) * 16 * NFP;
                 // one row's term for every lane (the 64 stars), into the lanes that still count it
                 auto term = [&](const SRow<NFP> &r, int i) {
-                    const double x = srow_x<NFP>(r, obs, wgt);
+                    const double x = srow_x<NFP>(r, so, sw);
                     const bool live = x < xcut;
                     MSTAT_LIVE(4, live);
                     if (live) {
@@ -362,7 +370,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
             while (m) { const int c = wi * 64 + __builtin_ctzll(m); m &= m - 1; chunk(c); }
         }
         for (int c = 64 * B9_MARG_MASK_WORDS; c < n_chunks; ++c) {      // (tables longer than the mask: every wave tests)
-            const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, obs, wgt);
+            const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, so, sw);
             if (__ballot(lb1 + t_wp[L.o_nbmin64 + c] < fma(-2.0, tmax[kp], cut2)) != 0ull) chunk(c);
         }
         s_ref[kp][wave][lane] = ref[kp]; s_sm[kp][wave][lane] = sm[kp];
