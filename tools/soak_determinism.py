@@ -2,7 +2,7 @@
 """Soak: the device-resident sampler run twice from the same state gives bit-identical chains (fixed summation
 orders, counter-based RNG, no data-path atomics), over many blocks -- on the bench shape (one-step launch) and, with a
 shape argument, on the single-chain shapes (tree launch, WD stars, two populations) against the host twin's first block too.
-    soak_determinism.py [n_blocks] [C2|C1|C3|W2|P2]"""
+    soak_determinism.py [n_blocks] [C2|C1|C3|W2|P2|C4|C4W]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +10,8 @@ from base_amd import abi, engine, mcmc, synth
 n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 shape = sys.argv[2] if len(sys.argv) > 2 else "C2"
 pk, nf, ns, wd, ny, npops, W = {"C2": ("parsec", 8, 50000, 0.0, 1, 1, 8), "C1": ("dsed", 8, 10000, 0.0, 1, 1, 1), "C3": ("parsec", 8, 20000, 0.05, 1, 1, 1),
-                                 "W2": ("parsec", 8, 50000, 0.01, 1, 1, 2), "P2": ("parsec", 5, 6000, 0.03, 3, 2, 1)}[shape]
+                                 "W2": ("parsec", 8, 50000, 0.01, 1, 1, 2), "P2": ("parsec", 5, 6000, 0.03, 3, 2, 1),
+                                 "C4": ("parsec", 8, 30000, 0.0, 3, 2, 8), "C4W": ("parsec", 8, 30000, 0.02, 3, 2, 8)}[shape]
 pack_d = synth.make_pack(pk, nf, n_y=ny); truth = synth.default_params(pack_d)
 cl = synth.make_cluster(pack_d, ns, seed=9003, truth=truth, wd_frac=wd, n_pops=npops)
 eng = engine.Engine(abi.make_pack(pack_d), abi.make_stars(cl), synth.default_priors(pack_d, truth, npops), abi.make_options(n_pops=npops))
