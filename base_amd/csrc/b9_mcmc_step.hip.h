@@ -327,7 +327,7 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
             __syncthreads();
             return s_hsel;
         };
-        heavy_stars<NFP, NPOPS, 2>(pk, st, hd, is, sd.iso_stride, sd.mass_cap, pr2, decide, sd.has_prev != 0, w, part, heavy_parts, out, nullptr, smem);
+        heavy_stars<NFP, NPOPS, 2>(pk, st, hd, is, sd.iso_stride, sd.mass_cap, pr2, decide, w, part, heavy_parts, out, nullptr, smem);
         B9_MARK("heavy-end");
         return role;
     }

@@ -217,7 +217,7 @@ __device__ __forceinline__ void tree_heavy(const DevPack &pk, const DevStars &st
     const IsoHdr *const h1[1] = {td.cand_hdr + cb * NPOPS};
     const double *const i1[1] = {td.cand_iso + cb * NPOPS * td.iso_stride}, *const p1[1] = {td.cand_par + cb * B9_NPARAM};
     double *const o1[1] = {td.partial + (((size_t)td.set * W + w) * NN + n) * td.part_stride + (size_t)td.n_groups * 4 + part};
-    heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, td.iso_stride, td.mass_cap, p1, [] { return 0; }, false, 0, part, td.heavy_parts, o1, nullptr, smem);
+    heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, td.iso_stride, td.mass_cap, p1, [] { return 0; }, 0, part, td.heavy_parts, o1, nullptr, smem);
 }
 
 // ---- proposal bookkeeping shared by the writer and the derivation role ---------------------------------------------------

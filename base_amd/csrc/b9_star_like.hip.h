@@ -245,7 +245,7 @@ __device__ __forceinline__ void hot_groups(const DevPack &pk, const DevStars &st
 //     AGB-tip table, per (candidate, population) the mass column, per candidate the parameter row -- is requested at
 //     entry, segment by segment, all loads independent: one memory round trip (it used to be 6 + 4 NPOPS dependent ones).
 //   * It is short of REGISTERS (it wants ~190 VGPRs under the kernel's cap of 168): what the chain does not need until
-//     its end is requested there, and with one population the lane view lives in scalar registers.
+//     its end is requested there, and the lane view -- one candidate, one population per wave -- lives in scalar registers.
 // A star occupies a PAIR of neighbouring lanes (its two components: star_ll_lanes).  TWO POPULATIONS are two wave pairs:
 // waves 0-1 walk the chunks on population A's isochrone, waves 2-3 the SAME chunks on population B's, so a wave's lane view
 // is uniform (scalar registers) and a star between the two populations' AGB tips has its WD chain in one wave and its MS/RGB
@@ -254,7 +254,7 @@ __device__ __forceinline__ void hot_groups(const DevPack &pk, const DevStars &st
 template <int NFP, int NPOPS, int NC, class SelectFn>
 __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &st, const IsoHdr *const (&hdr)[NC],
                                             const double *const (&iso_data)[NC], long long iso_stride, int mass_cap,
-                                            const double *const (&params)[NC], SelectFn select, bool both_exist, int w, int part, int parts,
+                                            const double *const (&params)[NC], SelectFn select, int w, int part, int parts,
                                             double *const (&out_partial)[NC], double *__restrict__ perstar, double *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -364,7 +364,6 @@ __device__ __forceinline__ void heavy_stars(const DevPack &pk, const DevStars &s
     bool none[NC];                                                               // no star above the candidate's tip
 #pragma unroll
     for (int c = 0; c < NC; ++c) none[c] = !(m_first > tip_min[c]);
-    (void)both_exist;
     const int sel = NC == 2 ? select() : 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) if (c != sel) { valid[c] = false; tip_min[c] = __builtin_inf(); }
@@ -498,7 +497,7 @@ __global__ __launch_bounds__(256, B9_K1_WAVES(NFP, NPOPS)) void k_star_like(DevP
         const IsoHdr *const h1[1] = {hdr};
         const double *const i1[1] = {iso_data}, *const p1[1] = {params};
         double *const o1[1] = {partial + (size_t)w * partial_stride + (size_t)n_groups * 4 + part};
-        heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, iso_stride, mass_cap, p1, [] { return 0; }, false, w, part, heavy_parts, o1, perstar, smem);
+        heavy_stars<NFP, NPOPS, 1>(pk, st, h1, i1, iso_stride, mass_cap, p1, [] { return 0; }, w, part, heavy_parts, o1, perstar, smem);
         return;
     }
     // LDS: the mass column of each population's isochrone -- the bracket search runs in LDS (dependent ds_reads
