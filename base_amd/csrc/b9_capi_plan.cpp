@@ -21,10 +21,16 @@ int step_slots(b9_ctx *ctx, int n_pops)
 // group and wave -- the grouping fixes how a walker's log-posterior ROUNDS, so it must not depend on how many walkers share
 // the GPU (a chain is then the same bits on 1, 2, 4 or 8 ranks).  It is a function of the catalogue, the pack, the options
 // and the device only: the tiles per workgroup the fused step wants on the REFERENCE shape of 8 walkers per GPU -- the
-// smallest value that lets the hot workgroups fill <= 70 % of one occupancy round (measured on 50k stars x 8 filters x 8
-// walkers: 3 tiles per workgroup 21.8 us per step, 1 tile 26.0, 4 tiles 25.6).  b9_tuning.tiles_per_block pins it.
+// smallest value that lets the hot workgroups fill <= hot_fill of one occupancy round.  b9_tuning.tiles_per_block pins it.
 // A launch plan's only freedom is how many whole groups a workgroup takes.
 constexpr int kReferenceWalkers = 8;
+
+// Share of the resident-workgroup slots the hot workgroups may take.  One population: 0.7 (measured on 50k stars x 8 filters x
+// 8 walkers: 3 tiles per workgroup 21.8 us per step, 1 tile 26.0, 4 tiles 25.6).  Two populations: 0.85 -- a hot workgroup
+// covers half a tile per population, so the launch has twice the wave-evaluations to place and the fewer tiles per wave are
+// worth the crowding (30k stars x 2 populations x 8 walkers: 3 tiles 19.7 us per step, 4 tiles 20.8) now that the derivation
+// runs ahead of the decision and gets by with two parts.
+static double hot_fill(int n_pops) { return n_pops == 2 ? 0.85 : 0.7; }
 
 Groups make_groups(b9_ctx *ctx, int n_pops)
 {
@@ -34,7 +40,7 @@ Groups make_groups(b9_ctx *ctx, int n_pops)
         const int slots = step_slots(ctx, n_pops);
         g = 1;
         // (two populations: a hot workgroup covers half of every tile of its groups, once per population -- n_pops per block)
-        while (g < 8 && (long long)((n_tiles + g - 1) / g) * n_pops * kReferenceWalkers > (long long)(0.7 * slots)) ++g;
+        while (g < 8 && (long long)((n_tiles + g - 1) / g) * n_pops * kReferenceWalkers > (long long)(hot_fill(n_pops) * slots)) ++g;
     }
     g = std::max(1, std::min(g, std::max(1, n_tiles)));
     return Groups{g, (n_tiles + g - 1) / g};
@@ -71,7 +77,7 @@ StepPlan make_step_plan(b9_ctx *ctx, int n_walkers, int n_pops)
     const int full_parts = (ctx->mass_cap * (ctx->pk.nfp + 1) + 255) / 256;
     const int m_max = std::max(1, 8 / gr.group_tiles);
     int m = 1;
-    while (m < m_max && (long long)((gr.n_groups + m - 1) / m) * n_pops * n_walkers > (long long)(0.7 * slots)) ++m;
+    while (m < m_max && (long long)((gr.n_groups + m - 1) / m) * n_pops * n_walkers > (long long)(hot_fill(n_pops) * slots)) ++m;
     sp.plan = with_groups_per_block(gr, m);
     int parts = ctx->derive_parts;
     if (parts <= 0) {

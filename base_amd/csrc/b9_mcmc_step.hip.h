@@ -262,6 +262,100 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
                      sd.iso_stride, sd.mass_cap, part, parts, axr);
 }
 
+// Derivation role, running AHEAD of the decision (as the tree launch's does, b9_mcmc_tree.hip.h): the role's chain was
+// decision -> parameter row -> grid brackets -> corner rows -> table values, five dependent legs.  Only the workgroup's FIRST
+// wave takes the decision (its loads leave first), draws step t+1's normals and forms the candidate's parameter row; waves
+// 1-3 meanwhile bracket the grid cell of the PREVIOUS state (a candidate is that state plus at most two steps: almost always
+// the same cell), read its corner rows and the corner values of the workgroup's share into registers.  When the parameters
+// arrive only the interpolation weights, the lerps and the stores remain; a candidate that fell into another cell repeats
+// the two trips for its own.  Same draws, same sums, same interpolation as step_derive (the writer's and k_mcmc_finish's
+// path) and derive_iso_block: same bits.
+#define B9_STEP_KV 3          // output items per thread whose corner values are kept in registers at a time
+__device__ __forceinline__ void step_derive_ahead(const DevPack &pk, const StepDev &sd, int w, int cand, int pop, int part, int parts)
+{
+    if (!sd.derive_next) return;
+    const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers, n_pops = sd.n_pops;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ double s_par[B9_NPARAM], s_z[12];
+    const double *in = step_state_in(sd, w);
+    const size_t rows = (size_t)W * n_pops;
+    const size_t cset = (size_t)((sd.set ^ 1) * 2 + cand);
+    if (wave == 0) {
+        DecideLoads dl = {};
+        decide_issue<false>(sd, w, dl);
+        const double cur_v = tid < B9_NPARAM ? in[B9_ST_CUR + tid] : 0.0;
+        const double prev_prop_v = tid < B9_NPARAM ? in[B9_ST_PROP + tid] : 0.0;
+        const double pc0 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 0) * W + w) * B9_NPARAM + tid] : 0.0;
+        const double pc1 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 1) * W + w) * B9_NPARAM + tid] : 0.0;
+        double crow[11];
+#pragma unroll
+        for (int j = 0; j < 11; ++j) crow[j] = (tid < d && j < d) ? sd.chol[tid * d + j] : 0.0;
+        const int fidx = tid < d ? sd.free_idx[tid] : 0;
+        {   // the normals of step t+1 (Philox + Box-Muller), independent of every decision: while the decision's loads are in flight
+            const int n_pairs = (d + 1) >> 1;
+            if (tid < n_pairs) {
+                unsigned r[4];
+                const unsigned long long sn = sd.step + 1;
+                philox4x32((unsigned)sn, (unsigned)(sn >> 32), (unsigned)sd.walker_ids[w], (unsigned)tid, sd.k0, sd.k1, r);
+                const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+                const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+                s_z[2 * tid] = rad * cos(ang);
+                s_z[2 * tid + 1] = rad * sin(ang);
+            }
+        }
+        double lp_new = 0.0;
+        const bool ok = decide_finish<false>(sd, w, dl, lp_new);
+        // candidate `cand` of step t+1:  base = state after step t-1 (step t rejected) or step t's proposal (accepted);
+        // row[free[i]] += sum_j chol[i][j] z_j  (j ascending, plain multiply-add -- as the host twin does)
+        if (tid < B9_NPARAM) s_par[tid] = cand ? (ok ? pc1 : pc0) : (ok ? prev_prop_v : cur_v);
+        __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS accesses complete in program order)
+        double delta = 0.0;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) if (j < d) delta = delta + crow[j] * s_z[j];
+        if (tid < d) s_par[fidx] += delta;                   // (each lane owns one sampled parameter)
+        __syncthreads();
+        if (pop == 0 && part == 0 && tid < B9_NPARAM) sd.cand_par[(cset * W + w) * B9_NPARAM + tid] = s_par[tid];
+        return;
+    }
+    // ---- waves 1..3: the derivation, ahead for the previous state's cell ----
+    const int nfp = pk.nfp, mass_cap = sd.mass_cap, wp = w * n_pops + pop;
+    const int first = part * 192 + (tid - 64), stride = parts * 192;
+    AxisRegs ax[3];
+    preload_axes3(pk, ax);
+    const double g_age = in[B9_ST_CUR + B9_P_LOGAGE], g_feh = in[B9_ST_CUR + B9_P_FEH];
+    const double g_y = in[B9_ST_CUR + (pop ? B9_P_Y2 : B9_P_Y)];
+    GridCell cell = grid_cell(pk, ax, g_age, g_feh, g_y);
+    CornerRegs cr = corner_rows(pk, cell);
+    double v[B9_STEP_KV][8];
+    {
+        const int total = (cr.n >= 2 && cr.n <= mass_cap) ? cr.n * (nfp + 1) : 0;
+        corner_values<B9_STEP_KV>(pk, cr, total, first, stride, v);
+    }
+    __syncthreads();                                         // the candidate's parameters (first wave)
+    const double log_age = s_par[B9_P_LOGAGE], feh = s_par[B9_P_FEH], y = pop ? s_par[B9_P_Y2] : s_par[B9_P_Y];
+    const GridCell own = grid_cell(pk, ax, log_age, feh, y);
+    const bool same = own.i_age == cell.i_age && own.i_feh == cell.i_feh && own.i_y == cell.i_y;
+    if (!same) { cell = own; cr = corner_rows(pk, cell); }
+    const IsoHdr h = header_of(pk, cell, cr, log_age, feh, y, mass_cap);
+    IsoHdr *hp = sd.cand_hdr + cset * rows + wp;
+    if (part == 0 && tid == 64) {
+        // (agb_tip of a valid isochrone is stored by the thread that interpolates the last point's mass)
+        hp->valid = h.valid; hp->first_eep = h.first_eep; hp->n = h.n; hp->i_feh = h.i_feh; hp->i_y = h.i_y; hp->i_age = h.i_age;
+        hp->t_feh = h.t_feh; hp->t_y = h.t_y; hp->t_age = h.t_age;
+        if (!h.valid) hp->agb_tip = 0.0;
+    }
+    if (!h.valid) return;
+    const int total = h.n * (nfp + 1);
+    double *omass = sd.cand_iso + (cset * rows + wp) * sd.iso_stride;
+    double *omags = omass + mass_cap;
+    if (!same) corner_values<B9_STEP_KV>(pk, cr, total, first, stride, v);
+    store_values<B9_STEP_KV>(pk, h, total, first, stride, v, omass, omags, &hp->agb_tip);
+    for (int f = first + B9_STEP_KV * stride; f < total; f += B9_STEP_KV * stride) {        // (few derivation parts: more than KV items per thread)
+        corner_values<B9_STEP_KV>(pk, cr, total, f, stride, v);
+        store_values<B9_STEP_KV>(pk, h, total, f, stride, v, omass, omags, &hp->agb_tip);
+    }
+}
+
 // Grid: [one WRITER per walker][derivation workgroups][heavy-star workgroups][pad to 8][hot workgroups]
 // (B9_DERIVE_ORDER=0: heavy-star workgroups first; < 0: the derivation workgroups trail the grid instead).
 template <int NFP, int NPOPS>
@@ -334,7 +428,7 @@ __device__ __forceinline__ int step_body(const DevPack &pk, const DevStars &st, 
     if (role == 2) {       // b = ((w * 2 + cand) * NPOPS + pop) * derive_parts + part
         const int part = b % derive_parts; b /= derive_parts;
         const int pop = b % NPOPS; b /= NPOPS;
-        step_derive(pk, sd, pr, b >> 1, b & 1, pop, part, derive_parts, nullptr, 0);
+        step_derive_ahead(pk, sd, b >> 1, b & 1, pop, part, derive_parts);
     }
     // The WRITER of a walker (decision, new state, chain record) is a workgroup of its own: as part 0 of a derivation
     // it made that workgroup the launch's last (state + prior + log u before its share of the isochrone: 9.1 against
