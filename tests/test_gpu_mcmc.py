@@ -100,12 +100,13 @@ def test_fused_step_plans_all_give_the_same_chain(monkeypatch, env, n_steps):
     assert dev[4] + two[4] == one[4]
 
 
-@pytest.mark.parametrize("depth", ["2", "3"])
+@pytest.mark.parametrize("depth", ["1", "2", "3"])
 @pytest.mark.parametrize("n_pops,n_y", [(1, 1), (2, 3)])
 def test_tree_candidates_in_other_grid_cells(monkeypatch, depth, n_pops, n_y):
-    """The tree launch's derivation role reads its tables AHEAD for the grid cell of the previous state; walkers that
-    sit on cell borders (age, FeH, Y) and take steps of a cell's size put many candidates in another cell, which then
-    repeat the reads for their own: the chain is the host twin's either way."""
+    """The derivation role -- of the tree launch (depth 2, 3) and of the one-step fused launch (depth 1:
+    step_derive_ahead) -- reads its tables AHEAD for the grid cell of the previous state; walkers that sit on cell borders
+    (age, FeH, Y) and take steps of a cell's size put many candidates in another cell, which then repeat the reads for
+    their own: the chain is the host twin's either way."""
     from base_amd import engine
     monkeypatch.setenv("B9_TREE_DEPTH", depth)
     pack_d, cl, pack, stars, priors, options = build_problem("dsed", 5, n_stars=1500, wd_frac=0.02, n_y=n_y, n_pops=n_pops, small=False, seed=5)
