@@ -127,6 +127,11 @@ def test_settings_yaml_and_flag_override(hostlib, tmp_path):
     assert float(kv["general.cluster.starting.logAge"]) == cl["truth"][abi.P_LOGAGE]
     args = [b"prog", b"--noSuchFlag", b"1"]
     assert hostlib.b9h_settings_dump(2, (C.c_char_p * 3)(*args), out, 8192) != 0
+    # the value-less switches of this build: --resComment (the provenance note inside the .res too), --forceRanks, --marginalise
+    args = [b"prog", b"--resComment", b"--forceRanks", b"--marginalise", b"--walkers", b"4"]
+    assert hostlib.b9h_settings_dump(len(args), (C.c_char_p * len(args))(*args), out, 8192) == 0, hostlib.b9h_last_error()
+    kv = dict(l.split(" = ", 1) for l in out.value.decode().strip().split("\n"))
+    assert kv["gpu.resComment"] == "1" and kv["gpu.forceRanks"] == "1" and kv["gpu.marginalise"] == "1" and kv["gpu.walkers"] == "4"
 
 
 def _cli(name, *args):
