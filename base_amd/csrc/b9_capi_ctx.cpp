@@ -65,6 +65,13 @@ int ensure_marg_table(b9_ctx *ctx, int n_walkers, int n_pops, int K, int Q)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_marg_tab, need * sizeof(double)));
         ctx->marg_tab_cap = need;
     }
+    const size_t need_wd = (size_t)n_walkers * n_pops * (size_t)b9k_marg_wd_table_doubles(ctx->pk.nfp, K);
+    if (need_wd > ctx->marg_wd_tab_cap) {
+        if (ctx->d_marg_wd_tab) (void)hipFree(ctx->d_marg_wd_tab);
+        ctx->d_marg_wd_tab = nullptr; ctx->marg_wd_tab_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_marg_wd_tab, need_wd * sizeof(double)));
+        ctx->marg_wd_tab_cap = need_wd;
+    }
     return B9_OK;
 }
 
@@ -165,7 +172,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx->pack_allocs);
     free_all(ctx->star_allocs);
-    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_marg_tab,
+    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_marg_tab, ctx->d_marg_wd_tab,
                     ctx->d_tree_hdr, ctx->d_tree_iso, ctx->d_tree_par, ctx->d_tree_partial};
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (auto &sl : ctx->slot) {

@@ -59,6 +59,8 @@ struct b9_ctx {
     size_t perstar_cap = 0;
     double *d_marg_tab = nullptr;    // marginalised mode: the companions' flux table of the current call (k_marg_table)
     size_t marg_tab_cap = 0;
+    double *d_marg_wd_tab = nullptr; // ... and the WD-stage stars' node table (k_marg_wd_table)
+    size_t marg_wd_tab_cap = 0;
     struct McmcSlot {                // fused step: one enqueued block (device block, pinned mirror, completion event)
         void *d = nullptr, *h = nullptr, *h_dev = nullptr;   // h_dev: the pinned mirror as the device sees it (mapped)
         size_t cap = 0, hcap = 0;

@@ -180,12 +180,13 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
 
 // doubles of one (walker, population)'s node table (MargLayout, b9_device.h)
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q) { return marg_layout(nfp, mass_cap, K, Q).total; }
+long long b9k_marg_wd_table_doubles(int nfp, int K) { return (long long)8 * K * (2 * nfp + 1); }       // per (walker, population)
 
 template <int NFP, int NPOPS, bool SAMPLE>
 static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                      long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
                                      double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune,
-                                     double *tab, hipStream_t stream)
+                                     double *tab, double *wd_tab, hipStream_t stream)
 {
     MargSample ms{};
     if (SAMPLE) { ms.mass = smp->mass; ms.ratio = smp->ratio; ms.member = smp->member; ms.pop = smp->pop; ms.k0 = smp->k0; ms.k1 = smp->k1; ms.row0 = smp->row0; }
@@ -211,26 +212,30 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
     hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
                        mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit);
-    if (st.n_wd > 0)          // the catalogue's WD-stage stars: their own (register-hungry) kernel, beside the main one's tail
+    if (st.n_wd > 0) {        // the catalogue's WD-stage stars: their node table (2 x 8 K WD chains per walker and population), then a wave per star
+        if (!wd_tab) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_marg_wd_table<NFP>), dim3(n_walkers * NPOPS, (8 * K + 63) / 64), dim3(128), 0, stream, pk, hdr, iso_data, iso_stride,
+                           mass_cap, NPOPS, d_params, K, wd_tab, n_walkers * NPOPS);
         hipLaunchKernelGGL((k_star_marg_wd<NFP, NPOPS, SAMPLE>), dim3((st.n_wd + 3) / 4, n_walkers), dim3(256), 0, stream, pk, st, hdr,
-                           iso_data, iso_stride, mass_cap, d_params, partial, partial_stride, perstar, K, ms);
+                           iso_data, iso_stride, mass_cap, d_params, partial, partial_stride, perstar, K, ms, wd_tab);
+    }
     return hipGetLastError();
 }
 
 template <int NFP, int NPOPS>
 static hipError_t launch_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                    long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                   double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, hipStream_t stream)
+                                   double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, double *wd_tab, hipStream_t stream)
 {
-    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, stream)
-               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, stream);
+    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, stream)
+               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, stream);
 }
 
 hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
-                         double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, hipStream_t stream)
+                         double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, double *wd_tab, hipStream_t stream)
 {
-#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, stream
+#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, stream
 #define SM2(NFP) launch_star_marg<NFP, 2>(SM_ARGS)
 #define SM1(NFP) launch_star_marg<NFP, 1>(SM_ARGS)
     B9_SWITCH_NFP(SM2, SM1)

@@ -47,8 +47,11 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
                          double *partial /* per walker: one sum per 64-star chunk, then one value per WD-stage star */, long long partial_stride,
                          double *perstar, int K, int Q, const B9MargSample *smp, bool prune /* false: every node of every star is evaluated */,
-                         double *tab /* the call's node table: n_walkers * n_pops * b9k_marg_table_doubles(nfp, mass_cap, K, Q) doubles */, hipStream_t stream);
+                         double *tab /* the call's node table: n_walkers * n_pops * b9k_marg_table_doubles(nfp, mass_cap, K, Q) doubles */,
+                         double *wd_tab /* the WD-stage stars' node table: n_walkers * n_pops * b9k_marg_wd_table_doubles(nfp, K) doubles (used when the catalogue has WD-stage stars) */,
+                         hipStream_t stream);
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q);
+long long b9k_marg_wd_table_doubles(int nfp, int K);
 
 // fused sampler step (given-mass mode): decision of step t-1 + stars of step t + candidates of step t+1
 // (tiles_per_block < 0: a workgroup's |tiles_per_block| tiles are strided n_groups apart instead of consecutive)

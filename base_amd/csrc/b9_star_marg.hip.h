@@ -525,8 +525,8 @@ __global__ __launch_bounds__(256) void k_marg_table(DevPack pk, const IsoHdr *__
 
 // ------------------------------------------------------------------------------------------
 // k_star_marg_wd: the WD-stage stars of the marginalised mode, one wavefront per (walker, star): lanes stride over
-// the 8 iso_increm primary-mass steps in (AGB tip, M_wd_up], each through the general WD branch (IFMR -> cooling
-// -> atmosphere); online log-sum-exp per lane, wavefront-shuffle merge.  Grid: (ceil(n_wd / 4), walkers).
+// the 8 iso_increm primary-mass steps in (AGB tip, M_wd_up], whose magnitudes k_marg_wd_table has tabulated per
+// (walker, population, DA / DB); online log-sum-exp per lane, wavefront-shuffle merge.  Grid: (ceil(n_wd / 4), walkers).
 // ------------------------------------------------------------------------------------------
 struct Lse { double mx, sm; };      // online log-sum-exp:  value = mx + log(sm)
 __device__ __forceinline__ void lse_add(Lse &a, double x)
@@ -546,15 +546,52 @@ __device__ __forceinline__ Lse lse_merge(Lse a, Lse b)
     return r;
 }
 
+// The WD-stage stars' node table.  Nothing about a node of THEIR integral depends on the star either: the magnitudes of a white
+// dwarf of ZAMS mass m1_j = tip + j dM (j = 1 .. 8 K) under a walker's parameters depend on (walker, population, j, DA / DB)
+// only -- so the WD chain (IFMR -> cooling tracks -> atmosphere) runs 2 x 8 K times per (walker, population) here instead of
+// 8 K times per STAR and walker in k_star_marg_wd (a thousand WD-stage stars: 500 x fewer chains).  Rows hold the apparent
+// magnitudes (modulus and absorption added, as the star loop formed them); lpm the mass prior of the node.
+//   wtab = rows[wp][type][8 K][NFP] | lpm[wp][8 K]          grid (walkers * pops, ceil(8 K / 64)) x 128 threads (type = wave)
+template <int NFP>
+__global__ __launch_bounds__(128) void k_marg_wd_table(DevPack pk, const IsoHdr *__restrict__ hdr, const double *__restrict__ iso_data,
+                                                       long long iso_stride, int mass_cap, int n_pops, const double *__restrict__ params,
+                                                       int K, double *__restrict__ wtab, int n_wp)
+{
+    const int wp = blockIdx.x, w = wp / n_pops, type = threadIdx.x >> 6, steps = 8 * K;
+    const int j = 1 + blockIdx.y * 64 + (threadIdx.x & 63);
+    const IsoHdr h = hdr[wp];
+    if (!h.valid) return;
+    IsoView<NFP> is;
+    is.n = h.n; is.tip = h.agb_tip; is.i_feh = h.i_feh; is.i_y = h.i_y; is.t_feh = h.t_feh; is.t_y = h.t_y;
+    is.mass = iso_data + (size_t)wp * iso_stride; is.mags = is.mass + mass_cap;
+    const double *par = params + (size_t)w * B9_NPARAM;
+    const double dM = (pk.m_wd_up - is.tip) / steps;
+    if (!(dM > 0.0) || j > steps) return;
+    WdAxes ax;
+    ax.log_age = pk.log_age;
+    const int ny = pk.n_y > 1 ? 2 : 1;
+    for (int df = 0; df < 2; ++df) for (int dy = 0; dy < 2; ++dy)
+        ax.tips[df * 2 + dy] = pk.tips + (size_t)((is.i_feh + df) * pk.n_y + (is.i_y + (dy < ny ? dy : 0))) * pk.n_age;
+    ax.wc_log_age_lds = nullptr; ax.wc_track = pk.wc_track; ax.wc_mass = pk.wc_mass; ax.wc_carb = pk.wc_carb;
+    ax.at_log_teff = pk.at_log_teff; ax.at_logg = pk.at_logg;
+    const double m1 = is.tip + dM * j, mod = par[B9_P_MOD], av = par[B9_P_ABS];
+    double p[NFP];
+    star_mags<NFP>(pk, ax, is, par, m1, type, p);
+    double *row = wtab + (((size_t)wp * 2 + type) * steps + (j - 1)) * NFP;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) row[f] = p[f] + (mod + pk.abs_m1[f] * av);
+    if (type == 0) wtab[(size_t)n_wp * 2 * steps * NFP + (size_t)wp * steps + (j - 1)] = log_prior_mass_dev(pk.log_mass_norm, m1);
+}
+
 template <int NFP, int NPOPS, bool SAMPLE>
 __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                                                       const double *__restrict__ iso_data, long long iso_stride,
                                                       int mass_cap, const double *__restrict__ params,
                                                       double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
-                                                      int K, MargSample ms)
+                                                      int K, MargSample ms, const double *__restrict__ wtab)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), w = blockIdx.y;
-    const int k_wd = blockIdx.x * 4 + wave;
+    const int k_wd = blockIdx.x * 4 + wave, n_wp = gridDim.y * NPOPS;
     if (k_wd >= st.n_wd) return;
     const int slot = st.wd_slot[k_wd], orig = st.perm[slot];
     const double *par = params + (size_t)w * B9_NPARAM;
@@ -565,10 +602,9 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
         if (lane == 0) { partial[(size_t)w * partial_stride + (st.mg_pad >> 6) + k_wd] = 0.0; if (perstar) perstar[(size_t)w * st.n + orig] = NEG_INF; }
         return;
     }
-    double obs[NFP], wgt[NFP], shift[NFP];
-    const double mod = par[B9_P_MOD], av = par[B9_P_ABS];
+    double obs[NFP], wgt[NFP];
 #pragma unroll
-    for (int f = 0; f < NFP; ++f) { obs[f] = st.obs[B9_SIDX(NFP, f, slot)]; wgt[f] = st.w[B9_SIDX(NFP, f, slot)]; shift[f] = mod + pk.abs_m1[f] * av; }
+    for (int f = 0; f < NFP; ++f) { obs[f] = st.obs[B9_SIDX(NFP, f, slot)]; wgt[f] = st.w[B9_SIDX(NFP, f, slot)]; }
     const double c0m = st.c0m[slot], la = st.la[slot];
     const int wd_type = st.flags[slot] & 1;
     double ll[NPOPS];
@@ -580,28 +616,22 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
     for (int kp = 0; kp < NPOPS; ++kp) {
         const IsoView<NFP> &is = iso[kp];
         Lse acc; acc.mx = NEG_INF; acc.sm = 0.0;
-        WdAxes ax;
-        ax.log_age = pk.log_age;
-        const int ny = pk.n_y > 1 ? 2 : 1;
-        for (int df = 0; df < 2; ++df) for (int dy = 0; dy < 2; ++dy)
-            ax.tips[df * 2 + dy] = pk.tips + (size_t)((is.i_feh + df) * pk.n_y + (is.i_y + (dy < ny ? dy : 0))) * pk.n_age;
-        ax.wc_log_age_lds = nullptr; ax.wc_track = pk.wc_track; ax.wc_mass = pk.wc_mass; ax.wc_carb = pk.wc_carb;
-        ax.at_log_teff = pk.at_log_teff; ax.at_logg = pk.at_logg;
-        const int steps = 8 * K;
+        const int steps = 8 * K, wp = w * NPOPS + kp;
         const double dM = (pk.m_wd_up - is.tip) / steps;
         if (dM > 0.0) {
             const double log_w = log(dM);
+            const double *__restrict__ const rows = wtab + (((size_t)wp * 2 + wd_type) * steps) * NFP;      // k_marg_wd_table's
+            const double *__restrict__ const lpm = wtab + (size_t)n_wp * 2 * steps * NFP + (size_t)wp * steps;
             for (int j = 1 + lane; j <= steps; j += 64) {
-                const double m1 = is.tip + dM * j;
-                double p[NFP];
-                star_mags<NFP>(pk, ax, is, par, m1, wd_type, p);
+                const double *__restrict__ const r = rows + (size_t)(j - 1) * NFP;
                 double chi2 = 0.0;
 #pragma unroll
-                for (int f = 0; f < NFP; ++f) { const double d = (p[f] + shift[f]) - obs[f]; chi2 = fma(wgt[f] * d, d, chi2); }
+                for (int f = 0; f < NFP; ++f) { const double d = r[f] - obs[f]; chi2 = fma(wgt[f] * d, d, chi2); }
                 if (isfinite(chi2)) {
-                    const double term = (log_prior_mass_dev(pk.log_mass_norm, m1) - 0.5 * chi2) + log_w;
+                    const double term = (lpm[j - 1] - 0.5 * chi2) + log_w;
                     lse_add(acc, term);
                     if (SAMPLE) {
+                        const double m1 = is.tip + dM * j;
                         const double key_ = term + lw_pop[kp] + gumbel(ms.k0, ms.k1, g_row, (unsigned)orig, (unsigned long long)j, (unsigned)kp);
                         if (key_ > best.key) { best.key = key_; best.mass = m1; best.ratio = 0.0; best.pop = kp; }
                     }
