@@ -72,6 +72,13 @@ int ensure_marg_table(b9_ctx *ctx, int n_walkers, int n_pops, int K, int Q)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_marg_wd_tab, need_wd * sizeof(double)));
         ctx->marg_wd_tab_cap = need_wd;
     }
+    const size_t need_sh = (size_t)n_walkers * (size_t)b9k_marg_shares_doubles(ctx->st.mg_pad / 64, n_pops);
+    if (need_sh > ctx->marg_shares_cap) {
+        if (ctx->d_marg_shares) (void)hipFree(ctx->d_marg_shares);
+        ctx->d_marg_shares = nullptr; ctx->marg_shares_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_marg_shares, need_sh * sizeof(double)));
+        ctx->marg_shares_cap = need_sh;
+    }
     return B9_OK;
 }
 
@@ -172,7 +179,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx->pack_allocs);
     free_all(ctx->star_allocs);
-    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_marg_tab, ctx->d_marg_wd_tab,
+    void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_marg_tab, ctx->d_marg_wd_tab, ctx->d_marg_shares,
                     ctx->d_tree_hdr, ctx->d_tree_iso, ctx->d_tree_par, ctx->d_tree_partial};
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (auto &sl : ctx->slot) {

@@ -50,7 +50,7 @@ int launch_stars(b9_ctx *ctx, const Bufs &bf, int32_t n_walkers, double *d_perst
         const int rc = ensure_marg_table(ctx, n_walkers, n_pops, K, Q);
         if (rc) return rc;
         HIPCHK(ctx, b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
-                                  n_walkers, n_pops, ctx->d_partial, partial_stride(ctx), d_perstar, K, Q, nullptr, ctx->marg_prune, ctx->d_marg_tab, ctx->d_marg_wd_tab, stream));
+                                  n_walkers, n_pops, ctx->d_partial, partial_stride(ctx), d_perstar, K, Q, nullptr, ctx->marg_prune, ctx->d_marg_tab, ctx->d_marg_wd_tab, ctx->d_marg_shares, stream));
     } else {
         HIPCHK(ctx, b9k_star_like(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params,
                                   n_walkers, n_pops, ctx->d_partial, partial_stride(ctx), d_perstar, plan, ctx->heavy_parts, stream));
@@ -173,7 +173,7 @@ int b9_sample_mass(b9_ctx *ctx, const double *params, int32_t n_rows, uint64_t s
         B9MargSample smp{d_out, d_out + per, d_out + 2 * per, d_pop, (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), (long long)(row0 + r0)};
         // the kernel indexes its outputs [row][n_stars] with the launch's own row count: rows are contiguous for any m
         if (e == hipSuccess) e = b9k_star_marg(ctx->pk, ctx->st, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params, m, n_pops,
-                                               ctx->d_partial, partial_stride(ctx), nullptr, K, Q, &smp, ctx->marg_prune, ctx->d_marg_tab, ctx->d_marg_wd_tab, s);
+                                               ctx->d_partial, partial_stride(ctx), nullptr, K, Q, &smp, ctx->marg_prune, ctx->d_marg_tab, ctx->d_marg_wd_tab, ctx->d_marg_shares, s);
         const size_t cnt = (size_t)m * n, o = (size_t)r0 * n;
         if (e == hipSuccess) e = hipMemcpyAsync(out_mass + o, d_out, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(out_ratio + o, d_out + per, sizeof(double) * cnt, hipMemcpyDeviceToHost, s);

@@ -61,6 +61,8 @@ struct b9_ctx {
     size_t marg_tab_cap = 0;
     double *d_marg_wd_tab = nullptr; // ... and the WD-stage stars' node table (k_marg_wd_table)
     size_t marg_wd_tab_cap = 0;
+    double *d_marg_shares = nullptr; // ... and the per-star shares of a split k_star_marg launch (small catalogues)
+    size_t marg_shares_cap = 0;
     struct McmcSlot {                // fused step: one enqueued block (device block, pinned mirror, completion event)
         void *d = nullptr, *h = nullptr, *h_dev = nullptr;   // h_dev: the pinned mirror as the device sees it (mapped)
         size_t cap = 0, hcap = 0;

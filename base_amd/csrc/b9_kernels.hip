@@ -180,13 +180,23 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
 
 // doubles of one (walker, population)'s node table (MargLayout, b9_device.h)
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q) { return marg_layout(nfp, mass_cap, K, Q).total; }
+// workgroups per (star chunk, walker) of k_star_marg by catalogue size (star chunks x populations): 1 from 512 up (32k stars of
+// one population), 4 from 128, 8 from 32, else 16.  Measured, ms per b9_logpost call unsplit -> split: 10k stars x 1 walker
+// 0.18 -> 0.08 (8 x 8 grid: 0.47 -> 0.18), 200 stars 0.14 -> 0.06, 20k x 8 walkers 0.21 -> 0.19, 10k x 8 walkers 0.11;
+// 30k x 2 populations x 8 walkers would lose (0.27 -> 0.37: 938 chunk-populations, left unsplit).
+int b9k_marg_split(int n_star_chunks, int n_pops)
+{
+    const int eff = n_star_chunks * n_pops;
+    return eff >= 512 ? 1 : (eff >= 128 ? 4 : (eff >= 32 ? 8 : 16));
+}
+long long b9k_marg_shares_doubles(int n_star_chunks, int n_pops) { return (long long)n_star_chunks * b9k_marg_split(n_star_chunks, n_pops) * n_pops * 128; }   // per walker
 long long b9k_marg_wd_table_doubles(int nfp, int K) { return (long long)8 * K * (2 * nfp + 1); }       // per (walker, population)
 
 template <int NFP, int NPOPS, bool SAMPLE>
 static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                      long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
                                      double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune,
-                                     double *tab, double *wd_tab, hipStream_t stream)
+                                     double *tab, double *wd_tab, double *shares, hipStream_t stream)
 {
     MargSample ms{};
     if (SAMPLE) { ms.mass = smp->mass; ms.ratio = smp->ratio; ms.member = smp->member; ms.pop = smp->pop; ms.k0 = smp->k0; ms.k1 = smp->k1; ms.row0 = smp->row0; }
@@ -208,10 +218,23 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     // same for all three: 164 us -- the kernel is VALU-bound, the placement only decides how much crosses the fabric)
     const int wsplit = n_walkers % 2 == 0 ? 2 : 1;
     const int csplit = 8 / wsplit, n_chunks = st.mg_pad / 64;
-    const int per_xcd = ((n_chunks + csplit - 1) / csplit) * (n_walkers / wsplit);
+    // SPLIT: a small catalogue's launch lasts as long as its heaviest star chunk (giants: 100 us where the median chunk takes
+    // 40) while most of the chip idles, so n_split workgroups share a chunk's window (k_star_marg / k_marg_merge).  A function
+    // of the CATALOGUE only -- it decides how a star's sum rounds, and a walker's chain must not depend on how many walkers
+    // share the GPU.  The sampleMass draws keep one workgroup per chunk.
+    const int n_split = SAMPLE ? 1 : b9k_marg_split(n_chunks, NPOPS);
+    if (n_split > 1 && !shares) return hipErrorInvalidValue;
+    const int per_xcd = ((n_chunks + csplit - 1) / csplit) * (n_walkers / wsplit) * n_split;
     const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
-    hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
-                       mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit);
+    if (n_split > 1)
+        hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, !SAMPLE>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
+                           mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, n_split, shares);
+    else
+        hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, false>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
+                           mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, 1, shares);
+    if (n_split > 1)
+        hipLaunchKernelGGL((k_marg_merge<NPOPS>), dim3(n_chunks, n_walkers), dim3(64), 0, stream, st, hdr, d_params, partial, partial_stride,
+                           perstar, shares, n_split);
     if (st.n_wd > 0) {        // the catalogue's WD-stage stars: their node table (2 x 8 K WD chains per walker and population), then a wave per star
         if (!wd_tab) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_marg_wd_table<NFP>), dim3(n_walkers * NPOPS, (8 * K + 63) / 64), dim3(128), 0, stream, pk, hdr, iso_data, iso_stride,
@@ -225,17 +248,17 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
 template <int NFP, int NPOPS>
 static hipError_t launch_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                    long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
-                                   double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, double *wd_tab, hipStream_t stream)
+                                   double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, double *wd_tab, double *shares, hipStream_t stream)
 {
-    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, stream)
-               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, stream);
+    return smp ? launch_star_marg_t<NFP, NPOPS, true>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, shares, stream)
+               : launch_star_marg_t<NFP, NPOPS, false>(pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, shares, stream);
 }
 
 hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                          long long iso_stride, int mass_cap, const double *d_params, int n_walkers, int n_pops,
-                         double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, double *wd_tab, hipStream_t stream)
+                         double *partial, long long partial_stride, double *perstar, int K, int Q, const B9MargSample *smp, bool prune, double *tab, double *wd_tab, double *shares, hipStream_t stream)
 {
-#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, stream
+#define SM_ARGS pk, st, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, partial, partial_stride, perstar, K, Q, smp, prune, tab, wd_tab, shares, stream
 #define SM2(NFP) launch_star_marg<NFP, 2>(SM_ARGS)
 #define SM1(NFP) launch_star_marg<NFP, 1>(SM_ARGS)
     B9_SWITCH_NFP(SM2, SM1)

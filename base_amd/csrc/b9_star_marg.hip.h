@@ -206,15 +206,16 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
 // dealt over the waves too (wave k tests chunks k, k + 4, ...) and the outcome travels as a bit mask in LDS.
 #define B9_MARG_MASK_WORDS 16        // level-1 outcomes of up to 1024 chunks go through the mask; later chunks are tested by every wave
 
-template <int NFP, int NPOPS, bool SAMPLE>
+template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT>
 __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE))
 void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                  const double *__restrict__ iso_data, long long iso_stride,
                  int mass_cap, const double *__restrict__ params,
                  double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
                  int K, int Q, MargSample ms, const double *__restrict__ tab, MargLayout L,
-                 int n_walkers, double cut2, int wsplit)
+                 int n_walkers, double cut2, int wsplit, int n_split_arg, double *__restrict__ shares)
 {
+    const int n_split = SPLIT ? n_split_arg : 1;          // (a compile-time 1 in the unsplit instance: its code is the one-workgroup kernel's)
     __shared__ double s_tmax[NPOPS][4][64], s_ref[NPOPS][4][64], s_sm[NPOPS][4][64];
     __shared__ unsigned long long s_mask[NPOPS][B9_MARG_MASK_WORDS];
     __shared__ double s_bkey[SAMPLE ? 4 : 1][64], s_bmass[SAMPLE ? 4 : 1][64], s_bratio[SAMPLE ? 4 : 1][64];
@@ -231,7 +232,11 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     const int xcd = blockIdx.x & 7, i_x = blockIdx.x >> 3;
     const int csplit = 8 / wsplit, wg_n = n_walkers / wsplit;           // chunk groups; walkers per group
     const int a = xcd % wsplit, b = xcd / wsplit;
-    const int p_local = i_x / wg_n, wl = i_x - p_local * wg_n;
+    // SPLIT (small catalogues, b9k_star_marg): n_split workgroups share one (star chunk, walker) -- workgroup s takes the node
+    // chunks c = s, s + n_split, ... of every star's window and leaves its per-star share (ref, sum) in `shares` for
+    // k_marg_merge; the splits of a chunk are neighbours in dispatch order on one XCD.
+    const int i_s = i_x / n_split, split = i_x - i_s * n_split;
+    const int p_local = i_s / wg_n, wl = i_s - p_local * wg_n;
     const int w = wl * wsplit + a;
     const int pos = p_local * csplit + b;
     if (pos * 64 >= st.mg_pad) return;
@@ -243,7 +248,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso_g, tip_min);
     const int orig = st.mg_perm[slot];
     if (!valid) {
-        if (wave == 0) {
+        if (wave == 0 && split == 0) {
             if (lane == 0) partial[(size_t)w * partial_stride + sc] = 0.0;
             if (perstar && orig >= 0) perstar[(size_t)w * st.n + orig] = NEG_INF;
         }
@@ -269,9 +274,30 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
             const double *__restrict__ const t_wp = tab + (size_t)(w * NPOPS + kp) * L.total;
             const int n_units = (((iso_g[kp].n - 1) * K + 63) >> 6) * 4;
             double xmin = __builtin_inf();
-            for (int u = wave; u < n_units; u += 4) {
-                const double x = row_x<NFP>(t_wp + L.o_rows + (size_t)u * Q * 16 * NFP, t_wp[L.o_nb + u * 16], so, sw);
-                xmin = __builtin_fmin(xmin, x);
+            if constexpr (SPLIT) {
+                // (rows requested one ahead, as in the main loop: a row's L2 trip hides behind its predecessor's chi^2 -- one exposed
+                //  trip per row made this pass 12 us of a split workgroup's life; units past the end re-read the last one)
+                auto srow = [&](int u) { const int uu = u < n_units ? u : n_units - 1; return t_wp + L.o_rows + (size_t)uu * Q * 16 * NFP; };
+                auto snb = [&](int u) { const int uu = u < n_units ? u : n_units - 1; return t_wp + L.o_nb + uu * 16; };
+                SRow<NFP> ra, rb;
+                ra.load(srow(wave), snb(wave));
+                ra.wait();
+    #pragma unroll 1
+                for (int u = wave; u < n_units; u += 8) {
+                    rb.load(srow(u + 4), snb(u + 4));
+                    __builtin_amdgcn_sched_barrier(0);
+                    xmin = __builtin_fmin(xmin, srow_x<NFP>(ra, so, sw));
+                    rb.wait();
+                    ra.load(srow(u + 8), snb(u + 8));
+                    __builtin_amdgcn_sched_barrier(0);
+                    xmin = __builtin_fmin(xmin, srow_x<NFP>(rb, so, sw));
+                    ra.wait();
+                }
+            } else {
+                for (int u = wave; u < n_units; u += 4) {
+                    const double x = row_x<NFP>(t_wp + L.o_rows + (size_t)u * Q * 16 * NFP, t_wp[L.o_nb + u * 16], so, sw);
+                    xmin = __builtin_fmin(xmin, x);
+                }
             }
             if (!dead && tmax[kp] == NEG_INF) { ref[kp] = -0.5 * xmin; tmax[kp] = ref[kp]; }
         }
@@ -285,7 +311,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
         tmax[kp] = __builtin_fmax(__builtin_fmax(tmax[kp], s_tmax[kp][0][lane]), __builtin_fmax(s_tmax[kp][1][lane], __builtin_fmax(s_tmax[kp][2][lane], s_tmax[kp][3][lane])));
         const double xcut = fma(-2.0, tmax[kp], cut2);
         const int c_end = n_chunks < 64 * B9_MARG_MASK_WORDS ? n_chunks : 64 * B9_MARG_MASK_WORDS;
-        for (int c = wave; c < c_end; c += 4) {
+        for (int c = split + n_split * wave; c < c_end; c += 4 * n_split) {          // (this workgroup's node chunks, dealt over its waves)
             const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, so, sw);
             MSTAT(0, 1);
             if (__ballot(lb1 + t_wp[L.o_nbmin64 + c] < xcut) != 0ull && lane == 0) atomicOr(&s_mask[kp][c >> 6], 1ull << (c & 63));
@@ -369,7 +395,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
             m = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)m);
             while (m) { const int c = wi * 64 + __builtin_ctzll(m); m &= m - 1; chunk(c); }
         }
-        for (int c = 64 * B9_MARG_MASK_WORDS; c < n_chunks; ++c) {      // (tables longer than the mask: every wave tests)
+        for (int c = 64 * B9_MARG_MASK_WORDS + split; c < n_chunks; c += n_split) {      // (tables longer than the mask: every wave tests)
             const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, so, sw);
             if (__ballot(lb1 + t_wp[L.o_nbmin64 + c] < fma(-2.0, tmax[kp], cut2)) != 0ull) chunk(c);
         }
@@ -388,8 +414,13 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
         double S = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) S += (s_sm[kp][k][lane] > 0.0) ? s_sm[kp][k][lane] * exp_fast(s_ref[kp][k][lane] - r) : 0.0;
+        if (n_split > 1) {                              // this workgroup's share of the star's sum: merged by k_marg_merge
+            double *sh = shares + ((((size_t)w * (st.mg_pad >> 6) + sc) * n_split + split) * NPOPS + kp) * 128;
+            sh[lane] = r; sh[64 + lane] = S;
+        }
         ll[kp] = (S > 0.0) ? c0m + (r + log(S)) : NEG_INF;
     }
+    if (n_split > 1) return;
     double v = 0.0;
     if (!dead) {
         double l = ll[0];
@@ -412,6 +443,49 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     const double tot = wave_sum(v);
     if (lane == 0) partial[(size_t)w * partial_stride + sc] = tot;
     MLIFE(1, __builtin_amdgcn_s_memrealtime());
+}
+
+// k_marg_merge: the stars of a SPLIT launch -- one wave per (star chunk, walker), lane = star: the n_split shares (ref, sum) of
+// every star merged in the order of the splits (the wave-0 merge of k_star_marg, continued), the star finished (mass-prior
+// constant, populations, field-star mixture) and the chunk's partial sum formed: what k_star_marg's last wave does when one
+// workgroup holds the whole window.
+template <int NPOPS>
+__global__ __launch_bounds__(64) void k_marg_merge(DevStars st, const IsoHdr *__restrict__ hdr, const double *__restrict__ params,
+                                                   double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
+                                                   const double *__restrict__ shares, int n_split)
+{
+    const int lane = threadIdx.x, sc = blockIdx.x, w = blockIdx.y;
+    bool valid = true;
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) valid = valid && hdr[w * NPOPS + kp].valid;
+    if (!valid) return;                                  // (k_star_marg's split 0 has written the chunk's 0 / -inf)
+    const int slot = sc * 64 + lane, orig = st.mg_perm[slot];
+    const double c0m = st.mg_c0m[slot], la = st.mg_la[slot];
+    double ll[NPOPS];
+#pragma unroll
+    for (int kp = 0; kp < NPOPS; ++kp) {
+        const double *sh = shares + ((((size_t)w * (st.mg_pad >> 6) + sc) * n_split) * NPOPS + kp) * 128;
+        double r = NEG_INF;
+        for (int k = 0; k < n_split; ++k) {
+            const double rk = sh[(size_t)k * NPOPS * 128 + lane], sk = sh[(size_t)k * NPOPS * 128 + 64 + lane];
+            r = (sk > 0.0 && rk > r) ? rk : r;
+        }
+        double S = 0.0;
+        for (int k = 0; k < n_split; ++k) {
+            const double rk = sh[(size_t)k * NPOPS * 128 + lane], sk = sh[(size_t)k * NPOPS * 128 + 64 + lane];
+            S += (sk > 0.0) ? sk * exp_fast(rk - r) : 0.0;
+        }
+        ll[kp] = (S > 0.0) ? c0m + (r + log(S)) : NEG_INF;
+    }
+    double v = 0.0;
+    if (orig >= 0) {
+        double l = ll[0];
+        if (NPOPS == 2) { const double lam = params[(size_t)w * B9_NPARAM + B9_P_LAMBDA]; l = logaddexp(log(lam) + ll[0], log1p(-lam) + ll[NPOPS - 1]); }
+        v = logaddexp(la, l);
+        if (perstar) perstar[(size_t)w * st.n + orig] = v;
+    }
+    const double tot = wave_sum(v);
+    if (lane == 0) partial[(size_t)w * partial_stride + sc] = tot;
 }
 
 // ------------------------------------------------------------------------------------------
