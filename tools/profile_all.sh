@@ -21,8 +21,8 @@ echo "config sweep done"
 {
   python3 tools/time_marg.py 50000 4 4 8; python3 tools/time_marg.py 50000 8 8 8; python3 tools/time_marg.py 50000 4 4 8 --filters 16
   python3 tools/time_marg.py 50000 4 4 8 --filters 4; python3 tools/time_marg.py 30000 4 4 8 --pops 2; python3 tools/time_marg.py 30000 4 4 8 --pops 2 --filters 16
-  python3 tools/time_marg.py 20000 4 4 8 --wd 0.05; python3 tools/time_marg.py 20000 4 4 1
+  python3 tools/time_marg.py 20000 4 4 8 --wd 0.05; python3 tools/time_marg.py 20000 4 4 1; python3 tools/time_marg.py 10000 4 4 1; python3 tools/time_marg.py 10000 8 8 1; python3 tools/time_marg.py 200 4 4 1 --filters 4
   python3 tools/time_marg.py 50000 4 4 8 --sample; python3 tools/time_marg.py 30000 4 4 8 --pops 2 --sample; python3 tools/time_marg.py 50000 4 4 8 --filters 16 --sample
 } > $O/${TAG}_marg_instances.txt 2>&1 || echo "(marg instances failed)"
-python3 tools/time_step.py C0 C1 C2 C3 C4 F16 F16P2 F4 > $O/${TAG}_time_step.txt 2>&1 || echo "(time_step failed)"
+{ python3 tools/time_step.py C0 C1 C2 C3 C4 F16 F16P2 F4; python3 tools/time_step.py C0 C1 C2 C3 C4 --marg 4 4; python3 tools/time_step.py C1 C3 --marg 8 8; } > $O/${TAG}_time_step.txt 2>&1 || echo "(time_step failed)"
 echo "all done"
