@@ -90,14 +90,18 @@ def test_device_sampler_equals_the_host_twin_and_one_rank_rccl():
     np.testing.assert_array_equal(st_rccl["chol"], st_dev["chol"])
 
 
-def test_two_ranks_on_one_gpu_match_one_rank():
+@pytest.mark.parametrize("mode", ["given_mass", "marginalised"])
+def test_two_ranks_on_one_gpu_match_one_rank(mode):
     """World size 2 through the PRODUCT block runner (device-resident fused steps, pipelined blocks) on one GPU: two
     threads, each with its own context and half of the walkers; only the all-gather is bridged by the test (a callback
     exchange -- RCCL refuses two ranks on one device).  Chains, proposal factor, scale and the replicated ensemble
-    state are the bits of the one-rank run."""
+    state are the bits of the one-rank run -- in the marginalised mode too, where this catalogue (47 star chunks) splits
+    every chunk's window over 8 workgroups: the split is a function of the catalogue, not of the walkers on the GPU."""
     import threading
     from base_amd import engine
     pack_d, cl, pack, stars, priors, options = build_problem("parsec", 8, n_stars=3000, wd_frac=0.02, small=False, seed=8)
+    if mode == "marginalised":
+        options = abi.make_options(abi.MODE_MARGINALISED, 1, 2, 3)
     start = synth.walker_params(cl["truth"], 8, seed=42, scale=0.05)
     eng1 = engine.Engine(pack, stars, priors, options)
     st1, samples1, lps1 = _device_run(eng1, hostlib.Exchange.local(), start)
