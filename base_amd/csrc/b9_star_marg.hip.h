@@ -274,30 +274,9 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
             const double *__restrict__ const t_wp = tab + (size_t)(w * NPOPS + kp) * L.total;
             const int n_units = (((iso_g[kp].n - 1) * K + 63) >> 6) * 4;
             double xmin = __builtin_inf();
-            if constexpr (SPLIT) {
-                // (rows requested one ahead, as in the main loop: a row's L2 trip hides behind its predecessor's chi^2 -- one exposed
-                //  trip per row made this pass 12 us of a split workgroup's life; units past the end re-read the last one)
-                auto srow = [&](int u) { const int uu = u < n_units ? u : n_units - 1; return t_wp + L.o_rows + (size_t)uu * Q * 16 * NFP; };
-                auto snb = [&](int u) { const int uu = u < n_units ? u : n_units - 1; return t_wp + L.o_nb + uu * 16; };
-                SRow<NFP> ra, rb;
-                ra.load(srow(wave), snb(wave));
-                ra.wait();
-    #pragma unroll 1
-                for (int u = wave; u < n_units; u += 8) {
-                    rb.load(srow(u + 4), snb(u + 4));
-                    __builtin_amdgcn_sched_barrier(0);
-                    xmin = __builtin_fmin(xmin, srow_x<NFP>(ra, so, sw));
-                    rb.wait();
-                    ra.load(srow(u + 8), snb(u + 8));
-                    __builtin_amdgcn_sched_barrier(0);
-                    xmin = __builtin_fmin(xmin, srow_x<NFP>(rb, so, sw));
-                    ra.wait();
-                }
-            } else {
-                for (int u = wave; u < n_units; u += 4) {
-                    const double x = row_x<NFP>(t_wp + L.o_rows + (size_t)u * Q * 16 * NFP, t_wp[L.o_nb + u * 16], so, sw);
-                    xmin = __builtin_fmin(xmin, x);
-                }
+            for (int u = wave; u < n_units; u += 4) {
+                const double x = row_x<NFP>(t_wp + L.o_rows + (size_t)u * Q * 16 * NFP, t_wp[L.o_nb + u * 16], so, sw);
+                xmin = __builtin_fmin(xmin, x);
             }
             if (!dead && tmax[kp] == NEG_INF) { ref[kp] = -0.5 * xmin; tmax[kp] = ref[kp]; }
         }
