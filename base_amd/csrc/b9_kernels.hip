@@ -180,16 +180,23 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
 
 // doubles of one (walker, population)'s node table (MargLayout, b9_device.h)
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q) { return marg_layout(nfp, mass_cap, K, Q).total; }
-// workgroups per (star chunk, walker) of k_star_marg by catalogue size (star chunks x populations): 1 from 512 up (32k stars of
-// one population), 4 from 128, 8 from 32, else 16.  Measured, ms per b9_logpost call unsplit -> split: 10k stars x 1 walker
-// 0.18 -> 0.08 (8 x 8 grid: 0.47 -> 0.18), 200 stars 0.14 -> 0.06, 20k x 8 walkers 0.21 -> 0.19, 10k x 8 walkers 0.11;
-// 30k x 2 populations x 8 walkers would lose (0.27 -> 0.37: 938 chunk-populations, left unsplit).
-int b9k_marg_split(int n_star_chunks, int n_pops)
+// workgroups per (star chunk, walker) of k_star_marg: by catalogue size (star chunks x populations) and grid (K x Q) -- never by
+// the walkers on the GPU.  1 from 512 chunk-populations up (32k stars of one population), 4 from 256, 8 below; doubled (at most
+// 16) from K Q = 64 nodes per EEP interval up: a finer grid is a longer window per star.  Measured, ms per b9_logpost call at
+// 4 x 4, one workgroup per chunk -> split: 10k stars x 1 walker 0.18 -> 0.07 (8 x 8 grid: 0.47 -> 0.11), 200 stars 0.14 ->
+// 0.06, 20k x 8 walkers 0.21 -> 0.19, 10k x 8 walkers 0.13; 30k x 2 populations x 8 walkers would lose (0.27 -> 0.37: 938
+// chunk-populations, left unsplit).  10k stars x 1 walker at 4 x 4, us per sampler step: 4 splits 69, 8: 52, 16: 57.
+int b9k_marg_split(int n_star_chunks, int n_pops, int K, int Q)
 {
     const int eff = n_star_chunks * n_pops;
-    return eff >= 512 ? 1 : (eff >= 128 ? 4 : (eff >= 32 ? 8 : 16));
+    int s = eff >= 512 ? 1 : (eff >= 256 ? 4 : 8);
+    if (s > 1 && K * Q >= 64) s = s * 2 > 16 ? 16 : s * 2;
+    return s;
 }
-long long b9k_marg_shares_doubles(int n_star_chunks, int n_pops) { return (long long)n_star_chunks * b9k_marg_split(n_star_chunks, n_pops) * n_pops * 128; }   // per walker
+long long b9k_marg_shares_doubles(int n_star_chunks, int n_pops)      // per walker: room for 16 splits where any grid splits at all
+{
+    return n_star_chunks * n_pops >= 512 ? 128 : (long long)n_star_chunks * 16 * n_pops * 128;
+}
 long long b9k_marg_wd_table_doubles(int nfp, int K) { return (long long)8 * K * (2 * nfp + 1); }       // per (walker, population)
 
 template <int NFP, int NPOPS, bool SAMPLE>
@@ -222,7 +229,7 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     // 40) while most of the chip idles, so n_split workgroups share a chunk's window (k_star_marg / k_marg_merge).  A function
     // of the CATALOGUE only -- it decides how a star's sum rounds, and a walker's chain must not depend on how many walkers
     // share the GPU.  The sampleMass draws keep one workgroup per chunk.
-    const int n_split = SAMPLE ? 1 : b9k_marg_split(n_chunks, NPOPS);
+    const int n_split = SAMPLE ? 1 : b9k_marg_split(n_chunks, NPOPS, K, Q);
     if (n_split > 1 && !shares) return hipErrorInvalidValue;
     const int per_xcd = ((n_chunks + csplit - 1) / csplit) * (n_walkers / wsplit) * n_split;
     const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();

@@ -51,7 +51,7 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
                          double *wd_tab /* the WD-stage stars' node table: n_walkers * n_pops * b9k_marg_wd_table_doubles(nfp, K) doubles (used when the catalogue has WD-stage stars) */,
                          double *shares /* per-star shares of split launches: n_walkers * b9k_marg_shares_doubles(star chunks, n_pops) doubles */,
                          hipStream_t stream);
-int b9k_marg_split(int n_star_chunks, int n_pops);
+int b9k_marg_split(int n_star_chunks, int n_pops, int K, int Q);
 long long b9k_marg_shares_doubles(int n_star_chunks, int n_pops);
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q);
 long long b9k_marg_wd_table_doubles(int nfp, int K);
