@@ -181,15 +181,16 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
 // doubles of one (walker, population)'s node table (MargLayout, b9_device.h)
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q) { return marg_layout(nfp, mass_cap, K, Q).total; }
 // workgroups per (star chunk, walker) of k_star_marg: by catalogue size (star chunks x populations) and grid (K x Q) -- never by
-// the walkers on the GPU.  1 from 512 chunk-populations up (32k stars of one population), 4 from 256, 8 below; doubled (at most
+// the walkers on the GPU.  1 from 512 chunk-populations up (32k stars of one population), 4 from 384, 8 below; doubled (at most
 // 16) from K Q = 64 nodes per EEP interval up: a finer grid is a longer window per star.  Measured, ms per b9_logpost call at
 // 4 x 4, one workgroup per chunk -> split: 10k stars x 1 walker 0.18 -> 0.07 (8 x 8 grid: 0.47 -> 0.11), 200 stars 0.14 ->
 // 0.06, 20k x 8 walkers 0.21 -> 0.19, 10k x 8 walkers 0.13; 30k x 2 populations x 8 walkers would lose (0.27 -> 0.37: 938
-// chunk-populations, left unsplit).  10k stars x 1 walker at 4 x 4, us per sampler step: 4 splits 69, 8: 52, 16: 57.
+// chunk-populations, left unsplit).  us per sampler step of ONE chain at 4 x 4: 10k stars 4 splits 69, 8: 52, 16: 57; 20k stars
+// (313 chunks) 4 splits 88, 8: 73 -- with 8 walkers on the GPU the same catalogue pays 0.18 -> 0.21 ms per call for that.
 int b9k_marg_split(int n_star_chunks, int n_pops, int K, int Q)
 {
     const int eff = n_star_chunks * n_pops;
-    int s = eff >= 512 ? 1 : (eff >= 256 ? 4 : 8);
+    int s = eff >= 512 ? 1 : (eff >= 384 ? 4 : 8);
     if (s > 1 && K * Q >= 64) s = s * 2 > 16 ? 16 : s * 2;
     return s;
 }
