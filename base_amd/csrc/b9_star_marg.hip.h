@@ -17,10 +17,10 @@
 // photometry -- hence the nodes that matter for them -- is similar) and walks the node table; a node's words are the same
 // for every lane, so they arrive by SCALAR loads (s_load_dwordx16: a row of 8 magnitudes in one instruction, no VGPRs,
 // no LDS) and the per-lane state is just the star's observations / weights and its running log-sum-exp.  No cross-lane
-// operation on the data path, no LDS, no barrier; a workgroup is one wave, so the hardware's dispatcher balances the
-// launch wave by wave.  (Round 3's layout -- one WAVE per star, lane = node -- paid per star for what is now paid per
-// 64 stars: bound tables in LDS, wave maxima, a chunk list, 8 vector loads per companion; 1720 wave-instructions per
-// star-eval against ~300 here.)
+// operation on the data path; a workgroup is FOUR waves holding the same 64 stars, each walking a quarter of every
+// 64-node chunk (see k_star_marg).  (Round 3's layout -- one WAVE per star, lane = node -- paid per star for what is now
+// paid per 64 stars: bound tables in LDS, wave maxima, a chunk list, 8 vector loads per companion; 1720 wave-instructions
+// per star-eval against ~300 here.)
 //
 // Pruning (rigorous; exact to ~1e-13 relative).  Terms more than B9_MARG_CUT e-folds below a LOWER bound `ref` of what the
 // star's value finally contains are dropped (< N e^-40 relative).  ref = max(the lane's running maximum, the field floor):
@@ -200,20 +200,27 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
 // A workgroup = FOUR waves holding the SAME 64 stars; wave k takes sub-chunk k of every 64-node chunk (a quarter of every
 // star's window, wherever it lies) and the four partial log-sum-exps are merged through LDS at the end.  (With one wave
 // per 64 stars the launch lasted as long as its heaviest wave -- a chunk of giants whose windows barely overlap walks
-// 2000 terms against an average of 240; the mean wave lived a quarter of the launch.)  The waves share their running
-// maxima through LDS -- plain reads and writes of a double per lane, no barrier: any earlier value of another wave's
-// maximum is still a valid pruning reference -- so each prunes as if it had seen the whole window.  The level-1 boxes are
-// dealt over the waves too (wave k tests chunks k, k + 4, ...) and the outcome travels as a bit mask in LDS.
+// 2000 terms against an average of 240; the mean wave lived a quarter of the launch.)  A wave prunes against the maxima
+// the four waves' seed passes merged BEHIND A BARRIER and, from there on, its OWN running maximum only: which terms enter a
+// star's sum is a function of the data, never of how the waves' clocks interleave (round 4 read the neighbours' running
+// maxima from LDS without a barrier -- a valid reference whenever it was read, but a timing-dependent one, and with it the
+// last bits of a star's value).  A wave's sub-chunks sample every region of the window, so its own maximum is within a
+// node spacing of the workgroup's.  The level-1 boxes are dealt over the waves too (wave k tests chunks k, k + 4, ...)
+// and the outcome travels as a bit mask in LDS.
 #define B9_MARG_MASK_WORDS 16        // level-1 outcomes of up to 1024 chunks go through the mask; later chunks are tested by every wave
 
-template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT>
-__global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE))
-void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
-                 const double *__restrict__ iso_data, long long iso_stride,
-                 int mass_cap, const double *__restrict__ params,
+// What a launch evaluates the stars AGAINST: the headers, parameter rows and node tables of its walkers.  The plain
+// launch knows them at entry; the sampler's fused step (b9_marg_step.hip.h) picks one of two candidates by the previous
+// step's accept / reject decision, taken inside the launch -- `select(w)` is called once per workgroup, by all its
+// threads, after the star's own words have been requested.
+struct MargSel { const IsoHdr *hdr; const double *params; const double *tab; };
+
+template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, class Select>
+__device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars &st, int block_id,
+                 const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
                  double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
-                 int K, int Q, MargSample ms, const double *__restrict__ tab, MargLayout L,
-                 int n_walkers, double cut2, int wsplit, int n_split_arg, double *__restrict__ shares)
+                 int K, int Q, const MargSample &ms, const MargLayout &L,
+                 int n_walkers, double cut2, int wsplit, int n_split_arg, double *__restrict__ shares, Select select)
 {
     const int n_split = SPLIT ? n_split_arg : 1;          // (a compile-time 1 in the unsplit instance: its code is the one-workgroup kernel's)
     __shared__ double s_tmax[NPOPS][4][64], s_ref[NPOPS][4][64], s_sm[NPOPS][4][64];
@@ -229,7 +236,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     // neighbours in the order on different XCD groups (a contiguous share per XCD left the XCD holding the giants working
     // alone for the launch's second half), and inside an XCD the walkers of one star chunk are neighbours in dispatch
     // order: the chunk's star data is fetched from HBM once per group.  (Speed only; any placement is correct.)
-    const int xcd = blockIdx.x & 7, i_x = blockIdx.x >> 3;
+    const int xcd = block_id & 7, i_x = block_id >> 3;
     const int csplit = 8 / wsplit, wg_n = n_walkers / wsplit;           // chunk groups; walkers per group
     const int a = xcd % wsplit, b = xcd / wsplit;
     // SPLIT (small catalogues, b9k_star_marg): n_split workgroups share one (star chunk, walker) -- workgroup s takes the node
@@ -242,11 +249,19 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     if (pos * 64 >= st.mg_pad) return;
     const int sc = st.marg_order[pos];
     const int slot = sc * 64 + lane;                                // (slot of the marginalised mode's own copy: DevStars::mg_*)
-    const double *par = params + (size_t)w * B9_NPARAM;
+    // the star's own words are requested before anything that depends on the walker's candidate
+    const int orig = st.mg_perm[slot];
+    double so[NFP], sw[NFP];                                       // the star, scaled: sqrt(w) obs, sqrt(w)
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) { so[f] = st.mg_so[B9_SIDX(NFP, f, slot)]; sw[f] = st.mg_sw[B9_SIDX(NFP, f, slot)]; }
+    const double c0m = st.mg_c0m[slot], la = st.mg_la[slot];
+    const MargSel sel = select(w);
+    const IsoHdr *__restrict__ const hdr = sel.hdr;
+    const double *__restrict__ const tab = sel.tab;
+    const double *par = sel.params + (size_t)w * B9_NPARAM;
     IsoView<NFP> iso_g[NPOPS];
     double tip_min;
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso_g, tip_min);
-    const int orig = st.mg_perm[slot];
     if (!valid) {
         if (wave == 0 && split == 0) {
             if (lane == 0) partial[(size_t)w * partial_stride + sc] = 0.0;
@@ -255,10 +270,6 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
         return;
     }
     const bool dead = orig < 0;
-    double so[NFP], sw[NFP];                                       // the star, scaled: sqrt(w) obs, sqrt(w)
-#pragma unroll
-    for (int f = 0; f < NFP; ++f) { so[f] = st.mg_so[B9_SIDX(NFP, f, slot)]; sw[f] = st.mg_sw[B9_SIDX(NFP, f, slot)]; }
-    const double c0m = st.mg_c0m[slot], la = st.mg_la[slot];
     // the field floor (in the units of the terms: the star's constant c0m is added at the end)
     const double floor_t = (SAMPLE || !(cut2 < __builtin_inf())) ? NEG_INF : la - c0m;
     if (threadIdx.x < NPOPS * B9_MARG_MASK_WORDS) (&s_mask[0][0])[threadIdx.x] = 0ull;
@@ -312,13 +323,10 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
         // one chunk that passed level 1: this wave's sub-chunk, mass ratio by mass ratio
         auto chunk = [&](int c) {
             MSTAT(1, 1);
-            // the other waves' maxima (whatever they have published so far)
-            tmax[kp] = __builtin_fmax(__builtin_fmax(tmax[kp], s_tmax[kp][0][lane]), __builtin_fmax(s_tmax[kp][1][lane], __builtin_fmax(s_tmax[kp][2][lane], s_tmax[kp][3][lane])));
             double xcut = fma(-2.0, tmax[kp], cut2);                      // a term counts while X < xcut
             const int u = c * 4 + wave;
             const double nbm = t_nbmin16[u];
             const double *__restrict__ const nbp = t_nb + u * 16;
-            bool any = false;
             for (int j = 0; j < Q; ++j) {
                 // level 2: this wave's 16 nodes x one mass ratio
                 const double lb2 = box_bound<NFP>(t_box2 + ((size_t)u * Q + j) * 2 * NFP, so, sw);
@@ -326,7 +334,6 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                 if (__ballot(lb2 + nbm < xcut) == 0ull) continue;
                 MSTAT(3, 1);
                 MLIFE_UNIT();
-                any = true;
                 const double *__restrict__ const rowp = t_rows + ((size_t)u * Q + j) * 16 * NFP;
                 // one row's term for every lane (the 64 stars), into the lanes that still count it
                 auto term = [&](const SRow<NFP> &r, int i) {
@@ -366,7 +373,6 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                 }
                 xcut = fma(-2.0, tmax[kp], cut2);
             }
-            if (any) s_tmax[kp][wave][lane] = tmax[kp];
         };
         const int n_words = (n_chunks + 63) >> 6;
         for (int wi = 0; wi < n_words && wi < B9_MARG_MASK_WORDS; ++wi) {
@@ -422,6 +428,19 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
     const double tot = wave_sum(v);
     if (lane == 0) partial[(size_t)w * partial_stride + sc] = tot;
     MLIFE(1, __builtin_amdgcn_s_memrealtime());
+}
+
+template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT>
+__global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE))
+void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
+                 const double *__restrict__ iso_data, long long iso_stride,
+                 int mass_cap, const double *__restrict__ params,
+                 double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
+                 int K, int Q, MargSample ms, const double *__restrict__ tab, MargLayout L,
+                 int n_walkers, double cut2, int wsplit, int n_split_arg, double *__restrict__ shares)
+{
+    star_marg_body<NFP, NPOPS, SAMPLE, SPLIT>(pk, st, (int)blockIdx.x, iso_data, iso_stride, mass_cap, partial, partial_stride, perstar, K, Q, ms, L,
+                                              n_walkers, cut2, wsplit, n_split_arg, shares, [&](int) { return MargSel{hdr, params, tab}; });
 }
 
 // k_marg_merge: the stars of a SPLIT launch -- one wave per (star chunk, walker), lane = star: the n_split shares (ref, sum) of
