@@ -58,11 +58,41 @@ int collect_block(b9_ctx *ctx, b9_ctx::McmcSlot &sl, b9_mcmc_block *blk)
     return B9_OK;
 }
 
-int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
+/* The marginalised mode runs the same block with k_marg_step in K(t)'s place (b9_marg_step.hip.h: the candidates are node
+ * tables, built inside the launch; no isochrone is materialised) and, for the block's first proposal, k_marg_table behind D0. */
+struct MargBlock {             // what the marginalised flavour adds to a fused block
+    int K = 1, Q = 1;
+    double *partial = nullptr;                 // [W][stride]: two parities of (star chunks + WD-stage stars) partials
+    long long stride = 0, tab_doubles = 0, wd_stride = 0;
+    int n_partial = 0;
+};
+
+// can the marginalised mode run fused steps on this context?  (the table builders' mass column must fit beside the star role's
+// workgroups in LDS: isochrones of more than ~600 points at 8 filters keep the two-launch step)
+bool marg_fused_ok(const b9_ctx *ctx) { return b9k_marg_step_lds(ctx->pk.nfp, ctx->mass_cap) <= B9_MSTEP_LDS_MAX(ctx->pk.nfp); }
+
+int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk, bool marg)
 {
     const int W = blk->n_walkers, d = blk->n_free, S = blk->n_steps, n_pops = ctx->opt.n_pops;
     const bool cont = (blk->flags & B9_BLOCK_CONTINUE) != 0, async = (blk->flags & B9_BLOCK_ASYNC) != 0;
-    const StepPlan sp = make_step_plan(ctx, W, n_pops);
+    StepPlan sp{};
+    MargBlock mb;
+    if (marg) {
+        mb.K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1;
+        mb.Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
+        // four candidate sets (two parities x two candidates) of node tables, WD tables and split shares
+        int rc = ensure_marg_table(ctx, 4 * W, n_pops, mb.K, mb.Q);
+        if (rc) return rc;
+        mb.n_partial = ctx->st.mg_pad / 64 + ctx->st.n_wd;
+        mb.stride = 2 * (((long long)mb.n_partial + 7) & ~7ll);
+        rc = ensure_capacity(ctx, W, n_pops, (size_t)std::max<long long>(mb.stride, partial_stride(ctx)) * W, false);
+        if (rc) return rc;
+        mb.partial = ctx->d_partial;
+        mb.tab_doubles = b9k_marg_table_doubles(ctx->pk.nfp, ctx->mass_cap, mb.K, mb.Q);
+        mb.wd_stride = (long long)W * n_pops * b9k_marg_wd_table_doubles(ctx->pk.nfp, mb.K);
+    } else {
+        sp = make_step_plan(ctx, W, n_pops);
+    }
     const B9Groups &plan = sp.plan;
     const int derive_parts = sp.derive_parts;
     // two slots (device block + pinned mirror + event) alternate, so that a block can be enqueued while its
@@ -142,10 +172,10 @@ int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
     }
     StepDev sd{};
     sd.d = d; sd.n_walkers = W; sd.n_pops = n_pops;
-    sd.n_partial = partial_count(ctx, plan); sd.mass_cap = ctx->mass_cap; sd.heavy_parts = ctx->heavy_parts;
+    sd.n_partial = marg ? mb.n_partial : partial_count(ctx, plan); sd.mass_cap = ctx->mass_cap; sd.heavy_parts = marg ? 0 : ctx->heavy_parts;
     sd.k0 = (unsigned)(blk->seed & 0xFFFFFFFFull); sd.k1 = (unsigned)(blk->seed >> 32);
-    sd.partial_stride = partial_stride(ctx); sd.iso_stride = ctx->iso_stride;
-    sd.state = d_state; sd.partial = ctx->d_partial;
+    sd.partial_stride = marg ? mb.stride : partial_stride(ctx); sd.iso_stride = ctx->iso_stride;
+    sd.state = d_state; sd.partial = marg ? mb.partial : ctx->d_partial;
     sd.cand_par = ctx->d_params; sd.cand_hdr = ctx->d_hdr; sd.cand_iso = ctx->d_iso;
     sd.chol = d_chol; sd.free_idx = d_free; sd.walker_ids = d_ids;
     sd.samples = d_samples; sd.lps = d_lps; sd.n_acc = d_nacc; sd.decided = d_decided;
@@ -161,6 +191,10 @@ int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
         HIPCHK(ctx, b9k_derive_iso(ctx->pk, sd.cand_par + c10 * W * B9_NPARAM, W, n_pops, sd.cand_hdr + c10 * rows,
                                    sd.cand_iso + c10 * rows * ctx->iso_stride, ctx->iso_stride, ctx->mass_cap,
                                    mc, ctx->pr, B9Prev{nullptr, 0, 0, nullptr, nullptr}, s));
+        if (marg)       // ... and its node tables (every later candidate's are built inside k_marg_step)
+            HIPCHK(ctx, b9k_marg_tables(ctx->pk, sd.cand_hdr + c10 * rows, sd.cand_iso + c10 * rows * ctx->iso_stride, ctx->iso_stride, ctx->mass_cap,
+                                        sd.cand_par + c10 * W * B9_NPARAM, W, n_pops, mb.K, mb.Q, ctx->d_marg_tab + c10 * rows * mb.tab_doubles,
+                                        ctx->st.n_wd > 0 ? ctx->d_marg_wd_tab + c10 * mb.wd_stride : nullptr, s));
     }
     long t_slot = -1;
     int t_covered = 0;
@@ -175,7 +209,11 @@ int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk)
             if (rc) return rc;
             t_covered = 0;
         } else if (ctx->timing > 0) ctx->launch_no++;
-        HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, plan, ctx->heavy_parts, derive_parts, ctx->derive_order, s));
+        if (marg)
+            HIPCHK(ctx, b9k_marg_step(ctx->pk, ctx->st, sd, ctx->pr, mb.K, mb.Q, ctx->marg_prune, ctx->d_marg_tab, ctx->d_marg_wd_tab, mb.wd_stride,
+                                      ctx->d_marg_shares, s));
+        else
+            HIPCHK(ctx, b9k_mcmc_step(ctx->pk, ctx->st, sd, ctx->pr, plan, ctx->heavy_parts, derive_parts, ctx->derive_order, s));
         if (t_slot >= 0 && (++t_covered >= ctx->timing_group || t == S - 1)) {
             ctx->ev_count[t_slot] = t_covered;
             int rc = timing_end(ctx, s, t_slot);
@@ -492,8 +530,9 @@ int b9_mcmc_run_block(b9_ctx *ctx, b9_mcmc_block *blk)
     if (rc) return rc;
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && !ctx->two_launch_steps) {
         const TreePlan tp = make_tree_plan(ctx, W, n_pops);
-        return tp.depth >= 2 ? run_block_tree(ctx, blk, tp) : run_block_fused(ctx, blk);
+        return tp.depth >= 2 ? run_block_tree(ctx, blk, tp) : run_block_fused(ctx, blk, false);
     }
+    if (ctx->opt.mode == B9_MODE_MARGINALISED && !ctx->two_launch_steps && marg_fused_ok(ctx)) return run_block_fused(ctx, blk, true);
     return run_block_two_launch(ctx, blk, plan);
 }
 

@@ -118,3 +118,34 @@ extern "C" int b9_debug_marg_life(unsigned long long *out) { return (int)hipMemc
 #define MLIFE(k, v) do {} while (0)
 #define MLIFE_UNIT() do {} while (0)
 #endif
+
+// -DB9_MSTEP_NO_FRONT (no writer, no builders) / -DB9_MSTEP_NO_BUILD / -DB9_MSTEP_NO_STARS / -DB9_MSTEP_FIXED_CAND (the stars always against the prologue's tables) / -DB9_MSTEP_NO_DECIDE / -DB9_MSTEP_WAVES=n (timing probes of k_marg_step; WRONG chains): the table builders
+// return at once / the star roles take candidate 0 without a decision / the kernel is built for n waves per SIMD
+#ifdef B9_MSTEP_NO_BUILD
+#define MSTEP_NO_BUILD 1
+#else
+#define MSTEP_NO_BUILD 0
+#endif
+#ifdef B9_MSTEP_NO_FRONT
+#define MSTEP_NO_FRONT 1
+#else
+#define MSTEP_NO_FRONT 0
+#endif
+#ifdef B9_MSTEP_NO_STARS
+#define MSTEP_NO_STARS 1
+#else
+#define MSTEP_NO_STARS 0
+#endif
+#ifdef B9_MSTEP_FIXED_CAND
+#define MSTEP_FIXED_CAND 1
+#else
+#define MSTEP_FIXED_CAND 0
+#endif
+#ifdef B9_MSTEP_NO_DECIDE
+#define MSTEP_NO_DECIDE 1
+#else
+#define MSTEP_NO_DECIDE 0
+#endif
+#ifndef B9_MSTEP_WAVES
+#define B9_MSTEP_WAVES(NFP, NPOPS) B9_MARG_WAVES(NFP, NPOPS, false)
+#endif

@@ -60,6 +60,7 @@ namespace tree_kd5 {
 }
 #undef B9_TREE_KD
 #include "b9_star_marg.hip.h"
+#include "b9_marg_step.hip.h"
 
 // ------------------------------------------------------------------------------------------
 // k_finalize: one workgroup per walker: fixed-order sum of the partials + prior -> logpost[w]
@@ -273,6 +274,88 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 #undef SM1
 #undef SM2
 #undef SM_ARGS
+}
+
+// ---- the marginalised mode's fused sampler step (k_marg_step) -----------------------------------------------------------
+// The node tables of a set of derived isochrones WITHOUT the star launch: the prologue of a fused block (its first
+// proposal comes from k_derive_iso; every later one is built inside k_marg_step).
+template <int NFP>
+static hipError_t launch_marg_tables(const DevPack &pk, const IsoHdr *hdr, const double *iso_data, long long iso_stride, int mass_cap,
+                                     const double *d_params, int n_walkers, int n_pops, int K, int Q, double *tab, double *wd_tab, hipStream_t stream)
+{
+    const MargLayout L = marg_layout(NFP, mass_cap, K, Q);
+    const size_t lds = sizeof(double) * ((size_t)mass_cap + 8 + 8 * NFP);
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_marg_table<NFP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_marg_table<NFP>), dim3(n_walkers * n_pops, L.n_chunks), dim3(256), lds, stream, pk, hdr, iso_data,
+                       iso_stride, mass_cap, n_pops, d_params, K, Q, tab, L);
+    if (wd_tab)
+        hipLaunchKernelGGL((k_marg_wd_table<NFP>), dim3(n_walkers * n_pops, (8 * K + 63) / 64), dim3(128), 0, stream, pk, hdr, iso_data, iso_stride,
+                           mass_cap, n_pops, d_params, K, wd_tab, n_walkers * n_pops);
+    return hipGetLastError();
+}
+
+hipError_t b9k_marg_tables(const DevPack &pk, const IsoHdr *hdr, const double *iso_data, long long iso_stride, int mass_cap,
+                           const double *d_params, int n_walkers, int n_pops, int K, int Q, double *tab, double *wd_tab, hipStream_t stream)
+{
+    switch (pk.nfp) {
+    case 4:  return launch_marg_tables<4>(pk, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, n_pops, K, Q, tab, wd_tab, stream);
+    case 8:  return launch_marg_tables<8>(pk, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, n_pops, K, Q, tab, wd_tab, stream);
+    case 16: return launch_marg_tables<16>(pk, hdr, iso_data, iso_stride, mass_cap, d_params, n_walkers, n_pops, K, Q, tab, wd_tab, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// Dynamic LDS of k_marg_step (its table builders' tiles; every workgroup of the launch gets it): the fused step runs only while it
+// leaves the star role its workgroups per CU (B9_MSTEP_LDS_MAX: 160 KB / 7 less the kernel's static arrays, with 8 filters)
+size_t b9k_marg_step_lds(int nfp, int mass_cap) { return sizeof(double) * B9_MSTEP_LDS_DOUBLES(nfp, mass_cap); }
+
+template <int NFP, int NPOPS>
+static hipError_t launch_marg_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, int K, int Q, bool prune,
+                                   double *tab, double *wd_tab, long long wd_stride, double *shares, hipStream_t stream)
+{
+    const int W = sd.n_walkers;
+    MargStep mx{};
+    mx.K = K; mx.Q = Q; mx.L = marg_layout(NFP, sd.mass_cap, K, Q);
+    mx.n_chunks_cap = mx.L.n_chunks;
+    mx.n_wd_blocks = st.n_wd > 0 ? (8 * K + 127) / 128 : 0;
+    mx.wsplit = W % 2 == 0 ? 2 : 1;
+    const int csplit = 8 / mx.wsplit, n_chunks = st.mg_pad / 64;
+    mx.n_split = b9k_marg_split(n_chunks, NPOPS, K, Q);
+    if (mx.n_split > 1 && !shares) return hipErrorInvalidValue;
+    if (st.n_wd > 0 && !wd_tab) return hipErrorInvalidValue;
+    mx.cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
+    mx.tab = tab; mx.wd_tab = wd_tab; mx.wd_stride = wd_stride; mx.shares = shares;
+    const int front = (W + W * 2 * NPOPS * (mx.n_chunks_cap + mx.n_wd_blocks) + 7) / 8 * 8;
+    const int stars = 8 * (((n_chunks + csplit - 1) / csplit) * (W / mx.wsplit) * mx.n_split);
+    const int wd = st.n_wd > 0 ? ((st.n_wd + 3) / 4) * W : 0;
+    const size_t lds = b9k_marg_step_lds(NFP, sd.mass_cap);
+    if (lds > B9_MSTEP_LDS_MAX(NFP)) return hipErrorInvalidValue;
+    if (mx.n_split > 1) {
+        hipLaunchKernelGGL((k_marg_step<NFP, NPOPS, true>), dim3(front + stars + wd), dim3(256), lds, stream, pk, st, sd, pr, mx, front, stars,
+                           hdr_rd, par_rd, tab_rd, wd_rd);
+        hipLaunchKernelGGL((k_marg_step_merge<NPOPS>), dim3(n_chunks, W), dim3(64), 0, stream, st, sd, mx);
+    } else {
+        hipLaunchKernelGGL((k_marg_step<NFP, NPOPS, false>), dim3(front + stars + wd), dim3(256), lds, stream, pk, st, sd, pr, mx, front, stars,
+                           hdr_rd, par_rd, tab_rd, wd_rd);
+    }
+    return hipGetLastError();
+}
+
+hipError_t b9k_marg_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, int K, int Q, bool prune,
+                         double *tab, double *wd_tab, long long wd_stride, double *shares, hipStream_t stream)
+{
+    const int n_pops = sd.n_pops;
+#define GS_ARGS pk, st, sd, pr, K, Q, prune, tab, wd_tab, wd_stride, shares, stream
+#define GS2(NFP) launch_marg_step<NFP, 2>(GS_ARGS)
+#define GS1(NFP) launch_marg_step<NFP, 1>(GS_ARGS)
+    B9_SWITCH_NFP(GS2, GS1)
+#undef GS1
+#undef GS2
+#undef GS_ARGS
 }
 
 // dynamic LDS of k_mcmc_step: the hot role's mass columns of both candidates (+ 8: find_bracket's masked over-read), or

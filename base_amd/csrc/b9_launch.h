@@ -56,6 +56,19 @@ long long b9k_marg_shares_doubles(int n_star_chunks, int n_pops);
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q);
 long long b9k_marg_wd_table_doubles(int nfp, int K);
 
+// marginalised mode, fused sampler step (b9_marg_step.hip.h): decision of step t-1 + stars of step t against one of its two candidate
+// node tables + both candidate tables of step t+1 (+ the merge launch of a split catalogue).  sd: StepDev with heavy_parts = 0,
+// n_partial = star chunks + WD-stage stars, cand_iso unused.  tab / wd_tab: [2 parities][2 candidates] blocks of n_walkers * n_pops
+// tables (b9k_marg_table_doubles / wd_stride doubles each).
+hipError_t b9k_marg_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, int K, int Q, bool prune,
+                         double *tab, double *wd_tab, long long wd_stride, double *shares, hipStream_t stream);
+// the tables alone (k_marg_table [+ k_marg_wd_table when wd_tab]) of derived isochrones: the fused block's prologue
+hipError_t b9k_marg_tables(const DevPack &pk, const IsoHdr *hdr, const double *iso_data, long long iso_stride, int mass_cap,
+                           const double *d_params, int n_walkers, int n_pops, int K, int Q, double *tab, double *wd_tab, hipStream_t stream);
+size_t b9k_marg_step_lds(int nfp, int mass_cap);
+// the most dynamic LDS k_marg_step may take and keep the star role's occupancy (7 workgroups per CU up to 8 filters, 4 with 16)
+#define B9_MSTEP_LDS_MAX(nfp) ((nfp) > 8 ? (size_t)30 * 1024 : (size_t)15 * 1024)
+
 // fused sampler step (given-mass mode): decision of step t-1 + stars of step t + candidates of step t+1
 // (tiles_per_block < 0: a workgroup's |tiles_per_block| tiles are strided n_groups apart instead of consecutive)
 hipError_t b9k_mcmc_step(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr,

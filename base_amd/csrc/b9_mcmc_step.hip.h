@@ -262,6 +262,48 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
                      sd.iso_stride, sd.mass_cap, part, parts, axr);
 }
 
+// The parameter row of candidate `cand` of step t+1 for walker w, formed by ONE wave (the caller's first) into s_par[12]
+// (LDS; s_z[12] is scratch): the decision of step t-1 from its partial sums, the normals of step t+1 (Philox + Box-Muller,
+// independent of every decision: while the decision's loads are in flight), and
+//     row = base;  row[free[i]] += sum_j chol[i][j] z_j   (j ascending, plain multiply-add -- as the host twin does)
+// with base = the state after step t-1 (cand 0: step t rejected) or step t's proposal (cand 1: accepted).  The other waves
+// see s_par behind the caller's next workgroup barrier.
+__device__ __forceinline__ void candidate_row_wave0(const StepDev &sd, int w, int cand, double *s_par, double *s_z)
+{
+    const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers;
+    const double *in = step_state_in(sd, w);
+    DecideLoads dl = {};
+    decide_issue<false>(sd, w, dl);
+    const double cur_v = tid < B9_NPARAM ? in[B9_ST_CUR + tid] : 0.0;
+    const double prev_prop_v = tid < B9_NPARAM ? in[B9_ST_PROP + tid] : 0.0;
+    const double pc0 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 0) * W + w) * B9_NPARAM + tid] : 0.0;
+    const double pc1 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 1) * W + w) * B9_NPARAM + tid] : 0.0;
+    double crow[11];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) crow[j] = (tid < d && j < d) ? sd.chol[tid * d + j] : 0.0;
+    const int fidx = tid < d ? sd.free_idx[tid] : 0;
+    {
+        const int n_pairs = (d + 1) >> 1;
+        if (tid < n_pairs) {
+            unsigned r[4];
+            const unsigned long long sn = sd.step + 1;
+            philox4x32((unsigned)sn, (unsigned)(sn >> 32), (unsigned)sd.walker_ids[w], (unsigned)tid, sd.k0, sd.k1, r);
+            const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+            const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+            s_z[2 * tid] = rad * cos(ang);
+            s_z[2 * tid + 1] = rad * sin(ang);
+        }
+    }
+    double lp_new = 0.0;
+    const bool ok = decide_finish<false>(sd, w, dl, lp_new);
+    if (tid < B9_NPARAM) s_par[tid] = cand ? (ok ? pc1 : pc0) : (ok ? prev_prop_v : cur_v);
+    __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS accesses complete in program order)
+    double delta = 0.0;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) if (j < d) delta = delta + crow[j] * s_z[j];
+    if (tid < d) s_par[fidx] += delta;                   // (each lane owns one sampled parameter)
+}
+
 // Derivation role, running AHEAD of the decision (as the tree launch's does, b9_mcmc_tree.hip.h): the role's chain was
 // decision -> parameter row -> grid brackets -> corner rows -> table values, five dependent legs.  Only the workgroup's FIRST
 // wave takes the decision (its loads leave first), draws step t+1's normals and forms the candidate's parameter row; waves
@@ -274,45 +316,14 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
 __device__ __forceinline__ void step_derive_ahead(const DevPack &pk, const StepDev &sd, int w, int cand, int pop, int part, int parts)
 {
     if (!sd.derive_next) return;
-    const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers, n_pops = sd.n_pops;
+    const int tid = threadIdx.x, W = sd.n_walkers, n_pops = sd.n_pops;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __shared__ double s_par[B9_NPARAM], s_z[12];
     const double *in = step_state_in(sd, w);
     const size_t rows = (size_t)W * n_pops;
     const size_t cset = (size_t)((sd.set ^ 1) * 2 + cand);
     if (wave == 0) {
-        DecideLoads dl = {};
-        decide_issue<false>(sd, w, dl);
-        const double cur_v = tid < B9_NPARAM ? in[B9_ST_CUR + tid] : 0.0;
-        const double prev_prop_v = tid < B9_NPARAM ? in[B9_ST_PROP + tid] : 0.0;
-        const double pc0 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 0) * W + w) * B9_NPARAM + tid] : 0.0;
-        const double pc1 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 1) * W + w) * B9_NPARAM + tid] : 0.0;
-        double crow[11];
-#pragma unroll
-        for (int j = 0; j < 11; ++j) crow[j] = (tid < d && j < d) ? sd.chol[tid * d + j] : 0.0;
-        const int fidx = tid < d ? sd.free_idx[tid] : 0;
-        {   // the normals of step t+1 (Philox + Box-Muller), independent of every decision: while the decision's loads are in flight
-            const int n_pairs = (d + 1) >> 1;
-            if (tid < n_pairs) {
-                unsigned r[4];
-                const unsigned long long sn = sd.step + 1;
-                philox4x32((unsigned)sn, (unsigned)(sn >> 32), (unsigned)sd.walker_ids[w], (unsigned)tid, sd.k0, sd.k1, r);
-                const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
-                const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
-                s_z[2 * tid] = rad * cos(ang);
-                s_z[2 * tid + 1] = rad * sin(ang);
-            }
-        }
-        double lp_new = 0.0;
-        const bool ok = decide_finish<false>(sd, w, dl, lp_new);
-        // candidate `cand` of step t+1:  base = state after step t-1 (step t rejected) or step t's proposal (accepted);
-        // row[free[i]] += sum_j chol[i][j] z_j  (j ascending, plain multiply-add -- as the host twin does)
-        if (tid < B9_NPARAM) s_par[tid] = cand ? (ok ? pc1 : pc0) : (ok ? prev_prop_v : cur_v);
-        __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS accesses complete in program order)
-        double delta = 0.0;
-#pragma unroll
-        for (int j = 0; j < 11; ++j) if (j < d) delta = delta + crow[j] * s_z[j];
-        if (tid < d) s_par[fidx] += delta;                   // (each lane owns one sampled parameter)
+        candidate_row_wave0(sd, w, cand, s_par, s_z);
         __syncthreads();
         if (pop == 0 && part == 0 && tid < B9_NPARAM) sd.cand_par[(cset * W + w) * B9_NPARAM + tid] = s_par[tid];
         return;

@@ -82,10 +82,17 @@ __device__ __forceinline__ double fma_vvs(double a, double b, double s_u) { doub
 // contribution sqrt(w_f) (C_f - obs_f) is ONE fma(sw_f, C_f, -so_f) with the magnitude as the scalar operand, its square
 // one more -- two VALU instructions per filter where w (C - obs)^2 took three (subtract, multiply, fma).
 
+// The node table as the star loop reads its wave-uniform words (boxes, nb minima, seed rows): through the CONSTANT address
+// space, so that every such read is a scalar load by construction.  (Left to the compiler, a uniform global load becomes an
+// s_load only while its "no store in this kernel may clobber it" analysis succeeds -- it does in k_star_marg alone and gives
+// up inside the much larger k_marg_step, where the same reads turned into vector loads + v_readfirstlane: +18 % launch time.)
+// The tables a launch reads are written by an EARLIER launch (k_marg_table, or the previous k_marg_step's builders).
+typedef const __attribute__((address_space(4))) double *b9_ctab;
+
 // lower bound of sum_f w_f (C_f - obs_f)^2 over every row with lo_f <= C_f <= hi_f (box = {lo[NFP], hi[NFP]}, wave-uniform):
 // the scaled distance of obs_f to the interval is max(sw lo - so, so - sw hi, 0)
 template <int NFP>
-__device__ __forceinline__ double box_bound(const double *__restrict__ box, const double (&so)[NFP], const double (&sw)[NFP])
+__device__ __forceinline__ double box_bound(b9_ctab box, const double (&so)[NFP], const double (&sw)[NFP])
 {
     double lb = 0.0;
 #pragma unroll
@@ -102,7 +109,7 @@ __device__ __forceinline__ double box_bound(const double *__restrict__ box, cons
 
 // X = nb + chi^2 of one table row (wave-uniform row, per-lane star)
 template <int NFP>
-__device__ __forceinline__ double row_x(const double *__restrict__ row, double nb, const double (&so)[NFP], const double (&sw)[NFP])
+__device__ __forceinline__ double row_x(b9_ctab row, double nb, const double (&so)[NFP], const double (&sw)[NFP])
 {
     double x = nb;
 #pragma unroll
@@ -211,9 +218,15 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
 
 // What a launch evaluates the stars AGAINST: the headers, parameter rows and node tables of its walkers.  The plain
 // launch knows them at entry; the sampler's fused step (b9_marg_step.hip.h) picks one of two candidates by the previous
-// step's accept / reject decision, taken inside the launch -- `select(w)` is called once per workgroup, by all its
-// threads, after the star's own words have been requested.
+// step's accept / reject decision, taken inside the launch: `select.issue(w)` requests what the decision reads (before
+// the star's own words are requested: its chain is the longer one), `select.finish(w)` -- called once per workgroup, by
+// all its threads, after the star's words have been requested -- returns the choice.
 struct MargSel { const IsoHdr *hdr; const double *params; const double *tab; };
+struct MargSelPlain {
+    MargSel s;
+    __device__ __forceinline__ void issue(int) {}
+    __device__ __forceinline__ MargSel finish(int) const { return s; }
+};
 
 template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, class Select>
 __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars &st, int block_id,
@@ -247,6 +260,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     const int w = wl * wsplit + a;
     const int pos = p_local * csplit + b;
     if (pos * 64 >= st.mg_pad) return;
+    select.issue(w);
     const int sc = st.marg_order[pos];
     const int slot = sc * 64 + lane;                                // (slot of the marginalised mode's own copy: DevStars::mg_*)
     // the star's own words are requested before anything that depends on the walker's candidate
@@ -255,7 +269,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
 #pragma unroll
     for (int f = 0; f < NFP; ++f) { so[f] = st.mg_so[B9_SIDX(NFP, f, slot)]; sw[f] = st.mg_sw[B9_SIDX(NFP, f, slot)]; }
     const double c0m = st.mg_c0m[slot], la = st.mg_la[slot];
-    const MargSel sel = select(w);
+    const MargSel sel = select.finish(w);
     const IsoHdr *__restrict__ const hdr = sel.hdr;
     const double *__restrict__ const tab = sel.tab;
     const double *par = sel.params + (size_t)w * B9_NPARAM;
@@ -282,7 +296,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
         tmax[kp] = dead ? __builtin_inf() : floor_t;                      // a term counts while it is within CUT of tmax
         // seed pass: lanes without a reference take the best single-star term among every 16th node (this wave: its sub-chunks)
         if (__ballot(!dead && tmax[kp] == NEG_INF) != 0ull && cut2 < __builtin_inf()) {
-            const double *__restrict__ const t_wp = tab + (size_t)(w * NPOPS + kp) * L.total;
+            const b9_ctab t_wp = (b9_ctab)(tab + (size_t)(w * NPOPS + kp) * L.total);
             const int n_units = (((iso_g[kp].n - 1) * K + 63) >> 6) * 4;
             double xmin = __builtin_inf();
             for (int u = wave; u < n_units; u += 4) {
@@ -296,7 +310,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     __syncthreads();
 #pragma unroll
     for (int kp = 0; kp < NPOPS; ++kp) {
-        const double *__restrict__ const t_wp = tab + (size_t)(w * NPOPS + kp) * L.total;
+        const b9_ctab t_wp = (b9_ctab)(tab + (size_t)(w * NPOPS + kp) * L.total);
         const int n_chunks = ((iso_g[kp].n - 1) * K + 63) >> 6;
         tmax[kp] = __builtin_fmax(__builtin_fmax(tmax[kp], s_tmax[kp][0][lane]), __builtin_fmax(s_tmax[kp][1][lane], __builtin_fmax(s_tmax[kp][2][lane], s_tmax[kp][3][lane])));
         const double xcut = fma(-2.0, tmax[kp], cut2);
@@ -316,9 +330,10 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
 
 #pragma unroll
     for (int kp = 0; kp < NPOPS; ++kp) {
-        const double *__restrict__ const t_wp = tab + (size_t)(w * NPOPS + kp) * L.total;
-        const double *__restrict__ const t_rows = t_wp + L.o_rows, *__restrict__ const t_nb = t_wp + L.o_nb;
-        const double *__restrict__ const t_box2 = t_wp + L.o_box2, *__restrict__ const t_nbmin16 = t_wp + L.o_nbmin16;
+        const double *__restrict__ const t_g = tab + (size_t)(w * NPOPS + kp) * L.total;      // (generic: the asynchronous row loads take addresses)
+        const b9_ctab t_wp = (b9_ctab)t_g;
+        const double *__restrict__ const t_rows = t_g + L.o_rows, *__restrict__ const t_nb = t_g + L.o_nb;
+        const b9_ctab t_box2 = t_wp + L.o_box2, t_nbmin16 = t_wp + L.o_nbmin16;
         const int n_chunks = ((iso_g[kp].n - 1) * K + 63) >> 6;
         // one chunk that passed level 1: this wave's sub-chunk, mass ratio by mass ratio
         auto chunk = [&](int c) {
@@ -440,7 +455,7 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                  int n_walkers, double cut2, int wsplit, int n_split_arg, double *__restrict__ shares)
 {
     star_marg_body<NFP, NPOPS, SAMPLE, SPLIT>(pk, st, (int)blockIdx.x, iso_data, iso_stride, mass_cap, partial, partial_stride, perstar, K, Q, ms, L,
-                                              n_walkers, cut2, wsplit, n_split_arg, shares, [&](int) { return MargSel{hdr, params, tab}; });
+                                              n_walkers, cut2, wsplit, n_split_arg, shares, MargSelPlain{MargSel{hdr, params, tab}});
 }
 
 // k_marg_merge: the stars of a SPLIT launch -- one wave per (star chunk, walker), lane = star: the n_split shares (ref, sum) of
@@ -448,9 +463,9 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
 // constant, populations, field-star mixture) and the chunk's partial sum formed: what k_star_marg's last wave does when one
 // workgroup holds the whole window.
 template <int NPOPS>
-__global__ __launch_bounds__(64) void k_marg_merge(DevStars st, const IsoHdr *__restrict__ hdr, const double *__restrict__ params,
-                                                   double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
-                                                   const double *__restrict__ shares, int n_split)
+__device__ __forceinline__ void marg_merge_body(const DevStars &st, const IsoHdr *__restrict__ hdr, const double *__restrict__ params,
+                                                double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
+                                                const double *__restrict__ shares, int n_split)
 {
     const int lane = threadIdx.x, sc = blockIdx.x, w = blockIdx.y;
     bool valid = true;
@@ -484,6 +499,14 @@ __global__ __launch_bounds__(64) void k_marg_merge(DevStars st, const IsoHdr *__
     }
     const double tot = wave_sum(v);
     if (lane == 0) partial[(size_t)w * partial_stride + sc] = tot;
+}
+
+template <int NPOPS>
+__global__ __launch_bounds__(64) void k_marg_merge(DevStars st, const IsoHdr *__restrict__ hdr, const double *__restrict__ params,
+                                                   double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
+                                                   const double *__restrict__ shares, int n_split)
+{
+    marg_merge_body<NPOPS>(st, hdr, params, partial, partial_stride, perstar, shares, n_split);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -655,18 +678,29 @@ __global__ __launch_bounds__(128) void k_marg_wd_table(DevPack pk, const IsoHdr 
     if (type == 0) wtab[(size_t)n_wp * 2 * steps * NFP + (size_t)wp * steps + (j - 1)] = log_prior_mass_dev(pk.log_mass_norm, m1);
 }
 
-template <int NFP, int NPOPS, bool SAMPLE>
-__global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
-                                                      const double *__restrict__ iso_data, long long iso_stride,
-                                                      int mass_cap, const double *__restrict__ params,
-                                                      double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
-                                                      int K, MargSample ms, const double *__restrict__ wtab)
+// (block_x, w): the four-star group and the walker -- the plain launch's (blockIdx.x, blockIdx.y); `select` as in
+// star_marg_body (its .tab is the WD-stage stars' node table), called by every thread of the workgroup
+template <int NFP, int NPOPS, bool SAMPLE, class Select>
+__device__ __forceinline__ void star_marg_wd_body(const DevPack &pk, const DevStars &st, int block_x, int w, int n_walkers,
+                                                  const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
+                                                  double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
+                                                  int K, const MargSample &ms, Select select)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), w = blockIdx.y;
-    const int k_wd = blockIdx.x * 4 + wave, n_wp = gridDim.y * NPOPS;
-    if (k_wd >= st.n_wd) return;
-    const int slot = st.wd_slot[k_wd], orig = st.perm[slot];
-    const double *par = params + (size_t)w * B9_NPARAM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k_wd = block_x * 4 + wave, n_wp = n_walkers * NPOPS;
+    const bool live = k_wd < st.n_wd;
+    select.issue(w);
+    const int slot = st.wd_slot[live ? k_wd : 0], orig = st.perm[slot];
+    double obs[NFP], wgt[NFP];
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) { obs[f] = st.obs[B9_SIDX(NFP, f, slot)]; wgt[f] = st.w[B9_SIDX(NFP, f, slot)]; }
+    const double c0m = st.c0m[slot], la = st.la[slot];
+    const int wd_type = st.flags[slot] & 1;
+    const MargSel sel = select.finish(w);
+    if (!live) return;
+    const IsoHdr *__restrict__ const hdr = sel.hdr;
+    const double *__restrict__ const wtab = sel.tab;
+    const double *par = sel.params + (size_t)w * B9_NPARAM;
     IsoView<NFP> iso[NPOPS];
     double tip_min;
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
@@ -674,11 +708,6 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
         if (lane == 0) { partial[(size_t)w * partial_stride + (st.mg_pad >> 6) + k_wd] = 0.0; if (perstar) perstar[(size_t)w * st.n + orig] = NEG_INF; }
         return;
     }
-    double obs[NFP], wgt[NFP];
-#pragma unroll
-    for (int f = 0; f < NFP; ++f) { obs[f] = st.obs[B9_SIDX(NFP, f, slot)]; wgt[f] = st.w[B9_SIDX(NFP, f, slot)]; }
-    const double c0m = st.c0m[slot], la = st.la[slot];
-    const int wd_type = st.flags[slot] & 1;
     double ll[NPOPS];
     Best best; best.key = NEG_INF; best.mass = 0.0; best.ratio = 0.0; best.pop = 0;
     const unsigned long long g_row = SAMPLE ? (unsigned long long)(ms.row0 + w) : 0ull;
@@ -740,4 +769,15 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
             if (ms.pop) ms.pop[o] = any ? best.pop : 0;
         }
     }
+}
+
+template <int NFP, int NPOPS, bool SAMPLE>
+__global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
+                                                      const double *__restrict__ iso_data, long long iso_stride,
+                                                      int mass_cap, const double *__restrict__ params,
+                                                      double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
+                                                      int K, MargSample ms, const double *__restrict__ wtab)
+{
+    star_marg_wd_body<NFP, NPOPS, SAMPLE>(pk, st, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, iso_data, iso_stride, mass_cap, partial, partial_stride,
+                                          perstar, K, ms, MargSelPlain{MargSel{hdr, params, wtab}});
 }
