@@ -334,6 +334,10 @@ static hipError_t launch_marg_step(const DevPack &pk, const DevStars &st, const 
     const int wd = st.n_wd > 0 ? ((st.n_wd + 3) / 4) * W : 0;
     const size_t lds = b9k_marg_step_lds(NFP, sd.mass_cap);
     if (lds > B9_MSTEP_LDS_MAX(NFP)) return hipErrorInvalidValue;
+    // this parity's two candidates, as the star roles read them (see MargStepSel)
+    const size_t rows = (size_t)W * NPOPS, c0 = (size_t)sd.set * 2;
+    const IsoHdr *hdr_rd = sd.cand_hdr + c0 * rows;
+    const double *par_rd = sd.cand_par + c0 * W * B9_NPARAM, *tab_rd = tab + c0 * rows * mx.L.total, *wd_rd = wd_tab ? wd_tab + c0 * wd_stride : nullptr;
     if (mx.n_split > 1) {
         hipLaunchKernelGGL((k_marg_step<NFP, NPOPS, true>), dim3(front + stars + wd), dim3(256), lds, stream, pk, st, sd, pr, mx, front, stars,
                            hdr_rd, par_rd, tab_rd, wd_rd);
