@@ -67,9 +67,9 @@ def logpost(pack_d, cl, priors, par, n_pops=1):
 
 
 def marg_perstar(pack_d, cl, par, K, Q, pop=0):
-    """Brute-force numpy statement of the marginalised per-star log-likelihood (MS/RGB-stage stars
-    only): log sum over primary nodes (K sub-steps per EEP interval, left endpoints) and mass ratios
-    j/Q of  prior(M1) * dM/Q * prod_f N(obs_f | combined_f, sigma_f^2).  Independent of the C oracle."""
+    """Brute-force numpy statement of the marginalised per-star log-likelihood of MS/RGB-stage stars
+    (WD-stage stars: marg_perstar_wd): log sum over primary nodes (K sub-steps per EEP interval, left endpoints) and mass
+    ratios j/Q of  prior(M1) * dM/Q * prod_f N(obs_f | combined_f, sigma_f^2).  Independent of the C oracle."""
     first, imass, imags = synth.derive_isochrone(pack_d, par[abi.P_LOGAGE], par[abi.P_FEH], par[abi.P_Y2 if pop else abi.P_Y])
     m_nodes, w_nodes = [], []
     for e in range(len(imass) - 1):
@@ -97,3 +97,61 @@ def marg_perstar(pack_d, cl, par, K, Q, pop=0):
             acc.append(lpm + g)
         out[i] = logsumexp(np.concatenate(acc))
     return out
+
+
+def marg_perstar_wd(pack_d, cl, par, K, pop=0):
+    """The same for the catalogue's WD-stage stars: M1 over (AGB tip, M_wd_up] in 8 K equal steps
+    (right endpoints tip + j dM, j = 1 .. 8 K), single stars, each through the WD branch of synth.forward_mags with the
+    star's own DA / DB flag:  log sum_j prior(M1_j) dM prod_f N(obs_f | wd_f(M1_j), sigma_f^2).  Entries of other stars: NaN."""
+    first, imass, imags = synth.derive_isochrone(pack_d, par[abi.P_LOGAGE], par[abi.P_FEH], par[abi.P_Y2 if pop else abi.P_Y])
+    tip, steps = imass[-1], 8 * K
+    dM = (pack_d["m_wd_up"] - tip) / steps
+    n = len(cl["mass1"])
+    out = np.full(n, np.nan)
+    if not dM > 0:
+        out[np.asarray(cl["stage"]) == abi.STAGE_WD] = -np.inf
+        return out
+    m_nodes = tip + dM * np.arange(1, steps + 1)
+    lpm = log_prior_mass(m_nodes, pack_d["m_wd_up"]) + np.log(dM)
+    sig = np.asarray(cl["sigma"]); used = sig > 0
+    var = np.where(used, sig ** 2, 1.0)
+    pred_by_type = {}
+    for i in np.nonzero(np.asarray(cl["stage"]) == abi.STAGE_WD)[0]:
+        ty = int(cl["wd_type"][i])
+        if ty not in pred_by_type:
+            pred_by_type[ty] = synth.forward_mags(pack_d, par, m_nodes, np.zeros(steps), np.full(steps, ty, int), pop=pop)
+        pred = pred_by_type[ty]
+        g = np.where(used[i], -0.5 * (np.log(2 * np.pi * var[i]) + (pred - cl["obs"][i]) ** 2 / var[i]), 0.0).sum(axis=1)
+        t = lpm + g
+        t = t[np.isfinite(t)]
+        out[i] = logsumexp(t) if len(t) else -np.inf
+    return out
+
+
+def marg_logpost(pack_d, cl, priors, par, K, Q, n_pops=1):
+    """(logpost, perstar) of the marginalised mode for one parameter row, every stage and one or two populations:
+    per star  logaddexp(log(1 - p) + log fs,  log p + [logaddexp over populations of log weight + marginal])."""
+    n = len(cl["mass1"])
+    lp = log_prior_cluster(priors, par, n_pops)
+    if not np.isfinite(lp):
+        return -np.inf, np.full(n, -np.inf)
+    wd = np.asarray(cl["stage"]) == abi.STAGE_WD
+    ll_pop = []
+    try:
+        for pop in range(n_pops):
+            ll = marg_perstar(pack_d, cl, par, K, Q, pop)
+            if wd.any():
+                ll = np.where(wd, marg_perstar_wd(pack_d, cl, par, K, pop), ll)
+            ll_pop.append(ll)
+    except ValueError:
+        return -np.inf, np.full(n, -np.inf)
+    ll = ll_pop[0]
+    if n_pops == 2:
+        lam = par[abi.P_LAMBDA]
+        with np.errstate(divide="ignore"):
+            ll = logsumexp(np.stack([np.log(lam) + ll_pop[0], np.log1p(-lam) + ll_pop[1]]), axis=0)
+    log_fs = -np.sum(np.log(cl["filter_prior_max"] - cl["filter_prior_min"]))
+    pm = cl["clust_prior"]
+    with np.errstate(divide="ignore"):
+        v = logsumexp(np.stack([np.log1p(-pm) + log_fs, np.log(pm) + ll]), axis=0)
+    return lp + v.sum(), v

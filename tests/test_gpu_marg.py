@@ -1,4 +1,4 @@
-"""GPU parity of the marginalised mode (k_star_marg, one wavefront per star) against the oracle's
+"""GPU parity of the marginalised mode (k_star_marg: one lane per star, four waves per 64 stars) against the oracle's
 brute-force definition of the same integral (oracle/b9_oracle.c::star_marg_loglike).
 [RECALL] BASE-9's marg.cpp restricts the secondary-mass range adaptively; that cannot be restated
 without the source, so both sides integrate the full (mass, mass-ratio) grid -- parity unpinned."""
@@ -118,4 +118,28 @@ def test_pruning_is_rigorous(n_pops, wd_frac, K, Q):
     err = np.abs(ps_a[fin] - ps_b[fin]) / np.maximum(1.0, np.abs(ps_b[fin]))
     assert err.max() <= 1e-12, err.max()
     np.testing.assert_allclose(lp_a, lp_b, rtol=1e-12)
+    eng.close()
+
+
+@pytest.mark.parametrize("name,walkers", [("C1", 1), ("C2", 8)])
+def test_marginalised_mode_is_bit_reproducible(name, walkers):
+    """Which terms enter a star's sum is a function of the data only (the pruning reference is the barrier-merged seed maxima
+    plus the wave's OWN running maximum), so repeated evaluations return the same bits for every star -- on the split
+    instance (C1: 157 star chunks, a chunk's window over 8 workgroups + k_marg_merge) and the unsplit one (C2) -- and two
+    runs of the fused sampler step (k_marg_step) give the same chain.  tools/soak_determinism.py --marg is the long version."""
+    from base_amd import engine, mcmc
+    cfg = synth.make_baseline_config(name)
+    eng = engine.Engine(cfg["pack"], cfg["stars"], cfg["priors"], abi.make_options(abi.MODE_MARGINALISED, 1, 4, 4))
+    rows = synth.walker_params(cfg["truth"], walkers, seed=11, scale=0.03)
+    lp0, ps0 = eng.logpost(rows, perstar=True)
+    assert np.all(np.isfinite(ps0))
+    for _ in range(20):
+        lp, ps = eng.logpost(rows, perstar=True)
+        assert np.array_equal(lp, lp0) and np.array_equal(ps, ps0)
+    free = np.array(mcmc.DEFAULT_FREE)
+    chol = np.diag([2e-5, 1e-4, 4e-5, 4e-5]) * 3.0
+    runs = [eng.mcmc_run_block(rows, lp0, np.arange(walkers), free, chol, 5, 0, 60) for _ in range(2)]
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert np.array_equal(a, b)
+    assert runs[0][4] == runs[1][4] and 0 < runs[0][4] < 60 * walkers
     eng.close()

@@ -214,6 +214,30 @@ def test_marginalised_mode_matches_numpy_brute_force():
     np.testing.assert_allclose(ps[0], want, rtol=1e-9, atol=1e-8)
 
 
+@pytest.mark.parametrize("n_pops,n_y,wd_frac,K,Q", [(1, 1, 0.25, 2, 3), (2, 3, 0.0, 2, 2), (2, 3, 0.2, 1, 3)])
+def test_marginalised_wd_stage_and_two_populations_match_numpy_brute_force(n_pops, n_y, wd_frac, K, Q):
+    """Third statement of the two pieces of the marginalised mode that had only two (oracle and kernel, one author): the
+    WD-stage stars' integral over (AGB tip, M_wd_up] through the WD branch (DA and DB), and the two-population mixture of
+    marginals -- numpy brute force over synth.forward_mags against the oracle, every star, 1e-10."""
+    pack_d, cl, pack, stars, priors, _ = build_problem("parsec", 5, n_stars=16, wd_frac=wd_frac, n_y=n_y, n_pops=n_pops,
+                                                       n_feh=3, n_age=4, n_eep=25, seed=12)
+    stage = np.asarray(cl["stage"])
+    if wd_frac > 0:     # both atmosphere types among the WD-stage stars
+        idx = np.nonzero(stage == abi.STAGE_WD)[0]
+        assert len(idx) >= 3
+        cl["wd_type"][idx[::2]] = 1
+        cl["wd_type"][idx[1::2]] = 0
+        stars = abi.make_stars(cl)
+    orc = oracle.Oracle(pack, stars, priors, abi.make_options(abi.MODE_MARGINALISED, n_pops, K, Q))
+    rows = synth.walker_params(cl["truth"], 2, seed=4, n_pops=n_pops, scale=0.05)
+    lp, ps = orc.logpost(rows, perstar=True)
+    for r in range(2):
+        want_lp, want = numpy_ref.marg_logpost(pack_d, cl, priors, rows[r], K, Q, n_pops)
+        assert np.all(np.isfinite(want))
+        np.testing.assert_allclose(ps[r], want, rtol=1e-10, atol=1e-10)
+        assert abs(lp[r] - want_lp) <= 1e-10 * max(1.0, abs(want_lp))
+
+
 def test_sample_mass_restatement_properties():
     """CPU-side pins of the sampleMass restatement: its Philox equals the numpy twin (itself pinned to the
     Random123 vectors in test_mcmc.py), draws are grid nodes, membership is what the marginal implies,
