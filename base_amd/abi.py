@@ -70,8 +70,8 @@ class b9_options(C.Structure):
 class b9_tuning(C.Structure):
     """Launch-plan tuning (include/base9_hip.h); all zeros = automatic."""
     _fields_ = [(n, C.c_int32) for n in ("tiles_per_block", "derive_parts", "derive_order", "heavy_parts", "two_launch_steps",
-                                         "marg_no_pruning", "timing_group", "plan_debug", "tree_depth")] + \
-               [("reserved", C.c_int32 * 7)]
+                                         "marg_no_pruning", "timing_group", "plan_debug", "tree_depth", "marg_piece_units")] + \
+               [("reserved", C.c_int32 * 6)]
 
 
 class b9_mcmc_block(C.Structure):

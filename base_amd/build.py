@@ -40,7 +40,7 @@ def _run(cmd: List[str]) -> None:
         sys.stderr.write(r.stderr)
 
 
-HIP_SOURCES = ("b9_kernels.hip", "b9_capi_ctx.cpp", "b9_capi_stage.cpp", "b9_capi_plan.cpp", "b9_capi_eval.cpp", "b9_capi_blocks.cpp")
+HIP_SOURCES = ("b9_kernels.hip", "b9_capi_ctx.cpp", "b9_capi_stage.cpp", "b9_capi_plan.cpp", "b9_capi_margplan.cpp", "b9_capi_eval.cpp", "b9_capi_blocks.cpp")
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:

@@ -72,7 +72,7 @@ int ensure_marg_table(b9_ctx *ctx, int n_walkers, int n_pops, int K, int Q)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_marg_wd_tab, need_wd * sizeof(double)));
         ctx->marg_wd_tab_cap = need_wd;
     }
-    const size_t need_sh = (size_t)n_walkers * (size_t)b9k_marg_shares_doubles(ctx->st.mg_pad / 64, n_pops);
+    const size_t need_sh = (size_t)n_walkers * (size_t)b9k_marg_shares_doubles(ctx->st.mg_n_pieces, n_pops);
     if (need_sh > ctx->marg_shares_cap) {
         if (ctx->d_marg_shares) (void)hipFree(ctx->d_marg_shares);
         ctx->d_marg_shares = nullptr; ctx->marg_shares_cap = 0;
@@ -98,7 +98,7 @@ int check_ready(b9_ctx *ctx)
     }
     if (ctx->opt.mode == B9_MODE_GIVEN_MASS && ctx->hs.min_mass1 <= 0.0)
         return fail(ctx, B9_ERR_INVALID, "given-mass mode needs mass1 > 0 for every star (the marginalised mode takes mass1 as a hint only)");
-    return B9_OK;
+    return ensure_marg_plan(ctx);
 }
 
 // event bracket of the dominant kernel's launch, every ctx->timing-th launch
@@ -179,6 +179,7 @@ void b9_ctx_destroy(b9_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx->pack_allocs);
     free_all(ctx->star_allocs);
+    free_all(ctx->marg_plan_allocs);
     void *bufs[] = {ctx->d_hdr, ctx->d_iso, ctx->d_partial, ctx->d_params, ctx->d_logpost, ctx->d_perstar, ctx->d_marg_tab, ctx->d_marg_wd_tab, ctx->d_marg_shares,
                     ctx->d_tree_hdr, ctx->d_tree_iso, ctx->d_tree_par, ctx->d_tree_partial};
     for (void *p : bufs) if (p) (void)hipFree(p);
@@ -201,8 +202,10 @@ const char *b9_last_error(const b9_ctx *ctx) { return ctx ? ctx->err.c_str() : g
 int b9_set_priors(b9_ctx *ctx, const b9_priors *p)
 {
     if (!ctx || !p) return B9_ERR_INVALID;
+    if (block_outstanding(ctx)) return fail(ctx, B9_ERR_STATE, kBlockOutstanding);
     for (int k = 0; k < 12; ++k) { ctx->pr.mean[k] = p->mean[k]; ctx->pr.var[k] = p->var[k]; }
     ctx->pr.log_age_min = p->log_age_min; ctx->pr.log_age_max = p->log_age_max;
+    ctx->marg_plan_ok = false;         // (the marginalised catalogue plan is measured at the prior means)
     return B9_OK;
 }
 
@@ -230,6 +233,7 @@ int b9_set_options(b9_ctx *ctx, const b9_options *o)
     if (o->mode != B9_MODE_GIVEN_MASS && o->mode != B9_MODE_MARGINALISED) return fail(ctx, B9_ERR_INVALID, "unknown mode");
     if (o->n_pops != 1 && o->n_pops != 2) return fail(ctx, B9_ERR_INVALID, "n_pops must be 1 or 2");
     ctx->opt = *o;
+    ctx->marg_plan_ok = false;
     return B9_OK;
 }
 

@@ -112,6 +112,8 @@ void apply_tuning(b9_ctx *ctx, const b9_tuning &t)
     ctx->timing_group = t.timing_group > 0 ? t.timing_group : 8;
     ctx->plan_debug = t.plan_debug != 0;
     ctx->tree_depth = std::max(0, std::min(B9_TREE_MAX_DEPTH, t.tree_depth));
+    if (ctx->marg_piece_units != std::max(0, t.marg_piece_units)) ctx->marg_plan_ok = false;
+    ctx->marg_piece_units = std::max(0, t.marg_piece_units);
     ctx->step_occ_key = -1; ctx->plan_debug_key = -1; ctx->tree_occ_key = -1;
 }
 
@@ -135,6 +137,7 @@ bool tuning_from_env(b9_tuning *t)
     num("B9_TIMING_GROUP", &t->timing_group);
     num("B9_PLAN_DEBUG", &t->plan_debug);
     num("B9_TREE_DEPTH", &t->tree_depth);
+    num("B9_MARG_PIECE_UNITS", &t->marg_piece_units);
     return any;
 }
 

@@ -234,7 +234,12 @@ int build_stars(b9_ctx *ctx)
         if ((rc = upload(ctx, ctx->star_allocs, mg_perm.data(), mg_perm.size(), &st.mg_perm))) return rc;
         if ((rc = upload(ctx, ctx->star_allocs, order.data(), order.size(), &st.marg_order))) return rc;
     }
+    st.mg_n_pieces = 0; st.mg_piece = nullptr; st.mg_share_base = nullptr;
     ctx->st = st;
+    ctx->marg_order_spread = st.marg_order;
+    ctx->marg_plan_ok = false;
+    free_all(ctx->marg_plan_allocs);
+    ctx->marg_cost.clear();
     ctx->n_wd_stage = 0;
     for (int i = 0; i < n; ++i) ctx->n_wd_stage += h.stage[i] == B9_STAGE_WD;
     ctx->stars_dirty = false;
@@ -299,6 +304,7 @@ int b9_load_pack(b9_ctx *ctx, const b9_pack *p)
     if ((rc = upload(ctx, A, p->feh, p->n_feh, &d.feh))) return rc;
     if ((rc = upload(ctx, A, p->y, p->n_y, &d.y))) return rc;
     if ((rc = upload(ctx, A, p->log_age, p->n_age, &d.log_age))) return rc;
+    ctx->h_feh.assign(p->feh, p->feh + p->n_feh); ctx->h_y.assign(p->y, p->y + p->n_y); ctx->h_log_age.assign(p->log_age, p->log_age + p->n_age);
     if ((rc = upload(ctx, A, p->iso_first_eep, n_iso, &d.first))) return rc;
     if ((rc = upload(ctx, A, p->iso_n_eep, n_iso, &d.cnt))) return rc;
     std::vector<long long> off(p->iso_offset, p->iso_offset + n_iso);

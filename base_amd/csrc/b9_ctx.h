@@ -3,6 +3,7 @@
 //   b9_capi_ctx.cpp     context life cycle, options / tuning, work buffers, introspection, timing
 //   b9_capi_stage.cpp   validation and staging of the model pack and the star catalogue into HBM (b9_load_pack, b9_load_stars)
 //   b9_capi_plan.cpp    launch plans: canonical tile groups, the fused step's and the tree step's plans
+//   b9_capi_margplan.cpp  the marginalised mode's catalogue plan: measured dispatch order, pieces of small catalogues
 //   b9_capi_eval.cpp    b9_logpost / b9_logpost_device / b9_sample_mass / b9_derive_isochrone
 //   b9_capi_blocks.cpp  the sampler's device-resident blocks (fused, tree-speculative, two-launch), b9_mcmc_run_block / b9_mcmc_wait
 #pragma once
@@ -63,6 +64,14 @@ struct b9_ctx {
     size_t marg_wd_tab_cap = 0;
     double *d_marg_shares = nullptr; // ... and the per-star shares of a split k_star_marg launch (small catalogues)
     size_t marg_shares_cap = 0;
+    // the marginalised mode's catalogue plan (b9_capi_margplan.cpp): measured dispatch order and pieces; remade after the stars,
+    // the pack, the priors or the options change
+    bool marg_plan_ok = false;
+    int marg_piece_units = 0;                 // b9_tuning.marg_piece_units: 0 = default
+    std::vector<void *> marg_plan_allocs;
+    const int *marg_order_spread = nullptr;   // the load-time order (photometric spread), owned by star_allocs
+    std::vector<double> marg_cost;            // measured cost per star chunk (units; empty: not measured)
+    std::vector<double> h_log_age, h_feh, h_y;   // host copies of the pack's grid axes (the plan's reference row is clamped into them)
     struct McmcSlot {                // fused step: one enqueued block (device block, pinned mirror, completion event)
         void *d = nullptr, *h = nullptr, *h_dev = nullptr;   // h_dev: the pinned mirror as the device sees it (mapped)
         size_t cap = 0, hcap = 0;
@@ -152,6 +161,9 @@ int ensure_marg_table(b9_ctx *ctx, int n_walkers, int n_pops, int K, int Q);
 int check_ready(b9_ctx *ctx);
 int timing_begin(b9_ctx *ctx, hipStream_t stream, long *slot);
 int timing_end(b9_ctx *ctx, hipStream_t stream, long slot);
+
+// ---- b9_capi_margplan.cpp
+int ensure_marg_plan(b9_ctx *ctx);
 
 // ---- b9_capi_plan.cpp
 struct Groups { int group_tiles, n_groups; };

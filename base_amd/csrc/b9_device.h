@@ -83,9 +83,19 @@ struct DevStars {
     const double *mg_so, *mg_sw;     // [mg_pad / 64][nfp][64]: sqrt(w) obs, sqrt(w) (w = 1 / sigma^2; 0 = unused filter)
     const double *mg_c0m, *mg_la;    // [mg_pad]
     const int *mg_perm;              // [mg_pad] original index of the star, -1 = empty
-    // ... and the order in which the chunks are dispatched: widest photometric spread (= largest union) first, so that the
-    // launch does not end on its heaviest workgroups
+    // ... and the order in which the chunks are dispatched: most expensive first, so that the launch does not end on its
+    // heaviest workgroups.  Cost = the node-table units a chunk's waves evaluate at the catalogue's REFERENCE parameter row
+    // (the prior means), counted once per (catalogue, pack, priors, options) by a pass of the kernel itself
+    // (b9_capi_margplan.cpp); before that pass, and when the reference row lies outside the grid: photometric spread.
     const int *marg_order;           // [mg_pad / 64]
+    // Small catalogues (fewer star chunks than the chip has workgroup slots): a chunk's window is shared by 1 .. 16 workgroups
+    // ("pieces": piece s of n takes the node chunks s, s + n, ...), as many as its measured cost asks for, so that the pieces
+    // cost about the same and the launch does not last as long as its heaviest chunk of giants.  mg_piece: dispatch order
+    // (most expensive piece first) of (chunk | piece << 20 | pieces of the chunk << 25); mg_share_base[c]: first piece id of
+    // chunk c (prefix sums; [n_chunks + 1]).  mg_n_pieces == 0: no split -- one workgroup per chunk, in marg_order.
+    int mg_n_pieces;
+    const int *mg_piece;             // [mg_n_pieces]
+    const int *mg_share_base;        // [mg_pad / 64 + 1]
 };
 
 #define B9_SIDX(nfp, f, i) ((((size_t)((i) >> 6) * (nfp)) + (f)) * 64 + ((i) & 63))

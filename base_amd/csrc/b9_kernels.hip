@@ -181,24 +181,13 @@ hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial,
 
 // doubles of one (walker, population)'s node table (MargLayout, b9_device.h)
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q) { return marg_layout(nfp, mass_cap, K, Q).total; }
-// workgroups per (star chunk, walker) of k_star_marg: by catalogue size (star chunks x populations) and grid (K x Q) -- never by
-// the walkers on the GPU.  1 from 512 chunk-populations up (32k stars of one population), 4 from 384, 8 below; doubled (at most
-// 16) from K Q = 64 nodes per EEP interval up: a finer grid is a longer window per star.  Measured, ms per b9_logpost call at
-// 4 x 4, one workgroup per chunk -> split: 10k stars x 1 walker 0.18 -> 0.07 (8 x 8 grid: 0.47 -> 0.11), 200 stars 0.14 ->
-// 0.06, 20k x 8 walkers 0.21 -> 0.19, 10k x 8 walkers 0.13; 30k x 2 populations x 8 walkers would lose (0.27 -> 0.37: 938
-// chunk-populations, left unsplit).  us per sampler step of ONE chain at 4 x 4: 10k stars 4 splits 69, 8: 52, 16: 57; 20k stars
-// (313 chunks) 4 splits 88, 8: 73 -- with 8 walkers on the GPU the same catalogue pays 0.18 -> 0.21 ms per call for that.
-int b9k_marg_split(int n_star_chunks, int n_pops, int K, int Q)
-{
-    const int eff = n_star_chunks * n_pops;
-    int s = eff >= 512 ? 1 : (eff >= 384 ? 4 : 8);
-    if (s > 1 && K * Q >= 64) s = s * 2 > 16 ? 16 : s * 2;
-    return s;
-}
-long long b9k_marg_shares_doubles(int n_star_chunks, int n_pops)      // per walker: room for 16 splits where any grid splits at all
-{
-    return n_star_chunks * n_pops >= 512 ? 128 : (long long)n_star_chunks * 16 * n_pops * 128;
-}
+// Does a catalogue of n_star_chunks x n_pops split its star chunks' windows over several workgroups (DevStars::mg_piece)?  Below 512
+// chunk-populations (32k stars of one population) -- a function of the CATALOGUE, never of the walkers on the GPU: it decides how a
+// star's sum rounds.  How many workgroups each chunk gets is the catalogue plan's business (b9_capi_margplan.cpp).  Measured in round 4
+// with a uniform split, ms per b9_logpost call at 4 x 4, one workgroup per chunk -> split: 10k stars x 1 walker 0.18 -> 0.07, 200 stars
+// 0.14 -> 0.06, 20k x 8 walkers 0.21 -> 0.19; 30k x 2 populations x 8 walkers would lose (0.27 -> 0.37: 938 chunk-populations, unsplit).
+int b9k_marg_split(int n_star_chunks, int n_pops) { return n_star_chunks * n_pops < 512 ? 1 : 0; }
+long long b9k_marg_shares_doubles(int n_pieces, int n_pops) { return (long long)std::max(1, n_pieces) * n_pops * 128; }      // per walker
 long long b9k_marg_wd_table_doubles(int nfp, int K) { return (long long)8 * K * (2 * nfp + 1); }       // per (walker, population)
 
 template <int NFP, int NPOPS, bool SAMPLE>
@@ -228,22 +217,22 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     const int wsplit = n_walkers % 2 == 0 ? 2 : 1;
     const int csplit = 8 / wsplit, n_chunks = st.mg_pad / 64;
     // SPLIT: a small catalogue's launch lasts as long as its heaviest star chunk (giants: 100 us where the median chunk takes
-    // 40) while most of the chip idles, so n_split workgroups share a chunk's window (k_star_marg / k_marg_merge).  A function
-    // of the CATALOGUE only -- it decides how a star's sum rounds, and a walker's chain must not depend on how many walkers
-    // share the GPU.  The sampleMass draws keep one workgroup per chunk.
-    const int n_split = SAMPLE ? 1 : b9k_marg_split(n_chunks, NPOPS, K, Q);
-    if (n_split > 1 && !shares) return hipErrorInvalidValue;
-    const int per_xcd = ((n_chunks + csplit - 1) / csplit) * (n_walkers / wsplit) * n_split;
+    // 40) while most of the chip idles, so several workgroups share a chunk's window (DevStars::mg_piece; k_marg_merge).  A
+    // function of the CATALOGUE only -- it decides how a star's sum rounds, and a walker's chain must not depend on how many
+    // walkers share the GPU.  The sampleMass draws keep one workgroup per chunk.
+    const bool split = !SAMPLE && st.mg_n_pieces > 0;
+    if (split && !shares) return hipErrorInvalidValue;
+    const int per_xcd = (((split ? st.mg_n_pieces : n_chunks) + csplit - 1) / csplit) * (n_walkers / wsplit);
     const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
-    if (n_split > 1)
+    if (split)
         hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, !SAMPLE>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
-                           mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, n_split, shares);
+                           mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, shares);
     else
         hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, false>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
-                           mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, 1, shares);
-    if (n_split > 1)
+                           mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, shares);
+    if (split)
         hipLaunchKernelGGL((k_marg_merge<NPOPS>), dim3(n_chunks, n_walkers), dim3(64), 0, stream, st, hdr, d_params, partial, partial_stride,
-                           perstar, shares, n_split);
+                           perstar, shares);
     if (st.n_wd > 0) {        // the catalogue's WD-stage stars: their node table (2 x 8 K WD chains per walker and population), then a wave per star
         if (!wd_tab) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_marg_wd_table<NFP>), dim3(n_walkers * NPOPS, (8 * K + 63) / 64), dim3(128), 0, stream, pk, hdr, iso_data, iso_stride,
@@ -252,6 +241,34 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
                            iso_data, iso_stride, mass_cap, d_params, partial, partial_stride, perstar, K, ms, wd_tab);
     }
     return hipGetLastError();
+}
+
+// The catalogue plan's counting pass: the unsplit star kernel on ONE row (the reference row), every wave leaving the number of
+// (16 nodes x one mass ratio) units it evaluated in cost[star chunk][4].
+template <int NFP, int NPOPS>
+static hipError_t launch_star_marg_cost(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, int mass_cap, const double *d_params,
+                                        double *partial, long long partial_stride, int K, int Q, bool prune, const double *tab, unsigned *cost, hipStream_t stream)
+{
+    MargSample ms{};
+    ms.cost = cost;
+    const MargLayout L = marg_layout(NFP, mass_cap, K, Q);
+    const int n_chunks = st.mg_pad / 64;
+    const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
+    hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, false, false, true>), dim3(8 * ((n_chunks + 7) / 8)), dim3(256), 0, stream, pk, st, hdr, (const double *)nullptr, 0ll,
+                       mass_cap, d_params, partial, partial_stride, (double *)nullptr, K, Q, ms, tab, L, 1, cut2, 1, (double *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t b9k_star_marg_cost(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, int mass_cap, const double *d_params, int n_pops,
+                              double *partial, long long partial_stride, int K, int Q, bool prune, const double *tab, unsigned *cost, hipStream_t stream)
+{
+#define CS_ARGS pk, st, hdr, mass_cap, d_params, partial, partial_stride, K, Q, prune, tab, cost, stream
+#define CS2(NFP) launch_star_marg_cost<NFP, 2>(CS_ARGS)
+#define CS1(NFP) launch_star_marg_cost<NFP, 1>(CS_ARGS)
+    B9_SWITCH_NFP(CS2, CS1)
+#undef CS1
+#undef CS2
+#undef CS_ARGS
 }
 
 template <int NFP, int NPOPS>
@@ -324,13 +341,13 @@ static hipError_t launch_marg_step(const DevPack &pk, const DevStars &st, const 
     mx.n_wd_blocks = st.n_wd > 0 ? (8 * K + 127) / 128 : 0;
     mx.wsplit = W % 2 == 0 ? 2 : 1;
     const int csplit = 8 / mx.wsplit, n_chunks = st.mg_pad / 64;
-    mx.n_split = b9k_marg_split(n_chunks, NPOPS, K, Q);
-    if (mx.n_split > 1 && !shares) return hipErrorInvalidValue;
+    const bool split = st.mg_n_pieces > 0;
+    if (split && !shares) return hipErrorInvalidValue;
     if (st.n_wd > 0 && !wd_tab) return hipErrorInvalidValue;
     mx.cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
     mx.tab = tab; mx.wd_tab = wd_tab; mx.wd_stride = wd_stride; mx.shares = shares;
     const int front = (W + W * 2 * NPOPS * (mx.n_chunks_cap + mx.n_wd_blocks) + 7) / 8 * 8;
-    const int stars = 8 * (((n_chunks + csplit - 1) / csplit) * (W / mx.wsplit) * mx.n_split);
+    const int stars = 8 * ((((split ? st.mg_n_pieces : n_chunks) + csplit - 1) / csplit) * (W / mx.wsplit));
     const int wd = st.n_wd > 0 ? ((st.n_wd + 3) / 4) * W : 0;
     const size_t lds = b9k_marg_step_lds(NFP, sd.mass_cap);
     if (lds > B9_MSTEP_LDS_MAX(NFP)) return hipErrorInvalidValue;
@@ -338,7 +355,7 @@ static hipError_t launch_marg_step(const DevPack &pk, const DevStars &st, const 
     const size_t rows = (size_t)W * NPOPS, c0 = (size_t)sd.set * 2;
     const IsoHdr *hdr_rd = sd.cand_hdr + c0 * rows;
     const double *par_rd = sd.cand_par + c0 * W * B9_NPARAM, *tab_rd = tab + c0 * rows * mx.L.total, *wd_rd = wd_tab ? wd_tab + c0 * wd_stride : nullptr;
-    if (mx.n_split > 1) {
+    if (split) {
         hipLaunchKernelGGL((k_marg_step<NFP, NPOPS, true>), dim3(front + stars + wd), dim3(256), lds, stream, pk, st, sd, pr, mx, front, stars,
                            hdr_rd, par_rd, tab_rd, wd_rd);
         hipLaunchKernelGGL((k_marg_step_merge<NPOPS>), dim3(n_chunks, W), dim3(64), 0, stream, st, sd, mx);

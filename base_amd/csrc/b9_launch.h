@@ -49,10 +49,13 @@ hipError_t b9k_star_marg(const DevPack &pk, const DevStars &st, const IsoHdr *hd
                          double *perstar, int K, int Q, const B9MargSample *smp, bool prune /* false: every node of every star is evaluated */,
                          double *tab /* the call's node table: n_walkers * n_pops * b9k_marg_table_doubles(nfp, mass_cap, K, Q) doubles */,
                          double *wd_tab /* the WD-stage stars' node table: n_walkers * n_pops * b9k_marg_wd_table_doubles(nfp, K) doubles (used when the catalogue has WD-stage stars) */,
-                         double *shares /* per-star shares of split launches: n_walkers * b9k_marg_shares_doubles(star chunks, n_pops) doubles */,
+                         double *shares /* per-star shares of split launches: n_walkers * b9k_marg_shares_doubles(pieces, n_pops) doubles */,
                          hipStream_t stream);
-int b9k_marg_split(int n_star_chunks, int n_pops, int K, int Q);
-long long b9k_marg_shares_doubles(int n_star_chunks, int n_pops);
+int b9k_marg_split(int n_star_chunks, int n_pops);           // 1: the catalogue's star chunks are split into pieces (DevStars::mg_piece)
+long long b9k_marg_shares_doubles(int n_pieces, int n_pops);   // per walker
+// the catalogue plan's counting pass (one row, unsplit): cost[star chunk][4] = units each wave evaluated
+hipError_t b9k_star_marg_cost(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, int mass_cap, const double *d_params, int n_pops,
+                              double *partial, long long partial_stride, int K, int Q, bool prune, const double *tab, unsigned *cost, hipStream_t stream);
 long long b9k_marg_table_doubles(int nfp, int mass_cap, int K, int Q);
 long long b9k_marg_wd_table_doubles(int nfp, int K);
 

@@ -29,7 +29,7 @@ struct MargStep {
     int K, Q;
     int n_chunks_cap;         // node chunks of the longest isochrone = table builders per (walker, candidate, population)
     int n_wd_blocks;          // WD-table builders per (walker, candidate, population): ceil(8 K / 128); 0 = no WD-stage stars
-    int wsplit, n_split;
+    int wsplit;
     double cut2;
     MargLayout L;
     double *tab;              // [2 parities][2 candidates][W * pops][L.total]
@@ -111,13 +111,16 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
     __shared__ double s_par[B9_NPARAM], s_z[12];
     __shared__ double s_box[4][2][NFP];
     double *const s_mass = smem, *const s_prim = smem + mass_cap + 8, *const s_sec = s_prim + 65 * NFP + (size_t)wave * B9_MSTEP_SEC_ROWS * NFP;
+    HSTAMP(0);
     if (wave == 0) candidate_row_wave0(sd, w, cand, s_par, s_z);
     __syncthreads();
+    HSTAMP(1);
     const size_t rows = (size_t)W * n_pops, cset = (size_t)((sd.set ^ 1) * 2 + cand);
     const int wp = w * n_pops + pop;
     if (c == 0 && pop == 0 && tid < B9_NPARAM) sd.cand_par[(cset * W + w) * B9_NPARAM + tid] = s_par[tid];
     CornerRegs cr;
     IsoHdr h = marg_header(pk, s_par, pop, mass_cap, cr);
+    HSTAMP(2);
     IsoHdr *hp = sd.cand_hdr + cset * rows + wp;
     if (!h.valid) { if (c == 0 && tid == 0) *hp = h; return; }
     const int n = h.n, n_nodes = (n - 1) * K, ny = pk.n_y > 1 ? 2 : 1;
@@ -134,6 +137,7 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
     if (tid < 8) s_mass[n + tid] = __builtin_inf();                     // find_bracket's masked over-read
     if (lane < NFP) { s_box[jl][0][lane] = __builtin_inf(); s_box[jl][1][lane] = NEG_INF; }
     __syncthreads();
+    HSTAMP(3);
     if (c == 0 && tid == 0) { h.agb_tip = s_mass[n - 1]; *hp = h; }
     const double mod = s_par[B9_P_MOD], av = s_par[B9_P_ABS];
     double *out = mx.tab + (cset * rows + wp) * mx.L.total;
@@ -209,6 +213,7 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
             if (lane == 0) { s_box[jl][0][f] = __builtin_fmin(s_box[jl][0][f], lo); s_box[jl][1][f] = __builtin_fmax(s_box[jl][1][f], hi); }
         }
     }
+    HSTAMP(4);
     if (jl == 0) {                // nb = -2 log(prior(m1) dM / Q) of every node, and its minima
         const double nb = ok ? -2.0 * (log_prior_mass_dev(pk.log_mass_norm, m1) + log_pos(dM / Q)) : __builtin_inf();
         out[L.o_nb + node] = nb;
@@ -226,6 +231,7 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
         double *b1 = out + L.o_box1 + (size_t)c * 2 * NFP;
         b1[tid] = lo <= hi ? lo : 0.0; b1[NFP + tid] = lo <= hi ? hi : 0.0;
     }
+    HSTAMP(5);
 }
 
 // WD-table builder: k_marg_wd_table's rows for (walker w, candidate cand, population pop), mass steps
@@ -300,46 +306,59 @@ struct MargStepSel {
 };
 
 template <int NFP, int NPOPS, bool SPLIT>
-__global__ __launch_bounds__(256, B9_MSTEP_WAVES(NFP, NPOPS))
-void k_marg_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, MargStep mx, int front_blocks, int star_blocks,
-                 const IsoHdr *__restrict__ hdr_rd, const double *__restrict__ par_rd, const double *__restrict__ tab_rd, const double *__restrict__ wd_rd)
+__device__ __forceinline__ int marg_step_body(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, const MargStep &mx,
+                                              int front_blocks, int star_blocks, const IsoHdr *__restrict__ hdr_rd, const double *__restrict__ par_rd,
+                                              const double *__restrict__ tab_rd, const double *__restrict__ wd_rd, double *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int W = sd.n_walkers;
     int b = blockIdx.x;
     if (b < front_blocks) {
-        if (MSTEP_NO_FRONT) return;
-        if (b < W) { step_derive(pk, sd, pr, b, 0, 0, 0, 1, nullptr, 1); return; }      // the writer of walker b
+        if (MSTEP_NO_FRONT) return 3;
+        if (b < W) { step_derive(pk, sd, pr, b, 0, 0, 0, 1, nullptr, 1); return 4; }      // the writer of walker b
         b -= W;
         const int n_tab = W * 2 * NPOPS * mx.n_chunks_cap;
         if (b < n_tab) {        // b = ((w * 2 + cand) * NPOPS + pop) * n_chunks_cap + c
             const int c = b % mx.n_chunks_cap; b /= mx.n_chunks_cap;
             const int pop = b % NPOPS; b /= NPOPS;
             marg_build_table<NFP>(pk, sd, mx, b >> 1, b & 1, pop, c, smem);
-            return;
+            return 2;
         }
         b -= n_tab;
         if (b < W * 2 * NPOPS * mx.n_wd_blocks) {
             const int blk = b % mx.n_wd_blocks; b /= mx.n_wd_blocks;
             const int pop = b % NPOPS; b /= NPOPS;
             marg_build_wd_table<NFP>(pk, sd, mx, b >> 1, b & 1, pop, blk);
+            return 5;
         }
-        return;
+        return 3;
     }
     b -= front_blocks;
-    if (MSTEP_NO_STARS) return;
+    if (MSTEP_NO_STARS) return 3;
     __shared__ int s_sel;
     MargStepSel select{sd, mx, &s_sel, b >= star_blocks, hdr_rd, par_rd, tab_rd, wd_rd, {}};
     double *const partial = sd.partial + (size_t)sd.set * (sd.partial_stride / 2);
     const MargSample ms{};
     if (b < star_blocks) {
-        star_marg_body<NFP, NPOPS, false, SPLIT>(pk, st, b, nullptr, 0, sd.mass_cap, partial, sd.partial_stride, nullptr, mx.K, mx.Q, ms, mx.L,
-                                                 W, mx.cut2, mx.wsplit, mx.n_split, mx.shares, select);
-        return;
+        star_marg_body<NFP, NPOPS, false, SPLIT, false>(pk, st, b, nullptr, 0, sd.mass_cap, partial, sd.partial_stride, nullptr, mx.K, mx.Q, ms, mx.L,
+                                                        W, mx.cut2, mx.wsplit, mx.shares, select);
+        return 0;
     }
     b -= star_blocks;
     const int nb = (st.n_wd + 3) / 4;                        // WD-stage stars: b = w * ceil(n_wd / 4) + group of four
     star_marg_wd_body<NFP, NPOPS, false>(pk, st, b % nb, b / nb, W, nullptr, 0, sd.mass_cap, partial, sd.partial_stride, nullptr, mx.K, ms, select);
+    return 1;
+}
+
+
+template <int NFP, int NPOPS, bool SPLIT>
+__global__ __launch_bounds__(256, B9_MSTEP_WAVES(NFP, NPOPS))
+void k_marg_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, MargStep mx, int front_blocks, int star_blocks,
+                 const IsoHdr *__restrict__ hdr_rd, const double *__restrict__ par_rd, const double *__restrict__ tab_rd, const double *__restrict__ wd_rd)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    B9_GANTT_ENTER();
+    const int role = marg_step_body<NFP, NPOPS, SPLIT>(pk, st, sd, pr, mx, front_blocks, star_blocks, hdr_rd, par_rd, tab_rd, wd_rd, smem);
+    B9_GANTT_EXIT(sd.step, role);
 }
 
 // The per-star shares of a split k_marg_step launch merged (k_marg_merge's sums), against the candidate that launch's
@@ -350,5 +369,5 @@ __global__ __launch_bounds__(64) void k_marg_step_merge(DevStars st, StepDev sd,
     const int w = blockIdx.y, W = sd.n_walkers;
     const size_t cset = (size_t)(sd.set * 2 + (sd.state[((size_t)sd.set * W + w) * B9_STATE_STRIDE + B9_ST_SEL] != 0.0 ? 1 : 0));
     marg_merge_body<NPOPS>(st, sd.cand_hdr + cset * W * NPOPS, sd.cand_par + cset * W * B9_NPARAM,
-                           sd.partial + (size_t)sd.set * (sd.partial_stride / 2), sd.partial_stride, nullptr, mx.shares, mx.n_split);
+                           sd.partial + (size_t)sd.set * (sd.partial_stride / 2), sd.partial_stride, nullptr, mx.shares);
 }

@@ -56,6 +56,7 @@ struct MargSample {
     int *pop;                        // [rows][n_stars] or null
     unsigned k0, k1;
     long long row0;                  // global index of row 0 (RNG counter)
+    unsigned *cost;                  // COST instance (the catalogue plan's counting pass): [star chunk][4 waves] units evaluated
 };
 
 struct Best { double key, mass, ratio; int pop; };
@@ -228,14 +229,13 @@ struct MargSelPlain {
     __device__ __forceinline__ MargSel finish(int) const { return s; }
 };
 
-template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, class Select>
+template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, bool COST, class Select>
 __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars &st, int block_id,
                  const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
                  double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
                  int K, int Q, const MargSample &ms, const MargLayout &L,
-                 int n_walkers, double cut2, int wsplit, int n_split_arg, double *__restrict__ shares, Select select)
+                 int n_walkers, double cut2, int wsplit, double *__restrict__ shares, Select select)
 {
-    const int n_split = SPLIT ? n_split_arg : 1;          // (a compile-time 1 in the unsplit instance: its code is the one-workgroup kernel's)
     __shared__ double s_tmax[NPOPS][4][64], s_ref[NPOPS][4][64], s_sm[NPOPS][4][64];
     __shared__ unsigned long long s_mask[NPOPS][B9_MARG_MASK_WORDS];
     __shared__ double s_bkey[SAMPLE ? 4 : 1][64], s_bmass[SAMPLE ? 4 : 1][64], s_bratio[SAMPLE ? 4 : 1][64];
@@ -252,16 +252,18 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     const int xcd = block_id & 7, i_x = block_id >> 3;
     const int csplit = 8 / wsplit, wg_n = n_walkers / wsplit;           // chunk groups; walkers per group
     const int a = xcd % wsplit, b = xcd / wsplit;
-    // SPLIT (small catalogues, b9k_star_marg): n_split workgroups share one (star chunk, walker) -- workgroup s takes the node
-    // chunks c = s, s + n_split, ... of every star's window and leaves its per-star share (ref, sum) in `shares` for
-    // k_marg_merge; the splits of a chunk are neighbours in dispatch order on one XCD.
-    const int i_s = i_x / n_split, split = i_x - i_s * n_split;
-    const int p_local = i_s / wg_n, wl = i_s - p_local * wg_n;
+    // SPLIT (small catalogues; DevStars::mg_piece): the dispatch position names a PIECE -- workgroup `split` of the n_split that
+    // share one (star chunk, walker) takes the node chunks c = split, split + n_split, ... of every star's window and leaves
+    // its per-star share (ref, sum) in `shares` for k_marg_merge.  (n_split is a compile-time 1 in the unsplit instance: its
+    // code is the one-workgroup kernel's.)
+    const int p_local = i_x / wg_n, wl = i_x - p_local * wg_n;
     const int w = wl * wsplit + a;
     const int pos = p_local * csplit + b;
-    if (pos * 64 >= st.mg_pad) return;
+    if (SPLIT ? pos >= st.mg_n_pieces : pos * 64 >= st.mg_pad) return;
+    const int piece = SPLIT ? st.mg_piece[pos] : 0;
+    const int split = SPLIT ? (piece >> 20) & 31 : 0, n_split = SPLIT ? (piece >> 25) & 63 : 1;      // (at most 32 pieces)
     select.issue(w);
-    const int sc = st.marg_order[pos];
+    const int sc = SPLIT ? piece & 0xFFFFF : st.marg_order[pos];
     const int slot = sc * 64 + lane;                                // (slot of the marginalised mode's own copy: DevStars::mg_*)
     // the star's own words are requested before anything that depends on the walker's candidate
     const int orig = st.mg_perm[slot];
@@ -325,6 +327,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
 
     Best best; best.key = NEG_INF; best.mass = 0.0; best.ratio = 0.0; best.pop = 0;
     const unsigned long long g_row = SAMPLE ? (unsigned long long)(ms.row0 + w) : 0ull;
+    unsigned n_cost = 0;                                 // COST: (16 nodes x one mass ratio) units this wave evaluates
     double lw_pop[2] = {0.0, 0.0};                       // log weight of the population in the key
     if (SAMPLE && NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; lw_pop[0] = log(lam); lw_pop[1] = log1p(-lam); }
 
@@ -349,6 +352,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
                 if (__ballot(lb2 + nbm < xcut) == 0ull) continue;
                 MSTAT(3, 1);
                 MLIFE_UNIT();
+                if (COST) ++n_cost;
                 const double *__restrict__ const rowp = t_rows + ((size_t)u * Q + j) * 16 * NFP;
                 // one row's term for every lane (the 64 stars), into the lanes that still count it
                 auto term = [&](const SRow<NFP> &r, int i) {
@@ -402,6 +406,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
         s_ref[kp][wave][lane] = ref[kp]; s_sm[kp][wave][lane] = sm[kp];
     }
     if (SAMPLE) { s_bkey[wave][lane] = best.key; s_bmass[wave][lane] = best.mass; s_bratio[wave][lane] = best.ratio; s_bpop[wave][lane] = best.pop; }
+    if (COST && lane == 0) ms.cost[(size_t)sc * 4 + wave] = n_cost;
     __syncthreads();
     if (wave != 0) return;
     // ---- wave 0: merge the four shares, finish the star, sum the chunk
@@ -414,13 +419,13 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
         double S = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) S += (s_sm[kp][k][lane] > 0.0) ? s_sm[kp][k][lane] * exp_fast(s_ref[kp][k][lane] - r) : 0.0;
-        if (n_split > 1) {                              // this workgroup's share of the star's sum: merged by k_marg_merge
-            double *sh = shares + ((((size_t)w * (st.mg_pad >> 6) + sc) * n_split + split) * NPOPS + kp) * 128;
+        if (SPLIT) {                                    // this workgroup's share of the star's sum: merged by k_marg_merge
+            double *sh = shares + ((((size_t)w * st.mg_n_pieces + st.mg_share_base[sc] + split) * NPOPS + kp) * 128);
             sh[lane] = r; sh[64 + lane] = S;
         }
         ll[kp] = (S > 0.0) ? c0m + (r + log(S)) : NEG_INF;
     }
-    if (n_split > 1) return;
+    if (SPLIT) return;
     double v = 0.0;
     if (!dead) {
         double l = ll[0];
@@ -445,29 +450,30 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     MLIFE(1, __builtin_amdgcn_s_memrealtime());
 }
 
-template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT>
+template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, bool COST = false>
 __global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE))
 void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                  const double *__restrict__ iso_data, long long iso_stride,
                  int mass_cap, const double *__restrict__ params,
                  double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
                  int K, int Q, MargSample ms, const double *__restrict__ tab, MargLayout L,
-                 int n_walkers, double cut2, int wsplit, int n_split_arg, double *__restrict__ shares)
+                 int n_walkers, double cut2, int wsplit, double *__restrict__ shares)
 {
-    star_marg_body<NFP, NPOPS, SAMPLE, SPLIT>(pk, st, (int)blockIdx.x, iso_data, iso_stride, mass_cap, partial, partial_stride, perstar, K, Q, ms, L,
-                                              n_walkers, cut2, wsplit, n_split_arg, shares, MargSelPlain{MargSel{hdr, params, tab}});
+    star_marg_body<NFP, NPOPS, SAMPLE, SPLIT, COST>(pk, st, (int)blockIdx.x, iso_data, iso_stride, mass_cap, partial, partial_stride, perstar, K, Q, ms, L,
+                                                    n_walkers, cut2, wsplit, shares, MargSelPlain{MargSel{hdr, params, tab}});
 }
 
-// k_marg_merge: the stars of a SPLIT launch -- one wave per (star chunk, walker), lane = star: the n_split shares (ref, sum) of
-// every star merged in the order of the splits (the wave-0 merge of k_star_marg, continued), the star finished (mass-prior
+// k_marg_merge: the stars of a SPLIT launch -- one wave per (star chunk, walker), lane = star: the chunk's shares (ref, sum) of
+// every star merged in the order of the pieces (the wave-0 merge of k_star_marg, continued), the star finished (mass-prior
 // constant, populations, field-star mixture) and the chunk's partial sum formed: what k_star_marg's last wave does when one
 // workgroup holds the whole window.
 template <int NPOPS>
 __device__ __forceinline__ void marg_merge_body(const DevStars &st, const IsoHdr *__restrict__ hdr, const double *__restrict__ params,
                                                 double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
-                                                const double *__restrict__ shares, int n_split)
+                                                const double *__restrict__ shares)
 {
     const int lane = threadIdx.x, sc = blockIdx.x, w = blockIdx.y;
+    const int sb = st.mg_share_base[sc], n_split = st.mg_share_base[sc + 1] - sb;
     bool valid = true;
 #pragma unroll
     for (int kp = 0; kp < NPOPS; ++kp) valid = valid && hdr[w * NPOPS + kp].valid;
@@ -477,7 +483,7 @@ __device__ __forceinline__ void marg_merge_body(const DevStars &st, const IsoHdr
     double ll[NPOPS];
 #pragma unroll
     for (int kp = 0; kp < NPOPS; ++kp) {
-        const double *sh = shares + ((((size_t)w * (st.mg_pad >> 6) + sc) * n_split) * NPOPS + kp) * 128;
+        const double *sh = shares + (((size_t)w * st.mg_n_pieces + sb) * NPOPS + kp) * 128;
         double r = NEG_INF;
         for (int k = 0; k < n_split; ++k) {
             const double rk = sh[(size_t)k * NPOPS * 128 + lane], sk = sh[(size_t)k * NPOPS * 128 + 64 + lane];
@@ -504,9 +510,9 @@ __device__ __forceinline__ void marg_merge_body(const DevStars &st, const IsoHdr
 template <int NPOPS>
 __global__ __launch_bounds__(64) void k_marg_merge(DevStars st, const IsoHdr *__restrict__ hdr, const double *__restrict__ params,
                                                    double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
-                                                   const double *__restrict__ shares, int n_split)
+                                                   const double *__restrict__ shares)
 {
-    marg_merge_body<NPOPS>(st, hdr, params, partial, partial_stride, perstar, shares, n_split);
+    marg_merge_body<NPOPS>(st, hdr, params, partial, partial_stride, perstar, shares);
 }
 
 // ------------------------------------------------------------------------------------------

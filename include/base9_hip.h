@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define B9_ABI_VERSION 5
+#define B9_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------------------ */
 typedef enum b9_status {
@@ -187,7 +187,10 @@ typedef struct b9_tuning {
                                /* workgroups are all resident at once AND whose estimated cost per step beats the one-step  */
                                /* launch's (few walkers per GPU, catalogues that leave the chip under-filled), else 1.      */
                                /* Env: B9_TREE_DEPTH                                                                        */
-    int32_t reserved[7];
+    int32_t marg_piece_units;  /* marginalised mode, small catalogues: the smallest share of a star chunk's node window worth a   */
+                               /* workgroup of its own, in (16 nodes x one mass ratio) units per wave (default 4).  Part of what a   */
+                               /* star's sum rounds like: every rank of a run must use the same value.  Env: B9_MARG_PIECE_UNITS   */
+    int32_t reserved[6];
 } b9_tuning;
 
 typedef struct b9_ctx b9_ctx;

@@ -35,7 +35,7 @@ def test_header_symbols_match_binding_table():
 def test_library_exports_every_declared_symbol(lib):
     for name in _declared_functions():
         assert hasattr(lib, name), f"{name} declared in base9_hip.h but not exported"
-    assert lib.b9_abi_version() == 5
+    assert lib.b9_abi_version() == 6
 
 
 def test_host_library_exports_every_declared_symbol():
