@@ -10,10 +10,17 @@
 //     fills the chip's workgroup slots once (never under b9_tuning.marg_piece_units units): pieces cost about the same, the launch no
 //     longer lasts as long as its heaviest chunk (round 4 split every chunk 8 ways: 10k stars, one chain: the heaviest
 //     piece lived 27 us, the median 6.5).
+// WHICH stars share a chunk stays what b9_load_stars made it -- neighbours along the first principal component of the
+// magnitudes.  Round 5 measured the alternatives with this same counting pass (wave-units on the reference row, 50k stars x 8
+// filters, 4 x 4 grid): that order 8012; stars re-dealt by their best node on the reference table 12812, by (best mass ratio,
+// best node) 8868 (the argmax wanders along the mass / mass-ratio degeneracy: photometric twins end up chunks apart); blocks
+// of 2 / 4 / 8 / 16 chunks re-sorted by the second component 8091 / 8371 / 9101 / 10467.  A star's own halo of live terms
+// (80 of the 163 a wave evaluates), not the union over its neighbours, is what a wave pays for.
 // Everything here is a function of the catalogue, the pack, the priors and the options -- the same on every rank, whatever
 // walkers it holds -- because the pieces decide how a star's sum rounds and a walker's chain must not depend on its
 // neighbours.  Speed only otherwise: any plan gives a correct sum.
 #include "b9_ctx.h"
+#include <cstdint>
 
 using namespace b9i;
 
@@ -50,6 +57,31 @@ void reference_row(const b9_ctx *ctx, double *row)
     if (!(row[B9_P_LAMBDA] > 0.0 && row[B9_P_LAMBDA] < 1.0)) row[B9_P_LAMBDA] = 0.5;
 }
 
+// the counting pass on the reference row: units evaluated per (star chunk, wave)
+int counting_pass(b9_ctx *ctx, const double *row, int K, int Q, std::vector<unsigned> &h_cost, bool &valid)
+{
+    const int n_pops = ctx->opt.n_pops, n_mc = ctx->st.mg_pad / 64;
+    const Bufs bf = buffer_set(ctx, 0);
+    unsigned *d_cost = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_cost, sizeof(unsigned) * 4 * n_mc));
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemsetAsync(d_cost, 0, sizeof(unsigned) * 4 * n_mc, s);
+    if (e == hipSuccess) e = b9k_derive_iso_rows(ctx->pk, row, bf.params, 1, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, s);
+    if (e == hipSuccess) e = b9k_marg_tables(ctx->pk, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params, 1, n_pops, K, Q, ctx->d_marg_tab, nullptr, s);
+    if (e == hipSuccess) e = b9k_star_marg_cost(ctx->pk, ctx->st, bf.hdr, ctx->mass_cap, bf.params, n_pops, ctx->d_partial, partial_stride(ctx), K, Q,
+                                                ctx->marg_prune, ctx->d_marg_tab, d_cost, s);
+    h_cost.assign(4 * (size_t)n_mc, 0u);
+    std::vector<IsoHdr> h_hdr(n_pops);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cost.data(), d_cost, sizeof(unsigned) * h_cost.size(), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_hdr.data(), bf.hdr, sizeof(IsoHdr) * n_pops, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_cost);
+    if (e != hipSuccess) return fail(ctx, B9_ERR_HIP, std::string("marginalised catalogue plan: ") + hipGetErrorString(e));
+    valid = true;
+    for (int k = 0; k < n_pops; ++k) valid = valid && h_hdr[k].valid;
+    return B9_OK;
+}
+
 }  // namespace
 
 namespace b9i {
@@ -61,9 +93,9 @@ int ensure_marg_plan(b9_ctx *ctx)
     const int n_pops = ctx->opt.n_pops, n_mc = ctx->st.mg_pad / 64;
     const int K = ctx->opt.marg_iso_increm > 0 ? ctx->opt.marg_iso_increm : 1, Q = ctx->opt.marg_n_q > 0 ? ctx->opt.marg_n_q : 1;
     free_all(ctx->marg_plan_allocs);
+    // back to the load-time order (until the plan's own is in place)
     ctx->st.mg_n_pieces = 0; ctx->st.mg_piece = nullptr; ctx->st.mg_share_base = nullptr;
-    ctx->st.marg_order = ctx->marg_order_spread;                  // (the load-time order, until the measured one is in place)
-    // ---- the counting pass on the reference row
+    ctx->st.marg_order = ctx->marg_order_spread;
     std::vector<double> cost(n_mc, -1.0);
     bool measured = false;
     {
@@ -73,24 +105,9 @@ int ensure_marg_plan(b9_ctx *ctx)
         if (rc) return rc;
         double row[B9_NPARAM];
         reference_row(ctx, row);
-        const Bufs bf = buffer_set(ctx, 0);
-        unsigned *d_cost = nullptr;
-        HIPCHK(ctx, hipMalloc((void **)&d_cost, sizeof(unsigned) * 4 * n_mc));
-        hipStream_t s = ctx->stream;
-        hipError_t e = hipMemsetAsync(d_cost, 0, sizeof(unsigned) * 4 * n_mc, s);
-        if (e == hipSuccess) e = b9k_derive_iso_rows(ctx->pk, row, bf.params, 1, n_pops, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, s);
-        if (e == hipSuccess) e = b9k_marg_tables(ctx->pk, bf.hdr, bf.iso, ctx->iso_stride, ctx->mass_cap, bf.params, 1, n_pops, K, Q, ctx->d_marg_tab, nullptr, s);
-        if (e == hipSuccess) e = b9k_star_marg_cost(ctx->pk, ctx->st, bf.hdr, ctx->mass_cap, bf.params, n_pops, ctx->d_partial, partial_stride(ctx), K, Q,
-                                                    ctx->marg_prune, ctx->d_marg_tab, d_cost, s);
-        std::vector<unsigned> h_cost(4 * (size_t)n_mc);
-        std::vector<IsoHdr> h_hdr(n_pops);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_cost.data(), d_cost, sizeof(unsigned) * h_cost.size(), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_hdr.data(), bf.hdr, sizeof(IsoHdr) * n_pops, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void)hipFree(d_cost);
-        if (e != hipSuccess) return fail(ctx, B9_ERR_HIP, std::string("marginalised catalogue plan: ") + hipGetErrorString(e));
-        measured = true;
-        for (int k = 0; k < n_pops; ++k) measured = measured && h_hdr[k].valid;
+        std::vector<unsigned> h_cost;
+        if ((rc = counting_pass(ctx, row, K, Q, h_cost, measured))) return rc;
+        if (ctx->plan_debug && measured) { double t = 0.0; for (unsigned c : h_cost) t += c; fprintf(stderr, "[marg plan] %.0f wave-units on the reference row\n", t); }
         // a chunk's cost: its busiest wave's units (the four waves share the chunk's life), plus the chunk's fixed work in the
         // same currency (entry, level-1 boxes, merge: about two units)
         if (measured)
