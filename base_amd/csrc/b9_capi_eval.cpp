@@ -1,6 +1,7 @@
 // b9_capi_eval.cpp -- one log-posterior evaluation through the C ABI: derive -> stars -> finalize (b9_logpost,
 // b9_logpost_device), the per-star mass draws (b9_sample_mass) and the isochrone dump (b9_derive_isochrone).
 #include "b9_ctx.h"
+#include <atomic>
 
 using namespace b9i;
 
@@ -66,7 +67,8 @@ namespace {
 // One log-posterior evaluation of rows that are already in buffer set 0's parameter rows (or in
 // d_params when that is a caller's device pointer): derive -> stars -> finalize.
 int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, double *d_logpost,
-                          double *d_perstar, hipStream_t stream, const double *host_rows = nullptr)
+                          double *d_perstar, hipStream_t stream, const double *host_rows = nullptr,
+                          unsigned long long *done_flag = nullptr, unsigned long long done_seq = 0)
 {
     const int n_pops = ctx->opt.n_pops;
     const B9Groups plan = make_plan(ctx, n_walkers, n_pops);
@@ -85,7 +87,7 @@ int launch_logpost(b9_ctx *ctx, double *d_params, int32_t n_walkers, double *d_l
     rc = launch_stars(ctx, bf, n_walkers, d_perstar, plan, stream);
     if (rc) return rc;
     HIPCHK(ctx, b9k_finalize(bf.hdr, ctx->d_partial, partial_count(ctx, plan), partial_stride(ctx), n_pops, bf.params, ctx->pr,
-                             n_walkers, d_logpost, d_perstar, ctx->st.n, off, stream));
+                             n_walkers, d_logpost, d_perstar, ctx->st.n, off, stream, done_flag, done_seq));
     return B9_OK;
 }
 
@@ -118,12 +120,19 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     // to 8 rows the parameters ride in the first launch's kernel arguments and the log-posteriors are written by
     // k_finalize straight into pinned host memory mapped into the device -- no copy command in the stream at all.
     if (!ctx->h_lp) {
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lp, sizeof(double) * 8, hipHostMallocMapped));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lp, sizeof(double) * 16, hipHostMallocMapped));
         HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_lp_dev, ctx->h_lp, 0));
+        std::memset(ctx->h_lp, 0, sizeof(double) * 16);
     }
     const bool small = n_walkers <= 8;
+    // ... and the host does not wait for the stream's completion signal either (a wake-up of several microseconds): the
+    // last launch stores a per-call sequence number behind every log-posterior and the host polls those words
+    volatile unsigned long long *const h_done = reinterpret_cast<volatile unsigned long long *>(ctx->h_lp + 8);
+    const bool polled = small && !out_perstar;
+    const unsigned long long seq = ++ctx->lp_seq;
     if (small) {
-        rc = launch_logpost(ctx, ctx->d_params, n_walkers, ctx->h_lp_dev, out_perstar ? ctx->d_perstar : nullptr, ctx->stream, params);
+        rc = launch_logpost(ctx, ctx->d_params, n_walkers, ctx->h_lp_dev, out_perstar ? ctx->d_perstar : nullptr, ctx->stream, params,
+                            polled ? reinterpret_cast<unsigned long long *>(ctx->h_lp_dev + 8) : nullptr, seq);
         if (rc) return rc;
     } else {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_params, params, sizeof(double) * B9_NPARAM * n_walkers, hipMemcpyHostToDevice, ctx->stream));
@@ -134,7 +143,19 @@ int b9_logpost(b9_ctx *ctx, const double *params, int32_t n_walkers, double *out
     if (out_perstar)
         HIPCHK(ctx, hipMemcpyAsync(out_perstar, ctx->d_perstar, sizeof(double) * (size_t)n_walkers * ctx->st.n,
                                    hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (polled) {
+        // (bounded: a launch that failed never stores its words -- after ~2 ms the stream's own wait takes over and reports)
+        bool done = false;
+        for (long spin = 0; spin < 2000000 && !done; ++spin) {
+            done = true;
+            for (int w = 0; w < n_walkers; ++w) done = done && h_done[w] == seq;
+            if (!done) __builtin_ia32_pause();
+        }
+        if (!done) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (small) std::memcpy(out_logpost, ctx->h_lp, sizeof(double) * n_walkers);
     return B9_OK;
 }

@@ -86,7 +86,8 @@ struct b9_ctx {
         size_t o_cur = 0, o_lp = 0;        // two-launch blocks: where the final state half sits in the block
     } slot[2];
     int next_slot = 0, last_slot = -1;
-    double *h_lp = nullptr, *h_lp_dev = nullptr;   // b9_logpost: 8 log-posteriors in mapped pinned host memory (host / device view)
+    double *h_lp = nullptr, *h_lp_dev = nullptr;   // b9_logpost: 8 log-posteriors + 8 completion words in mapped pinned host memory (host / device view)
+    unsigned long long lp_seq = 0;                 // ... and the number of the call the completion words announce
 
     // launch plan
     int n_cu = 256;            // compute units of the device (hipDeviceAttributeMultiprocessorCount)

@@ -71,14 +71,19 @@ __global__ __launch_bounds__(256) void k_finalize(const IsoHdr *__restrict__ hdr
                                                    int n_partial, long long partial_stride, int n_pops,
                                                    const double *__restrict__ params, DevPriors pr,
                                                    double *__restrict__ logpost, double *__restrict__ perstar,
-                                                   int n_stars, McmcDev mc)
+                                                   int n_stars, McmcDev mc, unsigned long long *__restrict__ done_flag, unsigned long long done_seq)
 {
     __shared__ double s_red[4], s_cur[B9_NPARAM], s_lp;
     const int w = blockIdx.x, tid = threadIdx.x;
     const double *row = params + (size_t)w * B9_NPARAM;
     bool in_support;
     const double lp = finish_logpost(hdr, partial + (size_t)w * partial_stride, n_partial, row, pr, n_pops, w, s_red, &in_support);
-    if (tid == 0) logpost[w] = lp;
+    if (tid == 0) {
+        logpost[w] = lp;
+        // b9_logpost's completion word (mapped host memory, behind the value it announces): the host polls it instead of
+        // waiting for the stream's completion signal
+        if (done_flag) { __threadfence_system(); __hip_atomic_store(done_flag + w, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
     // a walker inside the grid whose prior is -inf still has per-star values from the star kernel;
     // the oracle reports -inf for them as well
     if (perstar && !in_support)
@@ -172,10 +177,10 @@ hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 
 hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial, long long partial_stride,
                         int n_pops, const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        double *perstar, int n_stars, const McmcDev &mc, hipStream_t stream)
+                        double *perstar, int n_stars, const McmcDev &mc, hipStream_t stream, unsigned long long *done_flag, unsigned long long done_seq)
 {
     hipLaunchKernelGGL(k_finalize, dim3(n_walkers), dim3(256), 0, stream, hdr, partial, n_partial, partial_stride,
-                       n_pops, d_params, pr, d_logpost, perstar, n_stars, mc);
+                       n_pops, d_params, pr, d_logpost, perstar, n_stars, mc, done_flag, done_seq);
     return hipGetLastError();
 }
 

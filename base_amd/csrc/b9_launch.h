@@ -32,7 +32,9 @@ hipError_t b9k_star_like(const DevPack &pk, const DevStars &st, const IsoHdr *hd
 
 hipError_t b9k_finalize(const IsoHdr *hdr, const double *partial, int n_partial, long long partial_stride,
                         int n_pops, const double *d_params, const DevPriors &pr, int n_walkers, double *d_logpost,
-                        double *perstar, int n_stars, const McmcDev &mc, hipStream_t stream);
+                        double *perstar, int n_stars, const McmcDev &mc, hipStream_t stream,
+                        unsigned long long *done_flag = nullptr /* [n_walkers] in mapped host memory: done_seq is stored there behind the log-posterior */,
+                        unsigned long long done_seq = 0);
 
 // b9_sample_mass: where the per-star draws go (device pointers), RNG key and the global index of row 0
 struct B9MargSample {
