@@ -112,7 +112,7 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
     __shared__ double s_box[4][2][NFP];
     double *const s_mass = smem, *const s_prim = smem + mass_cap + 8, *const s_sec = s_prim + 65 * NFP + (size_t)wave * B9_MSTEP_SEC_ROWS * NFP;
     HSTAMP(0);
-    if (wave == 0) candidate_row_wave0(sd, w, cand, s_par, s_z);
+    if (wave == 0) candidate_row_wave0<true>(sd, w, cand, s_par, s_z);
     __syncthreads();
     HSTAMP(1);
     const size_t rows = (size_t)W * n_pops, cset = (size_t)((sd.set ^ 1) * 2 + cand);
@@ -244,7 +244,7 @@ __device__ __forceinline__ void marg_build_wd_table(const DevPack &pk, const Ste
     const int tid = threadIdx.x, lane = tid & 63, W = sd.n_walkers, n_pops = sd.n_pops, K = mx.K, steps = 8 * K;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), type = wave & 1;
     __shared__ double s_par[B9_NPARAM], s_z[12];
-    if (wave == 0) candidate_row_wave0(sd, w, cand, s_par, s_z);
+    if (wave == 0) candidate_row_wave0<true>(sd, w, cand, s_par, s_z);
     __syncthreads();
     const size_t cset = (size_t)((sd.set ^ 1) * 2 + cand);
     const int wp = w * n_pops + pop, n_wp = W * n_pops;
@@ -274,8 +274,8 @@ __device__ __forceinline__ void marg_build_wd_table(const DevPack &pk, const Ste
     if (type == 0) wtab[(size_t)n_wp * 2 * steps * NFP + (size_t)wp * steps + (j - 1)] = log_prior_mass_dev(pk.log_mass_norm, m1);
 }
 
-// The star roles' choice of candidate: the decision of step t-1, taken by the workgroup's first wave (its loads leave at the
-// role's entry, before the star's own) and shared through LDS behind one barrier.  hdr / par / tab / wd: THIS parity's two
+// The star roles' choice of candidate: the decision of step t-1, waited for by the workgroup's first wave (wait_decision: the
+// walker's writer publishes it) and shared through LDS behind one barrier.  hdr / par / tab / wd: THIS parity's two
 // candidates as the launch's own `const __restrict__` kernel arguments -- read through the StepDev / MargStep pointers
 // (which the builders of the same launch write through, for the other parity) the compiler cannot prove the tables
 // unclobbered and turns every scalar load of a box or an nb word into a vector load + v_readfirstlane: +18 % launch time.
@@ -286,16 +286,11 @@ struct MargStepSel {
     bool wd;                 // the WD-stage stars' role: .tab is the candidate's WD table
     const IsoHdr *__restrict__ hdr;
     const double *__restrict__ par, *__restrict__ tab, *__restrict__ wdt;
-    DecideLoads dl;
-    __device__ __forceinline__ void issue(int w)
-    {
-        if (!MSTEP_NO_DECIDE && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) decide_issue<B9_SHORTCUT>(sd, w, dl);
-    }
+    __device__ __forceinline__ void issue(int) {}
     __device__ __forceinline__ MargSel finish(int w)
     {
         if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) {
-            double lp_new;
-            const int s0 = (!MSTEP_NO_DECIDE && decide_finish<B9_SHORTCUT>(sd, w, dl, lp_new)) ? 1 : 0;
+            const int s0 = (!MSTEP_NO_DECIDE && wait_decision(sd, w)) ? 1 : 0;
             if (threadIdx.x == 0) *s_sel = s0;
         }
         __syncthreads();
@@ -335,7 +330,7 @@ __device__ __forceinline__ int marg_step_body(const DevPack &pk, const DevStars 
     b -= front_blocks;
     if (MSTEP_NO_STARS) return 3;
     __shared__ int s_sel;
-    MargStepSel select{sd, mx, &s_sel, b >= star_blocks, hdr_rd, par_rd, tab_rd, wd_rd, {}};
+    MargStepSel select{sd, mx, &s_sel, b >= star_blocks, hdr_rd, par_rd, tab_rd, wd_rd};
     double *const partial = sd.partial + (size_t)sd.set * (sd.partial_stride / 2);
     const MargSample ms{};
     if (b < star_blocks) {

@@ -262,18 +262,39 @@ __device__ __forceinline__ void step_derive(const DevPack &pk, const StepDev &sd
                      sd.iso_stride, sd.mass_cap, part, parts, axr);
 }
 
+// The decision of step t-1 as walker w's WRITER publishes it (sd.decided[w] = step << 1 | accepted), waited for by one wave.
+// The writers are the launch's first workgroups: resident, and deciding, before any workgroup that waits for them is
+// dispatched.  Used where re-summing would cost more than waiting: a walker of the marginalised step has one partial per
+// 64-star chunk (782 at 50k stars), and 1400 first-round workgroups each reading their walker's 49 freshly rewritten lines
+// made every decision of the launch take 7.6 us (the writer's own included) against the 3-4 us of eight writers reading
+// alone.  Bounded: a writer that never shows (it cannot, but nothing else depends on that) leaves the decision to the waiter.
+__device__ __forceinline__ bool wait_decision(const StepDev &sd, int w)
+{
+    if (!sd.has_prev) return false;
+    for (int spin = 0; spin < (1 << 16); ++spin) {
+        const unsigned long long f = __hip_atomic_load(sd.decided + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((f >> 1) == sd.step) return (f & 1ull) != 0;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    double lp_new;
+    return step_decide<false>(sd, w, lp_new);
+}
+
 // The parameter row of candidate `cand` of step t+1 for walker w, formed by ONE wave (the caller's first) into s_par[12]
 // (LDS; s_z[12] is scratch): the decision of step t-1 from its partial sums, the normals of step t+1 (Philox + Box-Muller,
 // independent of every decision: while the decision's loads are in flight), and
 //     row = base;  row[free[i]] += sum_j chol[i][j] z_j   (j ascending, plain multiply-add -- as the host twin does)
 // with base = the state after step t-1 (cand 0: step t rejected) or step t's proposal (cand 1: accepted).  The other waves
 // see s_par behind the caller's next workgroup barrier.
+// WAIT (the marginalised step, whose walkers have ~800 partial sums each): the decision is not re-summed here but taken from
+// the word the walker's writer publishes (wait_decision).
+template <bool WAIT = false>
 __device__ __forceinline__ void candidate_row_wave0(const StepDev &sd, int w, int cand, double *s_par, double *s_z)
 {
     const int tid = threadIdx.x, d = sd.d, W = sd.n_walkers;
     const double *in = step_state_in(sd, w);
     DecideLoads dl = {};
-    decide_issue<false>(sd, w, dl);
+    if (!WAIT) decide_issue<false>(sd, w, dl);
     const double cur_v = tid < B9_NPARAM ? in[B9_ST_CUR + tid] : 0.0;
     const double prev_prop_v = tid < B9_NPARAM ? in[B9_ST_PROP + tid] : 0.0;
     const double pc0 = tid < B9_NPARAM ? sd.cand_par[((size_t)(sd.set * 2 + 0) * W + w) * B9_NPARAM + tid] : 0.0;
@@ -295,7 +316,7 @@ __device__ __forceinline__ void candidate_row_wave0(const StepDev &sd, int w, in
         }
     }
     double lp_new = 0.0;
-    const bool ok = decide_finish<false>(sd, w, dl, lp_new);
+    const bool ok = WAIT ? wait_decision(sd, w) : decide_finish<false>(sd, w, dl, lp_new);
     if (tid < B9_NPARAM) s_par[tid] = cand ? (ok ? pc1 : pc0) : (ok ? prev_prop_v : cur_v);
     __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS accesses complete in program order)
     double delta = 0.0;

@@ -33,12 +33,13 @@ cpu_baseline = the CPU oracle ("port"; the reference itself is not mounted, see 
                box's host cores on a bounded sample of the same workload (rank 0, N=1); with it, |delta logPost| of
                the HIP path against that CPU path: of b9_logpost on 128 random rows AND of the timed sampler's own
                ensemble state after the timed region (delta_logpost_sampler).
-sustained    = the same loop over 5000 further steps, timed the same way (its own value / ms_per_step; `value` stays the
+sustained    = the same loop over 140 000 further steps (>= 2 s), timed the same way (its own value / ms_per_step; `value` stays the
                K steps'), with the shader clock observed in-kernel over that stretch (`clock_mhz_observed`): the roofline
                peaks are quoted at the 2.4 GHz maximum, `roofline.*_at_observed_clock` rescale them.
 groups       = with N > 1 ranks the line is refused (exit 3) unless the RCCL communicator itself reports N ranks on N
                DISTINCT GPUs (PCI bus ids gathered through it).
-marginalised_mode = the same three objects (value, roofline, cpu_baseline + delta) for the marginalised evaluation mode.
+marginalised_mode = the same objects (value, roofline, cpu_baseline + delta, the sampler with its own sustained leg and
+               clock) for the marginalised evaluation mode.
 
 Prints ONE JSON line on rank 0.
 """
@@ -63,8 +64,9 @@ MCMC_BLOCK = 100        # steps between adaptation points (= between all-gathers
 TIMING_EVERY = 25       # a HIP-event bracket opens at every 25th launch of the dominant kernel in the timed region and spans 8 launches
 PREWARM_STEPS = 1000    # untimed, BEFORE the W warm-up steps: clocks, first touch of every buffer, RCCL channels, and the sampler's
                         # own burn-in (10 adaptation blocks: the timed steps run with the adapted proposal, as a real run's do)
-SUSTAINED_STEPS = 5000  # the `sustained` leg: timed like the K steps (barrier + synchronize on both sides), long enough for clocks to show
-PROFILE_TAG = "r04"     # profiles/<tag>_summary.json: rocprofv3 PMC passes of this command (tools/profile_round.sh)
+SUSTAINED_STEPS = 140000  # the `sustained` leg: timed like the K steps (barrier + synchronize on both sides); >= 2 s of back-to-back launches
+MARG_SUSTAINED_STEPS = 15000   # the marginalised sampler's sustained leg (>= 2 s at ~0.14 ms per step)
+PROFILE_TAG = "r05"     # profiles/<tag>_summary.json: rocprofv3 PMC passes of this command (tools/profile_round.sh)
 MARG_K = MARG_Q = 4     # marginalised leg: sub-steps per EEP interval x mass ratios
 
 
@@ -358,14 +360,16 @@ def marg_useful_lane_ops(n_filt: int, live_terms: float) -> dict:
             "mean": live_terms * per_term + per_star}
 
 
-def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_cpu: bool, n_calls: int = 20, steps: int = 200):
+def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_cpu: bool, n_calls: int = 20, steps: int = 400, sustained: bool = True):
     """The marginalised evaluation mode as a measured configuration of its own (every star integrated over primary mass and
     mass ratio, 4 sub-steps per EEP interval x 4 mass ratios = 6384 nodes/star; one LANE per star, a wave walks the node
     table for 64 photometric neighbours):  (i) b9_logpost calls through the C ABI;  (ii) the SAMPLER in this mode -- the C++
-    b9h::WalkerSampler driving device-resident blocks, two launches per step -- as MCMC steps/s, with the ensemble state
-    it ends on checked against the CPU oracle;  (iii) k_star_marg's fp64 VALU roofline, launch time measured live with HIP
-    events: issue occupancy from the committed counters and the USEFUL fraction from the committed count of terms that
-    enter a star's sum;  (iv) the CPU oracle's brute-force marginalisation on a bounded sample."""
+    b9h::WalkerSampler driving device-resident blocks, ONE launch per step (k_marg_step: decision + stars + both candidate
+    node tables of the next step) -- as MCMC steps/s over `steps` steps and over a sustained leg of >= 2 s with the observed
+    shader clock, the ensemble state it ends on checked against the CPU oracle;  (iii) the fp64 VALU rooflines of k_star_marg
+    (the b9_logpost calls) and k_marg_step (the sampler), launch times measured live with HIP events: issue occupancy from
+    the committed counters and the USEFUL fraction from the committed count of terms that enter a star's sum;  (iv) the CPU
+    oracle's brute-force marginalisation on a bounded sample."""
     import numpy as np
     from base_amd import abi, engine, hostlib, mcmc, synth
     opts = abi.make_options(abi.MODE_MARGINALISED, 1, MARG_K, MARG_Q)
@@ -388,12 +392,12 @@ def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_c
            "ms_per_logpost_call": 1e3 * dt, "calls": n_calls,
            "config": {"workload": f"the bench cluster ({N_STARS} stars x {N_FILT} filters x {WALKERS_PER_GPU} walkers), marginalised mode: "
                                   f"{MARG_K} sub-steps per EEP interval x {MARG_Q} mass ratios; b9_logpost calls (derive + k_marg_table + k_star_marg + finalize)"}}
-    # ---- the sampler in this mode: the same C++ driver as the headline, two launches per step
+    # ---- the sampler in this mode: the same C++ driver as the headline, one launch per step
     free = mcmc.DEFAULT_FREE
     smp = hostlib.HostSampler(WALKERS_PER_GPU, free, [mcmc.DEFAULT_STEP[k] for k in free], hostlib.Exchange.local(), seed=2025,
-                              block=50, engine=eng)
+                              block=MCMC_BLOCK, engine=eng)
     smp.initialise(synth.walker_params(truth, WALKERS_PER_GPU, seed=42, scale=0.02))
-    smp.run(100)                                            # untimed: two adaptation blocks
+    smp.run(200)                                            # untimed: two adaptation blocks
     acc0 = smp.state()["accepted_local"]
     hostlib._check(hostlib.load().b9h_device_synchronize())
     t0 = time.perf_counter()
@@ -401,13 +405,44 @@ def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_c
     hostlib._check(hostlib.load().b9h_device_synchronize())
     dt_s = time.perf_counter() - t0
     st = smp.state()
-    out["sampler"] = {"mcmc_steps_per_s": steps / dt_s, "ms_per_step": 1e3 * dt_s / steps, "steps": steps, "warmup_steps_untimed": 100,
-                      "value": evals * steps / dt_s, "unit": "star-likelihood evals/s", "walkers": WALKERS_PER_GPU, "mcmc_block": 50,
+    out["sampler"] = {"mcmc_steps_per_s": steps / dt_s, "ms_per_step": 1e3 * dt_s / steps, "steps": steps, "warmup_steps_untimed": 200,
+                      "value": evals * steps / dt_s, "unit": "star-likelihood evals/s", "walkers": WALKERS_PER_GPU, "mcmc_block": MCMC_BLOCK,
                       "accept_rate": (st["accepted_local"] - acc0) / float(WALKERS_PER_GPU * steps),
-                      "driver": "C++ host library (b9h::WalkerSampler), device-resident blocks; a step = k_derive_iso (finishing the "
-                                "previous step) + k_marg_table + k_star_marg"}
+                      "driver": "C++ host library (b9h::WalkerSampler), device-resident blocks; a step = ONE k_marg_step launch (the previous "
+                                "step's decision, the stars against the chosen candidate's node table, both candidate tables of the next step)"}
     stats = marg_stats(source_hash)
     useful = marg_useful_lane_ops(N_FILT, stats["live_terms_per_star_eval"]) if "stale" not in stats else None
+    # ... and its sustained leg: >= 2 s of back-to-back launches, the shader clock stamped at both ends, every 50th launch
+    # of k_marg_step opening a HIP-event bracket over 8 launches
+    if sustained:
+        eng.enable_timing(2 * TIMING_EVERY)                 # (300 brackets: inside the pre-created event pool)
+        eng.kernel_time_ms(reset=True)
+        hostlib._check(hostlib.load().b9h_device_synchronize())
+        t0 = time.perf_counter()
+        eng.clock_stamp(0)
+        smp.run(MARG_SUSTAINED_STEPS)
+        eng.clock_stamp(1)
+        hostlib._check(hostlib.load().b9h_device_synchronize())
+        dt_ss = time.perf_counter() - t0
+        ks_ms, ks_n = eng.kernel_time_ms(reset=True)
+        eng.enable_timing(0)
+        clock = eng.clock_mhz()
+        step_s = ks_ms / max(ks_n, 1) * 1e-3
+        roof_s = valu_roofline(profile_counters("k_marg_step", source_hash), step_s if ks_n else None, useful["mean"] * evals if useful else None)
+        roof_s.update({"kernel": "k_marg_step", "launches_timed": ks_n, "avg_launch_us": 1e6 * step_s if ks_n else None, "star_evals_per_launch": evals,
+                       "note": "the sampler's launch: decision + 6256 star workgroups + 408 front workgroups (writers, table builders); launch period "
+                               "from HIP-event brackets over 8 launches in the sustained leg; useful work = the star role's (the builders' tables "
+                               "are overhead of the speculation, not counted)"})
+        if clock["mhz"] > 0:
+            scale = CLOCK_GHZ * 1e3 / clock["mhz"]
+            roof_s["frac_at_observed_clock"] = roof_s["frac"] * scale if roof_s.get("frac") is not None else None
+            roof_s["useful_frac_at_observed_clock"] = roof_s["useful_frac"] * scale if roof_s.get("useful_frac") is not None else None
+        out["sampler"]["sustained"] = {"steps": MARG_SUSTAINED_STEPS, "seconds": dt_ss, "ms_per_step": 1e3 * dt_ss / MARG_SUSTAINED_STEPS,
+                                       "mcmc_steps_per_s": MARG_SUSTAINED_STEPS / dt_ss, "value": evals * MARG_SUSTAINED_STEPS / dt_ss,
+                                       "unit": "star-likelihood evals/s", "clock": clock}
+        out["sampler"]["clock_mhz_observed"] = clock["mhz"]
+        out["sampler"]["roofline"] = roof_s
+    st = smp.state()
     roof = valu_roofline(profile_counters("k_star_marg", source_hash), launch_s if k_n else None,
                          useful["mean"] * evals if useful else None)
     roof.update({"kernel": "k_star_marg", "launches_timed": k_n, "avg_launch_us": 1e6 * launch_s if k_n else None,
@@ -433,12 +468,14 @@ def marginalised_leg(pack, stars, priors, truth, local_rank, source_hash, with_c
                                          f"oracle/b9_oracle.c star_marg_loglike (brute force over the whole grid, no pruning)",
                                "delta_logpost": d}
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        # the sampler's own numbers: the log-posteriors its walkers hold after the timed steps (formed by the block's launches)
-        got = np.asarray(st["all_logpost"], dtype=np.float64)
-        want = orc.logpost(np.asarray(st["all_params"], dtype=np.float64))
+        # the sampler's own numbers: the log-posteriors its walkers hold after the timed steps (formed by k_marg_step's launches);
+        # two of the eight walkers (the brute-force oracle needs ~4 s per row)
+        pick = [0, WALKERS_PER_GPU - 1]
+        got = np.asarray(st["all_logpost"], dtype=np.float64)[pick]
+        want = orc.logpost(np.asarray(st["all_params"], dtype=np.float64)[pick])
         ds = _delta(got, want)
-        ds["what"] = ("the marginalised sampler's ensemble state after its timed steps: log-posteriors formed by the block's own launches "
-                      f"at the {WALKERS_PER_GPU} walkers' positions, full cluster, against the oracle's brute-force integral")
+        ds["what"] = ("the marginalised sampler's ensemble state after its sustained leg: log-posteriors formed by k_marg_step's launches "
+                      f"at the positions of walkers {pick[0]} and {pick[1]}, full cluster, against the oracle's brute-force integral")
         out["sampler"]["delta_logpost_sampler"] = ds
     smp.close()
     eng.close()
@@ -456,7 +493,7 @@ def main():
     ap.add_argument("--no-marginalised", action="store_true", help="diagnostic: skip the marginalised-mode leg")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the HIP-event bracketing of k_mcmc_step")
     ap.add_argument("--no-prewarm", action="store_true", help="diagnostic: skip the untimed pre-warm block")
-    ap.add_argument("--no-sustained", action="store_true", help="diagnostic: skip the 5000-step sustained leg")
+    ap.add_argument("--no-sustained", action="store_true", help="diagnostic: skip the sustained legs")
     args = ap.parse_args()
 
     is_rank = "RANK" in os.environ or "B9_RANK" in os.environ
@@ -510,7 +547,7 @@ def main():
     st = sampler.state()                    # (the state the parity check below reads: right after the K timed steps)
     if world > 1:
         check_group(world, exchange.comm_ranks, exchange.devices)
-    # ---- sustained leg: the same loop over >= 5000 steps, timed the same way, with the shader clock stamped on the stream at
+    # ---- sustained leg: the same loop over 140 000 steps (>= 2 s), timed the same way, with the shader clock stamped on the stream at
     # both ends (in-kernel s_memtime against the 100 MHz s_memrealtime: what the chip ran at, not what sysfs says)
     sustained = None
     if not args.no_sustained:
@@ -565,7 +602,8 @@ def main():
                                    "(10 FeH x 60 ages x 400 EEPs), given-mass mode, 8 walkers per GPU; one LANE per star "
                                    "(64-star chunks, per-wave shuffle reduction, fixed-order sum of the per-wave partials) -- "
                                    "not one wavefront per star: with one interpolation per star a wave per star would idle 63 "
-                                   "lanes; the marginalised mode (marginalised_mode below) is one wavefront per star",
+                                   "lanes; the marginalised mode (marginalised_mode below) is one lane per star too (a wave walks the node "
+                                   "table for its 64 stars)",
                        "n_stars": N_STARS, "n_filters": N_FILT, "walkers_per_gpu": WALKERS_PER_GPU,
                        "walkers_total": n_walkers, "parallelism": f"walkers{world}", "ranks": exchange.world,
                        "rccl_ranks": exchange.comm_ranks, "devices": exchange.devices, "forced_ranks": bool(args.force_ranks),
@@ -593,7 +631,7 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_marginalised:
             out["marginalised_mode"] = marginalised_leg(pack, stars, priors, truth, local_rank, source_hash,
-                                                        with_cpu=not args.no_cpu_baseline)
+                                                        with_cpu=not args.no_cpu_baseline, sustained=not args.no_sustained)
         print(json.dumps(out), flush=True)
     exchange.barrier()
     sampler.close()
