@@ -369,7 +369,14 @@ int b9_clock_mhz(b9_ctx *ctx, double *mhz, double *mhz_min, double *mhz_max, dou
     }
     if (v.empty()) return fail(ctx, B9_ERR_STATE, "b9_clock_mhz: the two stamps share no compute unit");
     std::sort(v.begin(), v.end());
-    *mhz = v.size() % 2 ? v[v.size() / 2] : 0.5 * (v[v.size() / 2 - 1] + v[v.size() / 2]);
+    auto median = [](const std::vector<double> &x) { return x.size() % 2 ? x[x.size() / 2] : 0.5 * (x[x.size() / 2 - 1] + x[x.size() / 2]); };
+    {   // a CU whose pair was torn by a pre-emption between the two counter reads shows as an outlier: dropped (3 % of the median)
+        const double m0 = median(v);
+        std::vector<double> kept;
+        for (double x : v) if (std::fabs(x - m0) <= 0.03 * m0) kept.push_back(x);
+        if (!kept.empty()) v.swap(kept);
+    }
+    *mhz = median(v);
     if (mhz_min) *mhz_min = v.front();
     if (mhz_max) *mhz_max = v.back();
     if (ref_seconds) *ref_seconds = ref;

@@ -588,8 +588,8 @@ __global__ void k_clock_stamp(unsigned long long *out)
     unsigned long long t, tr;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(tr) :: "memory");
     const unsigned slot = ((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu);      // HW_ID[15:8] = shader engine, shader array, CU
-    out[2 * slot] = t;
-    out[2 * slot + 1] = tr;
+    // several workgroups land on one CU: the FIRST to claim the (zeroed) slot writes both words, so a pair is one workgroup's
+    if (atomicCAS(out + 2 * slot, 0ull, t) == 0ull) out[2 * slot + 1] = tr;
 }
 hipError_t b9k_clock_stamp(unsigned long long *d_out, hipStream_t stream)
 {

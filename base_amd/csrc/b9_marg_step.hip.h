@@ -109,7 +109,7 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
     const int tid = threadIdx.x, lane = tid & 63, jl = tid >> 6, W = sd.n_walkers, n_pops = sd.n_pops, K = mx.K, Q = mx.Q;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mass_cap = sd.mass_cap;
     __shared__ double s_par[B9_NPARAM], s_z[12];
-    __shared__ double s_box[4][2][NFP];
+    __shared__ double s_box[4][2][NFP], s_shift[NFP];
     double *const s_mass = smem, *const s_prim = smem + mass_cap + 8, *const s_sec = s_prim + 65 * NFP + (size_t)wave * B9_MSTEP_SEC_ROWS * NFP;
     HSTAMP(0);
     if (wave == 0) candidate_row_wave0<true>(sd, w, cand, s_par, s_z);
@@ -136,10 +136,12 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
     }
     if (tid < 8) s_mass[n + tid] = __builtin_inf();                     // find_bracket's masked over-read
     if (lane < NFP) { s_box[jl][0][lane] = __builtin_inf(); s_box[jl][1][lane] = NEG_INF; }
+    // modulus + absorption per filter (compile-time indices into the kernel argument: a run-time index would copy the array to scratch)
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) if (tid == f) s_shift[f] = s_par[B9_P_MOD] + pk.abs_m1[f] * s_par[B9_P_ABS];
     __syncthreads();
     HSTAMP(3);
     if (c == 0 && tid == 0) { h.agb_tip = s_mass[n - 1]; *hp = h; }
-    const double mod = s_par[B9_P_MOD], av = s_par[B9_P_ABS];
     double *out = mx.tab + (cset * rows + wp) * mx.L.total;
     const MargLayout &L = mx.L;
     const int node = c * 64 + lane, sub = lane >> 4, i16 = lane & 15, u = c * 4 + sub;
@@ -184,7 +186,7 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
         }
 #pragma unroll 2
         for (int f = 0; f < NFP; ++f) {
-            const double shift = mod + pk.abs_m1[f] * av;
+            const double shift = s_shift[f];
             double C = 0.0;
             if (ok) {
                 const double p1f = lerp(pr0[f], pr0[NFP + f], t1);

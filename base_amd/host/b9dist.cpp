@@ -162,16 +162,23 @@ class RcclExchange final : public Exchange {
         barrier();                                            // everyone has read the id
         if (rank == 0) {
             std::remove(path.c_str());
-            // (under a launcher that is not ours -- torchrun -- nobody else would remove the directory: it is empty now)
-            if (!std::getenv("B9_LAUNCH_NONCE")) (void)::rmdir(dir.c_str());
+            // The directory is removed here only when it is the DEFAULT one this library made up (nobody else would remove it,
+            // and it is empty now).  A directory a launcher of ours made is the launcher's to remove (B9_LAUNCHER_OWNS_DIR), and
+            // one the user named through B9_DIST_DIR is the user's: never removed.
+            if (!std::getenv("B9_LAUNCHER_OWNS_DIR") && !std::getenv("B9_DIST_DIR")) (void)::rmdir(dir.c_str());
         }
-        // what the communicator itself says about the group: its rank count, and every rank's GPU (PCI bus id),
-        // all-gathered through it -- a record that N distinct devices took part, not an echo of the arguments
+        // what the communicator itself says about the group: its rank count, and every rank's GPU (host name + PCI bus id:
+        // identical nodes have identical bus ids), all-gathered through it -- a record that N distinct devices took part, not
+        // an echo of the arguments
         NCCLX(ncclCommCount(comm_, &comm_count_));
         {
-            constexpr int L = 32;
+            constexpr int L = 96;
             char mine[L] = {0};
-            HIPX(hipDeviceGetPCIBusId(mine, L, device));
+            char host[48] = {0}, bus[32] = {0};
+            if (::gethostname(host, sizeof host - 1) != 0) std::snprintf(host, sizeof host, "host");
+            HIPX(hipDeviceGetPCIBusId(bus, sizeof bus, device));
+            for (char *c = host; *c; ++c) if (*c == ',') *c = '_';       // (the ids travel as a comma-separated list)
+            std::snprintf(mine, L, "%s/%s", host, bus);
             char *d_all = nullptr;
             HIPX(hipMalloc((void **)&d_all, (size_t)L * world));
             HIPX(hipMemcpyAsync(d_all + (size_t)L * rank, mine, L, hipMemcpyHostToDevice, stream_));
@@ -190,7 +197,8 @@ class RcclExchange final : public Exchange {
             if (!bad.empty()) fail(bad);
         }
         test_stall("after-init", rank);
-        if (std::getenv("B9_LAUNCH_NONCE")) {   // ready marker for OUR launchers' start-up deadline (they remove it; nobody else would)
+        if (std::getenv("B9_LAUNCHER_OWNS_DIR")) {   // ready marker for OUR launchers' start-up deadline (they remove it; nobody else would:
+                                                     // a srun / mpirun user who exports B9_LAUNCH_NONCE by hand gets no markers)
             const std::string ready = dir + "/ready." + nonce + "." + std::to_string(rank);
             if (FILE *f = std::fopen(ready.c_str(), "w")) std::fclose(f);
         }

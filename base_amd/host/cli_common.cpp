@@ -221,6 +221,7 @@ bool launch_ranks_if_requested(int argc, char **argv, int *exit_code)
             setenv("B9_WORLD_SIZE", std::to_string(n).c_str(), 1);
             setenv("B9_LOCAL_RANK", std::to_string(r).c_str(), 1);
             setenv("B9_DIST_DIR", dir, 1);
+            setenv("B9_LAUNCHER_OWNS_DIR", "1", 1);
             if (force) setenv("B9_FORCE_RANKS", "1", 1);
             setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      // dmabuf IPC (what this driver supports) unless the user chose
             execv("/proc/self/exe", argv);

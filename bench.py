@@ -104,7 +104,7 @@ def launch_ranks(args) -> int:
     try:
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), B9_DIST_DIR=dist_dir,
-                       MASTER_ADDR="127.0.0.1", B9_LAUNCH_NONCE=nonce)
+                       MASTER_ADDR="127.0.0.1", B9_LAUNCH_NONCE=nonce, B9_LAUNCHER_OWNS_DIR="1")
             if args.force_ranks:
                 env["B9_FORCE_RANKS"] = "1"
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
