@@ -143,3 +143,40 @@ def test_marginalised_mode_is_bit_reproducible(name, walkers):
         assert np.array_equal(a, b)
     assert runs[0][4] == runs[1][4] and 0 < runs[0][4] < 60 * walkers
     eng.close()
+
+
+@pytest.mark.parametrize("n_pops,wd_frac,n_stars,walkers", [(1, 0.0, 9000, 3), (1, 0.08, 2500, 2), (2, 0.05, 3000, 2), (1, 0.0, 40000, 2)])
+def test_fused_marginalised_step_equals_the_two_launch_step(n_pops, wd_frac, n_stars, walkers):
+    """k_marg_step (one launch per step: decision + stars + both candidate node tables of the next step, built by workgroups
+    that derive their isochrone tiles themselves) against the two-launch step it replaced (k_derive_iso, k_marg_table,
+    k_star_marg [, k_marg_merge, k_marg_wd_table, k_star_marg_wd]; b9_tuning.two_launch_steps): the same chain -- same
+    proposals (bit for bit), the same decisions, log-posteriors equal to the rounding of the two decision sums' orders.
+    Covers split catalogues (pieces + merge), WD-stage stars, two populations with a helium axis (eight corner isochrones per
+    table value), an unsplit catalogue, continued blocks, and proposals that leave the grid (a step scale that reaches the
+    grid's edge in log age)."""
+    from base_amd import engine, mcmc
+    pack_d, cl, pack, stars, priors, _ = build_problem("parsec", 8, n_stars=n_stars, wd_frac=wd_frac, n_y=3 if n_pops == 2 else 1,
+                                                       n_pops=n_pops, small=False, seed=21)
+    eng = engine.Engine(pack, stars, priors, abi.make_options(abi.MODE_MARGINALISED, n_pops, 3, 3))
+    free = np.array(list(mcmc.DEFAULT_FREE) + ([abi.P_Y, abi.P_Y2, abi.P_LAMBDA] if n_pops == 2 else []))
+    chol = np.diag([3e-4, 2e-3, 8e-4, 8e-4] + ([3e-4, 3e-4, 2e-3] if n_pops == 2 else []))
+    chol[0, 0] = 0.4 if n_stars == 2500 else chol[0, 0]                 # (this case: most log-age proposals fall off the grid)
+    start = synth.walker_params(cl["truth"], walkers, seed=3, scale=0.05, n_pops=n_pops)
+    lp0 = eng.logpost(start)
+    ids = np.arange(walkers)
+
+    def chain():
+        a = eng.mcmc_run_block(start, lp0, ids, free, chol, 17, 0, 40)
+        b = eng.mcmc_run_block(a[0], a[1], ids, free, chol, 17, 40, 25)
+        return a, b
+    fused = chain()
+    eng.set_tuning(two_launch_steps=1)
+    two = chain()
+    eng.set_tuning()
+    for f, t in zip(fused, two):
+        assert f[4] == t[4]
+        np.testing.assert_array_equal(f[2], t[2])                        # the chain: identical positions
+        np.testing.assert_allclose(f[3], t[3], rtol=1e-12)              # its log-posteriors
+        np.testing.assert_array_equal(f[0], t[0])
+    assert 0 < fused[0][4] < 40 * walkers
+    eng.close()
