@@ -3,7 +3,7 @@
 # PMC passes (never combined with a trace domain) -- on the bench shape (50k stars x 8 filters x 8 walkers, K = Q = 4).
 # usage: tools/profile_marg.sh <tag>     -> gpurun_out/<tag>_marg_*
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 CMD="python3 tools/time_marg.py 50000 4 4 8"

@@ -3,11 +3,11 @@
 # a trace domain: MI355X_MICROARCH.md "rocprofv3 PMC slots"), then tools/profile_summary.py.
 # usage: tools/profile_round.sh <tag> <commit>     -> gpurun_out/<tag>_*   (copy the summaries to profiles/)
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r05}
 COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-BENCH="python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline --no-sustained"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -- $BENCH > $O/${TAG}_trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- $BENCH > $O/${TAG}_pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/${TAG}_pmc_write -- $BENCH > $O/${TAG}_pmc_write.log 2>&1 || exit 1

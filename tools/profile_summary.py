@@ -62,6 +62,18 @@ for k, c in out["pmc"].items():
              "wave_cycles_busy_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0)),
              "wave_cycles_waiting_frac": c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0))}
 out["roofline_k_star_marg"] = mroof
+sroof = {}
+for k, c in out["pmc"].items():       # the marginalised sampler's fused step
+    if not k.startswith("k_marg_step<") or k not in out["kernels"]:
+        continue
+    t = out["kernels"][k]["avg_us"] * 1e-6
+    sroof = {"kernel": k, "avg_launch_us": out["kernels"][k]["avg_us"],
+             "valu_issue_frac": 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (N_SIMD * CLOCK * t),
+             "valu_insts_per_star_eval": c.get("SQ_INSTS_VALU", 0.0) / 400000.0,
+             "hbm_bytes_per_launch": c.get("hbm_bytes_per_launch"), "hbm_frac": c.get("hbm_bytes_per_launch", 0.0) / t / HBM_PEAK,
+             "wave_cycles_busy_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0)),
+             "wave_cycles_waiting_frac": c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0))}
+out["roofline_k_marg_step"] = sroof
 json.dump(out, open(f"gpurun_out/{tag}_summary.json", "w"), indent=1)
 with open(f"gpurun_out/{tag}_summary.md", "w") as md:
     md.write(f"# rocprofv3 summary {tag} (commit {commit}, kernel sources sha256 {out['csrc_sha256'][:16]})\n\ncommand: `{command}` under `rocprofv3 --kernel-trace --stats` and separate `--pmc` passes\n\n")
@@ -80,6 +92,10 @@ with open(f"gpurun_out/{tag}_summary.md", "w") as md:
         md.write(f"* launch: {mroof['avg_launch_us'] / 1e3:.2f} ms; fp64 VALU issue **{mroof['valu_issue_frac']:.3f}**; {mroof['valu_insts_per_star_eval']:.0f} VALU wave-instructions per star-eval\n")
         md.write(f"* HBM: {mroof['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch = {mroof['hbm_frac']:.4f} of peak; LDS bank-conflict cycles / LDS active cycles = {mroof['lds_bank_conflict_over_lds_active']:.2f}\n")
         md.write(f"* wave cycles: {mroof['wave_cycles_busy_frac']:.2f} issuing, {mroof['wave_cycles_waiting_frac']:.2f} waiting\n")
+    if sroof:
+        md.write(f"\n## Marginalised sampler: `{sroof['kernel']}` (one launch per step: decision + stars + next step's candidate tables)\n\n")
+        md.write(f"* launch: {sroof['avg_launch_us']:.1f} us; fp64 VALU issue **{sroof['valu_issue_frac']:.3f}**; {sroof['valu_insts_per_star_eval']:.0f} VALU wave-instructions per star-eval\n")
+        md.write(f"* HBM: {(sroof['hbm_bytes_per_launch'] or 0) / 1e6:.1f} MB per launch = {sroof['hbm_frac']:.4f} of peak; wave cycles: {sroof['wave_cycles_busy_frac']:.2f} issuing, {sroof['wave_cycles_waiting_frac']:.2f} waiting\n")
     md.write("\n## PMC (mean per dispatch)\n\n")
     for k, c in out["pmc"].items():
         if "copyBuffer" in k: continue
