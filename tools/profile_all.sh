@@ -7,14 +7,16 @@ TAG=${1:-r05}; COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 mkdir -p $O
-python3 bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench_line.err || exit 1
-echo "bench line done"
-python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_line_driver_shape.json 2>> $O/${TAG}_bench_line.err || exit 1
 bash tools/profile_round.sh $TAG $COMMIT > $O/${TAG}_profile_round.log 2>&1 || exit 1
 echo "profile_round done"
 bash tools/profile_marg.sh $TAG > $O/${TAG}_profile_marg.log 2>&1 || exit 1
 echo "profile_marg done"
 python3 tools/marg_stats.py $TAG > $O/${TAG}_marg_stats.log 2>&1 && cp profiles/${TAG}_marg_stats.json $O/ || echo "(marg_stats failed)"
+# the bench lines LAST: they quote the counters of the passes above (profiles/<tag>_summary.json, <tag>_marg_stats.json of THESE sources)
+cp $O/${TAG}_summary.json profiles/${TAG}_summary.json
+python3 bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench_line.err || exit 1
+echo "bench line done"
+python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_line_driver_shape.json 2>> $O/${TAG}_bench_line.err || exit 1
 { echo "# Config sweep, ${TAG} (commit ${COMMIT}; tools/config_sweep.py on one MI355X)"; echo; python3 tools/config_sweep.py; } > $O/${TAG}_config_sweep.md 2>&1 || echo "(config_sweep failed)"
 echo "config sweep done"
 { echo "# Walkers per GPU, 50k stars x 8 filters, ${TAG} (commit ${COMMIT}; tools/walker_scaling.py; 1-4 walkers run the tree launch)"; echo; python3 tools/walker_scaling.py; } > $O/${TAG}_walker_scaling.md 2>&1 || echo "(walker_scaling failed)"
