@@ -213,7 +213,12 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
 // star's sum is a function of the data, never of how the waves' clocks interleave (round 4 read the neighbours' running
 // maxima from LDS without a barrier -- a valid reference whenever it was read, but a timing-dependent one, and with it the
 // last bits of a star's value).  A wave's sub-chunks sample every region of the window, so its own maximum is within a
-// node spacing of the workgroup's.  The level-1 boxes are dealt over the waves too (wave k tests chunks k, k + 4, ...)
+// node spacing of the workgroup's.  The price (`tools/marg_stats.py`, bench cluster): 184 rows evaluated per star-eval against
+// round 4's 163, at the same launch time.  Measured and not adopted (round 5): exchanging the maxima behind a barrier after
+// every chunk of the walk (179 rows; 137.5 -> 153.6 us per step of 50k stars x 8 walkers: a barrier stalls the three waves
+// that are ahead); starting the walk at the chunk whose boxes look best for the 64 stars together and re-testing level 1
+// at every later chunk (184 rows, 141.0 us); the same plus ONE exchange after that first chunk (179 rows, 155.4 us).
+// What a wave evaluates is the union of its stars' own halos, whatever the order it meets them in.  The level-1 boxes are dealt over the waves too (wave k tests chunks k, k + 4, ...)
 // and the outcome travels as a bit mask in LDS.
 #define B9_MARG_MASK_WORDS 16        // level-1 outcomes of up to 1024 chunks go through the mask; later chunks are tested by every wave
 
