@@ -195,6 +195,18 @@ int b9k_marg_split(int n_star_chunks, int n_pops) { return n_star_chunks * n_pop
 long long b9k_marg_shares_doubles(int n_pieces, int n_pops) { return (long long)std::max(1, n_pieces) * n_pops * 128; }      // per walker
 long long b9k_marg_wd_table_doubles(int nfp, int K) { return (long long)8 * K * (2 * nfp + 1); }       // per (walker, population)
 
+// Does a launch of `wgs` star workgroups leave the chip nearly empty (at most five waves per SIMD on average)?  Then its waves
+// are latency-bound on the row loop: the SPARSE tile setting (star_marg_body, TILE = 2: same bits, speed only).
+static bool marg_sparse(long long wgs)
+{
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
+    }
+    return wgs * 4 <= (long long)5 * n_cu * 4;
+}
+
 template <int NFP, int NPOPS, bool SAMPLE>
 static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, const IsoHdr *hdr, const double *iso_data,
                                      long long iso_stride, int mass_cap, const double *d_params, int n_walkers,
@@ -229,8 +241,19 @@ static hipError_t launch_star_marg_t(const DevPack &pk, const DevStars &st, cons
     if (split && !shares) return hipErrorInvalidValue;
     const int per_xcd = (((split ? st.mg_n_pieces : n_chunks) + csplit - 1) / csplit) * (n_walkers / wsplit);
     const double cut2 = prune ? 2.0 * B9_MARG_CUT : __builtin_inf();
-    if (split)
-        hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, !SAMPLE>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
+    // rows through LDS tiles or through scalar registers (star_marg_body, TILE): measured per instance -- 8 (4) filters x one
+    // population, unsplit, is the one shape the scalar path still wins in this kernel (2.20 against 2.17e9 star-evals/s)
+    const bool sparse = !SAMPLE && split && marg_sparse((long long)st.mg_n_pieces * n_walkers);
+    const bool tiled = !SAMPLE && (split || NPOPS == 2 || NFP >= 16);
+    const size_t tile_lds = sizeof(double) * 4 * B9_TILE_DOUBLES(NFP);
+    if (sparse)
+        hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, !SAMPLE, false, SAMPLE ? 0 : 2>), dim3(8 * per_xcd), dim3(256), tile_lds, stream, pk, st, hdr, iso_data, iso_stride,
+                           mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, shares);
+    else if (split)
+        hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, !SAMPLE, false, SAMPLE ? 0 : 1>), dim3(8 * per_xcd), dim3(256), tile_lds, stream, pk, st, hdr, iso_data, iso_stride,
+                           mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, shares);
+    else if (tiled)
+        hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, false, false, SAMPLE ? 0 : 1>), dim3(8 * per_xcd), dim3(256), tile_lds, stream, pk, st, hdr, iso_data, iso_stride,
                            mass_cap, d_params, partial, partial_stride, perstar, K, Q, ms, tab, L, n_walkers, cut2, wsplit, shares);
     else
         hipLaunchKernelGGL((k_star_marg<NFP, NPOPS, SAMPLE, false>), dim3(8 * per_xcd), dim3(256), 0, stream, pk, st, hdr, iso_data, iso_stride,
@@ -360,9 +383,14 @@ static hipError_t launch_marg_step(const DevPack &pk, const DevStars &st, const 
     const size_t rows = (size_t)W * NPOPS, c0 = (size_t)sd.set * 2;
     const IsoHdr *hdr_rd = sd.cand_hdr + c0 * rows;
     const double *par_rd = sd.cand_par + c0 * W * B9_NPARAM, *tab_rd = tab + c0 * rows * mx.L.total, *wd_rd = wd_tab ? wd_tab + c0 * wd_stride : nullptr;
+    static_assert(B9_MSTEP_LDS_DOUBLES(NFP, 2) >= 4 * B9_TILE_DOUBLES(NFP), "the star role's row tiles borrow the builders' dynamic LDS");
     if (split) {
-        hipLaunchKernelGGL((k_marg_step<NFP, NPOPS, true>), dim3(front + stars + wd), dim3(256), lds, stream, pk, st, sd, pr, mx, front, stars,
-                           hdr_rd, par_rd, tab_rd, wd_rd);
+        if (marg_sparse((long long)st.mg_n_pieces * W))
+            hipLaunchKernelGGL((k_marg_step<NFP, NPOPS, true, 2>), dim3(front + stars + wd), dim3(256), lds, stream, pk, st, sd, pr, mx, front, stars,
+                               hdr_rd, par_rd, tab_rd, wd_rd);
+        else
+            hipLaunchKernelGGL((k_marg_step<NFP, NPOPS, true>), dim3(front + stars + wd), dim3(256), lds, stream, pk, st, sd, pr, mx, front, stars,
+                               hdr_rd, par_rd, tab_rd, wd_rd);
         hipLaunchKernelGGL((k_marg_step_merge<NPOPS>), dim3(n_chunks, W), dim3(64), 0, stream, st, sd, mx);
     } else {
         hipLaunchKernelGGL((k_marg_step<NFP, NPOPS, false>), dim3(front + stars + wd), dim3(256), lds, stream, pk, st, sd, pr, mx, front, stars,

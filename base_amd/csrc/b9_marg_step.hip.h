@@ -302,7 +302,7 @@ struct MargStepSel {
     }
 };
 
-template <int NFP, int NPOPS, bool SPLIT>
+template <int NFP, int NPOPS, bool SPLIT, int TILE>
 __device__ __forceinline__ int marg_step_body(const DevPack &pk, const DevStars &st, const StepDev &sd, const DevPriors &pr, const MargStep &mx,
                                               int front_blocks, int star_blocks, const IsoHdr *__restrict__ hdr_rd, const double *__restrict__ par_rd,
                                               const double *__restrict__ tab_rd, const double *__restrict__ wd_rd, double *smem)
@@ -336,7 +336,7 @@ __device__ __forceinline__ int marg_step_body(const DevPack &pk, const DevStars 
     double *const partial = sd.partial + (size_t)sd.set * (sd.partial_stride / 2);
     const MargSample ms{};
     if (b < star_blocks) {
-        star_marg_body<NFP, NPOPS, false, SPLIT, false>(pk, st, b, nullptr, 0, sd.mass_cap, partial, sd.partial_stride, nullptr, mx.K, mx.Q, ms, mx.L,
+        star_marg_body<NFP, NPOPS, false, SPLIT, false, TILE>(pk, st, b, smem, nullptr, 0, sd.mass_cap, partial, sd.partial_stride, nullptr, mx.K, mx.Q, ms, mx.L,
                                                         W, mx.cut2, mx.wsplit, mx.shares, select);
         return 0;
     }
@@ -347,14 +347,15 @@ __device__ __forceinline__ int marg_step_body(const DevPack &pk, const DevStars 
 }
 
 
-template <int NFP, int NPOPS, bool SPLIT>
-__global__ __launch_bounds__(256, B9_MSTEP_WAVES(NFP, NPOPS))
+// (TILE: the star role's rows through the dynamic LDS the builders' tiles occupy in THEIR workgroups -- star_marg_body)
+template <int NFP, int NPOPS, bool SPLIT, int TILE = 1>
+__global__ __launch_bounds__(256, TILE ? B9_TILE_OCC(NFP, NPOPS, TILE) : B9_MSTEP_WAVES(NFP, NPOPS))
 void k_marg_step(DevPack pk, DevStars st, StepDev sd, DevPriors pr, MargStep mx, int front_blocks, int star_blocks,
                  const IsoHdr *__restrict__ hdr_rd, const double *__restrict__ par_rd, const double *__restrict__ tab_rd, const double *__restrict__ wd_rd)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     B9_GANTT_ENTER();
-    const int role = marg_step_body<NFP, NPOPS, SPLIT>(pk, st, sd, pr, mx, front_blocks, star_blocks, hdr_rd, par_rd, tab_rd, wd_rd, smem);
+    const int role = marg_step_body<NFP, NPOPS, SPLIT, TILE>(pk, st, sd, pr, mx, front_blocks, star_blocks, hdr_rd, par_rd, tab_rd, wd_rd, smem);
     B9_GANTT_EXIT(sd.step, role);
 }
 

@@ -158,9 +158,16 @@ template <> struct SRow<16> {
     __device__ __forceinline__ double mag(int f) const { return f < 8 ? m0[f & 7] : m1[f & 7]; }
 };
 
-// X = nb + chi^2 of a row held in scalar registers
-template <int NFP>
-__device__ __forceinline__ double srow_x(const SRow<NFP> &r, const double (&so)[NFP], const double (&sw)[NFP])
+// The same row as the TILE instances hold it: read back from the wave's LDS tile (every lane the same address: a broadcast)
+// into vector registers.
+template <int NFP> struct VRow {
+    double m[NFP], nb;
+    __device__ __forceinline__ double mag(int f) const { return m[f]; }
+};
+
+// X = nb + chi^2 of a row held in scalar registers (or, TILE, in vector registers: the same operations)
+template <int NFP, class Row>
+__device__ __forceinline__ double srow_x(const Row &r, const double (&so)[NFP], const double (&sw)[NFP])
 {
     double x = r.nb;
 #pragma unroll
@@ -234,8 +241,24 @@ struct MargSelPlain {
     __device__ __forceinline__ MargSel finish(int) const { return s; }
 };
 
-template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, bool COST, class Select>
-__device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars &st, int block_id,
+// TILE: how a unit's 16 rows reach the lanes.  The scalar path (SRow) holds ONE row ahead in scalar registers -- all that
+// fits -- so a wave pays a scalar-load round trip per row unless six other waves of its SIMD cover it.  The TILE instances
+// fetch a unit's 16 rows + 16 nb words in ONE vector round trip (lane l: 16 bytes of the kilobyte), stage them in the wave's
+// LDS tile (`tile_lds`: 4 x (16 NFP + 16) doubles; in k_marg_step the dynamic LDS its builders' tiles occupy in THEIR
+// workgroups) and read them back row by row as broadcasts into vector registers.  Same rows, same operations, same order:
+// the bits of the scalar path -- which instance runs is the launch's choice (b9_kernels.hip).  Measured, us per sampler
+// step, scalar -> tile: one chain on 10k stars 31.6 -> 26.2 (a lone wave is latency-bound), 20k stars 37.2 -> 33.3; 8
+// walkers x 50k stars 138.0 -> 133.9; two populations (30k stars x 8 walkers) 207 -> 175; 16 filters 238 -> 215.  Built for
+// B9_TILE_OCC waves per SIMD with B9_TILE_UNROLL rows in flight (sweep: 8 filters occupancy 4 / 5 / 6 / 7: 146 / 137 / 134 /
+// 138 us; two populations 186 / 175 / 184 / 192; 16 filters at 6: 418, the rows spill).
+#define B9_TILE_DOUBLES(NFP) (16 * (NFP) + 16)
+// TILE = 2, the SPARSE setting (launches that leave the chip nearly empty: one chain on a split catalogue): four rows in flight
+// at occupancy 4 -- 20k stars, one chain, 8 x 8 grid: 62.0 -> 55.9 us per step; with 8 walkers on the same catalogue it
+// loses (91 -> 99.7), so the launch picks by its own size (b9_kernels.hip: marg_sparse).
+#define B9_TILE_OCC(NFP, NPOPS, TILE) (((NFP) >= 16 || (TILE) == 2) ? 4 : ((NPOPS) == 2 ? 5 : 6))
+#define B9_TILE_UNROLL(NFP, NPOPS, TILE) (((NFP) >= 16 || (NPOPS) == 2 || (TILE) == 2) ? 4 : 2)
+template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, bool COST, int TILE, class Select>
+__device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars &st, int block_id, double *tile_lds,
                  const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
                  double *__restrict__ partial, long long partial_stride, double *__restrict__ perstar,
                  int K, int Q, const MargSample &ms, const MargLayout &L,
@@ -360,7 +383,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
                 if (COST) ++n_cost;
                 const double *__restrict__ const rowp = t_rows + ((size_t)u * Q + j) * 16 * NFP;
                 // one row's term for every lane (the 64 stars), into the lanes that still count it
-                auto term = [&](const SRow<NFP> &r, int i) {
+                auto term = [&](const auto &r, int i) {
                     const double x = srow_x<NFP>(r, so, sw);
                     const bool live = x < xcut;
                     MSTAT_LIVE(4, live);
@@ -379,6 +402,31 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
                         lse_term(t, ref[kp], sm[kp], tmax[kp]);
                     }
                 };
+                if constexpr (TILE) {
+                    constexpr int T_UNROLL = B9_TILE_UNROLL(NFP, NPOPS, TILE);
+                    // the unit in one vector round trip -> the wave's LDS tile -> rows as broadcasts
+                    double *const tile = tile_lds + wave * B9_TILE_DOUBLES(NFP);
+                    const double2 *__restrict__ const src = reinterpret_cast<const double2 *>(rowp);
+                    double2 v[(NFP + 7) / 8];
+#pragma unroll
+                    for (int k = 0; k < (NFP + 7) / 8; ++k) v[k] = (NFP >= 8 || lane < 32) ? src[lane + 64 * k] : double2{0.0, 0.0};
+                    const double nbv = nbp[lane & 15];
+                    __builtin_amdgcn_wave_barrier();             // (the previous unit's reads of the tile are done)
+#pragma unroll
+                    for (int k = 0; k < (NFP + 7) / 8; ++k) if (NFP >= 8 || lane < 32) reinterpret_cast<double2 *>(tile)[lane + 64 * k] = v[k];
+                    if (lane < 16) tile[16 * NFP + lane] = nbv;
+                    __builtin_amdgcn_wave_barrier();             // (one wave: its LDS accesses complete in program order)
+#pragma unroll T_UNROLL
+                    for (int i = 0; i < 16; ++i) {
+                        VRow<NFP> r;
+#pragma unroll
+                        for (int f = 0; f < NFP; ++f) r.m[f] = tile[i * NFP + f];
+                        r.nb = tile[16 * NFP + i];
+                        term(r, i);
+                    }
+                    xcut = fma(-2.0, tmax[kp], cut2);
+                    continue;
+                }
                 // the unit's 16 rows, two at a time: row i + 1 is requested before row i is evaluated.  (The request past the
                 // unit's last row reads the next unit's first row / the word after nb's sub-chunk: inside the table, unused.)
                 SRow<NFP> ra, rb;
@@ -455,8 +503,8 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     MLIFE(1, __builtin_amdgcn_s_memrealtime());
 }
 
-template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, bool COST = false>
-__global__ __launch_bounds__(256, B9_MARG_WAVES(NFP, NPOPS, SAMPLE))
+template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, bool COST = false, int TILE = 0>
+__global__ __launch_bounds__(256, TILE ? B9_TILE_OCC(NFP, NPOPS, TILE) : B9_MARG_WAVES(NFP, NPOPS, SAMPLE))
 void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                  const double *__restrict__ iso_data, long long iso_stride,
                  int mass_cap, const double *__restrict__ params,
@@ -464,7 +512,8 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
                  int K, int Q, MargSample ms, const double *__restrict__ tab, MargLayout L,
                  int n_walkers, double cut2, int wsplit, double *__restrict__ shares)
 {
-    star_marg_body<NFP, NPOPS, SAMPLE, SPLIT, COST>(pk, st, (int)blockIdx.x, iso_data, iso_stride, mass_cap, partial, partial_stride, perstar, K, Q, ms, L,
+    extern __shared__ __attribute__((aligned(16))) double tile_lds[];        // (TILE: 4 x B9_TILE_DOUBLES doubles)
+    star_marg_body<NFP, NPOPS, SAMPLE, SPLIT, COST, TILE>(pk, st, (int)blockIdx.x, tile_lds, iso_data, iso_stride, mass_cap, partial, partial_stride, perstar, K, Q, ms, L,
                                                     n_walkers, cut2, wsplit, shares, MargSelPlain{MargSel{hdr, params, tab}});
 }
 
