@@ -83,7 +83,7 @@ int run_block_fused(b9_ctx *ctx, b9_mcmc_block *blk, bool marg)
         // four candidate sets (two parities x two candidates) of node tables, WD tables and split shares
         int rc = ensure_marg_table(ctx, 4 * W, n_pops, mb.K, mb.Q);
         if (rc) return rc;
-        mb.n_partial = ctx->st.mg_pad / 64 + ctx->st.n_wd;
+        mb.n_partial = ctx->st.mg_pad / 64 + (ctx->st.n_wd + 3) / 4;
         mb.stride = 2 * (((long long)mb.n_partial + 7) & ~7ll);
         rc = ensure_capacity(ctx, W, n_pops, (size_t)std::max<long long>(mb.stride, partial_stride(ctx)) * W, false);
         if (rc) return rc;

@@ -16,10 +16,10 @@ Bufs buffer_set(const b9_ctx *ctx, int set)
 }
 
 // number of partial sums one walker gets from the star kernel under the current plan / mode
-// (marginalised mode: one per 64-star chunk -- the star kernel sums a chunk's values in a fixed order -- and one per WD-stage star)
+// (marginalised mode: one per 64-star chunk -- the star kernel sums a chunk's values in a fixed order -- and one per four WD-stage stars)
 int partial_count(const b9_ctx *ctx, const B9Groups &plan)
 {
-    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.mg_pad / 64 + ctx->st.n_wd : plan.n_groups * 4 + ctx->heavy_parts;
+    return ctx->opt.mode == B9_MODE_MARGINALISED ? ctx->st.mg_pad / 64 + (ctx->st.n_wd + 3) / 4 : plan.n_groups * 4 + ctx->heavy_parts;
 }
 
 // doubles between two walkers' partial rows (room for either mode's row)

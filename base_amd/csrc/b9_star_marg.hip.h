@@ -757,17 +757,23 @@ __device__ __forceinline__ void star_marg_wd_body(const DevPack &pk, const DevSt
     const double c0m = st.c0m[slot], la = st.la[slot];
     const int wd_type = st.flags[slot] & 1;
     const MargSel sel = select.finish(w);
-    if (!live) return;
+    // the workgroup's four stars leave ONE partial: their values summed in wave order ((v0 + v1) + (v2 + v3); a wave past
+    // the last star adds 0) -- a catalogue of a thousand WD-stage stars had a thousand partials for every decision to read
+    __shared__ double s_v4[4];
+    double v_out = 0.0;
+    const int k_part = (st.mg_pad >> 6) + block_x;
     const IsoHdr *__restrict__ const hdr = sel.hdr;
     const double *__restrict__ const wtab = sel.tab;
     const double *par = sel.params + (size_t)w * B9_NPARAM;
     IsoView<NFP> iso[NPOPS];
     double tip_min;
     const bool valid = load_iso_views<NFP, NPOPS>(hdr, iso_data, iso_stride, mass_cap, w, iso, tip_min);
-    if (!valid) {
-        if (lane == 0) { partial[(size_t)w * partial_stride + (st.mg_pad >> 6) + k_wd] = 0.0; if (perstar) perstar[(size_t)w * st.n + orig] = NEG_INF; }
+    if (!valid) {          // (uniform over the workgroup: one walker)
+        if (lane == 0 && live && perstar) perstar[(size_t)w * st.n + orig] = NEG_INF;
+        if (tid == 0) partial[(size_t)w * partial_stride + k_part] = 0.0;
         return;
     }
+    if (live) {
     double ll[NPOPS];
     Best best; best.key = NEG_INF; best.mass = 0.0; best.ratio = 0.0; best.pop = 0;
     const unsigned long long g_row = SAMPLE ? (unsigned long long)(ms.row0 + w) : 0ull;
@@ -818,7 +824,7 @@ __device__ __forceinline__ void star_marg_wd_body(const DevPack &pk, const DevSt
         double l = ll[0];
         if (NPOPS == 2) { const double lam = par[B9_P_LAMBDA]; l = logaddexp(log(lam) + ll[0], log1p(-lam) + ll[NPOPS - 1]); }
         const double v = logaddexp(la, l);
-        partial[(size_t)w * partial_stride + (st.mg_pad >> 6) + k_wd] = v;        // (a WD-stage star's value is a partial of its own)
+        v_out = v;
         if (perstar) perstar[(size_t)w * st.n + orig] = v;
         if (SAMPLE) {
             const size_t o = (size_t)w * st.n + orig;
@@ -829,6 +835,10 @@ __device__ __forceinline__ void star_marg_wd_body(const DevPack &pk, const DevSt
             if (ms.pop) ms.pop[o] = any ? best.pop : 0;
         }
     }
+    }
+    if (lane == 0) s_v4[wave] = v_out;
+    __syncthreads();
+    if (tid == 0) partial[(size_t)w * partial_stride + k_part] = (s_v4[0] + s_v4[1]) + (s_v4[2] + s_v4[3]);
 }
 
 template <int NFP, int NPOPS, bool SAMPLE>
