@@ -23,8 +23,9 @@ for k, c in out["pmc"].items():         # MI355X_MICROARCH.md "HBM": FETCH_SIZE 
     if "FETCH_SIZE" in c:
         c["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
 HBM_PEAK, CLOCK, N_SIMD, EVALS = 8.0e12, 2.4e9, 1024, 400000.0
+_main = sorted((k for k in out["pmc"] if k.startswith("k_star_marg<") and k in out["kernels"]), key=lambda k: -out["kernels"][k]["calls"] * out["kernels"][k]["avg_us"])[:1]
 for k, c in out["pmc"].items():
-    if not k.startswith("k_star_marg<") or k not in out["kernels"]:
+    if k not in _main:
         continue
     t = out["kernels"][k]["avg_us"] * 1e-6
     wc = max(1.0, c.get("SQ_WAVE_CYCLES", 1.0))

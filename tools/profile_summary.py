@@ -50,8 +50,10 @@ for k, c in out["pmc"].items():
             "wave_cycles_waiting_frac": c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0))}
 out["roofline_k_mcmc_step"] = roof
 mroof = {}
+# (several k_star_marg instances run: the catalogue plan's one-launch counting pass is one -- the instance with the most time is meant)
+_marg = sorted((k for k in out["pmc"] if k.startswith("k_star_marg<") and k in out["kernels"]), key=lambda k: -out["kernels"][k]["calls"] * out["kernels"][k]["avg_us"])[:1]
 for k, c in out["pmc"].items():
-    if not k.startswith("k_star_marg<") or k not in out["kernels"]:
+    if k not in _marg:
         continue
     t = out["kernels"][k]["avg_us"] * 1e-6
     mroof = {"kernel": k, "avg_launch_us": out["kernels"][k]["avg_us"],
