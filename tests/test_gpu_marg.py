@@ -180,3 +180,39 @@ def test_fused_marginalised_step_equals_the_two_launch_step(n_pops, wd_frac, n_s
         np.testing.assert_array_equal(f[0], t[0])
     assert 0 < fused[0][4] < 40 * walkers
     eng.close()
+
+
+def test_catalogue_plan_changes_rounding_only_and_survives_an_off_grid_reference():
+    """The marginalised catalogue plan (measured dispatch order, cost-proportional pieces of a small catalogue) decides how a
+    star's sum is grouped, nothing else: per-star values under different piece sizes (b9_tuning.marg_piece_units) agree to
+    1e-12 and each setting is bit-reproducible; priors whose means lie OUTSIDE the grid (the plan's reference row is clamped
+    into it) and priors without a usable reference (NaN means) still give the oracle's values."""
+    from base_amd import engine
+    pack_d, cl, pack, stars, priors, _ = build_problem("parsec", 8, n_stars=5000, small=False, seed=31)
+    opt = abi.make_options(abi.MODE_MARGINALISED, 1, 3, 4)
+    eng = engine.Engine(pack, stars, priors, opt)
+    rows = synth.walker_params(cl["truth"], 2, seed=5, scale=0.05)
+    base_lp, base_ps = eng.logpost(rows, perstar=True)
+    for units in (2, 9):
+        eng.set_tuning(marg_piece_units=units)
+        lp, ps = eng.logpost(rows, perstar=True)
+        lp2, ps2 = eng.logpost(rows, perstar=True)
+        assert np.array_equal(ps, ps2) and np.array_equal(lp, lp2)
+        np.testing.assert_allclose(ps, base_ps, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lp, base_lp, rtol=1e-12)
+    eng.set_tuning()
+    want = oracle.Oracle(pack, stars, priors, opt, native=True).logpost(rows[:1], perstar=True)[1]
+    for bad in ("outside", "nan"):
+        pr = abi.b9_priors()
+        for k in range(abi.B9_NPARAM):
+            pr.mean[k], pr.var[k] = priors.mean[k], priors.var[k]
+        pr.log_age_min, pr.log_age_max = priors.log_age_min, priors.log_age_max
+        pr.mean[abi.P_LOGAGE] = 99.0 if bad == "outside" else float("nan")
+        pr.mean[abi.P_MOD] = priors.mean[abi.P_MOD] + (25.0 if bad == "outside" else 0.0)      # (a reference row no star is near)
+        e2 = engine.Engine(pack, stars, pr, opt)
+        got = e2.logpost(rows[:1], perstar=True)[1]
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin)
+        assert np.max(np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))) <= 1e-9
+        e2.close()
+    eng.close()
