@@ -290,6 +290,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     if (SPLIT ? pos >= st.mg_n_pieces : pos * 64 >= st.mg_pad) return;
     const int piece = SPLIT ? st.mg_piece[pos] : 0;
     const int split = SPLIT ? (piece >> 20) & 31 : 0, n_split = SPLIT ? (piece >> 25) & 63 : 1;      // (at most 32 pieces)
+    HSTAMP(0);
     select.issue(w);
     const int sc = SPLIT ? piece & 0xFFFFF : st.marg_order[pos];
     const int slot = sc * 64 + lane;                                // (slot of the marginalised mode's own copy: DevStars::mg_*)
@@ -300,6 +301,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     for (int f = 0; f < NFP; ++f) { so[f] = st.mg_so[B9_SIDX(NFP, f, slot)]; sw[f] = st.mg_sw[B9_SIDX(NFP, f, slot)]; }
     const double c0m = st.mg_c0m[slot], la = st.mg_la[slot];
     const MargSel sel = select.finish(w);
+    HSTAMP(1);
     const IsoHdr *__restrict__ const hdr = sel.hdr;
     const double *__restrict__ const tab = sel.tab;
     const double *par = sel.params + (size_t)w * B9_NPARAM;
@@ -353,6 +355,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     }
     __syncthreads();
 
+    HSTAMP(2);
     Best best; best.key = NEG_INF; best.mass = 0.0; best.ratio = 0.0; best.pop = 0;
     const unsigned long long g_row = SAMPLE ? (unsigned long long)(ms.row0 + w) : 0ull;
     unsigned n_cost = 0;                                 // COST: (16 nodes x one mass ratio) units this wave evaluates
@@ -370,10 +373,16 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
         auto chunk = [&](int c) {
             MSTAT(1, 1);
             double xcut = fma(-2.0, tmax[kp], cut2);                      // a term counts while X < xcut
-            const int u = c * 4 + wave;
+            // The chunk's 4 Q units (sub-chunk of 16 nodes x mass ratio) are dealt over the four waves DIAGONALLY: unit (sub, j)
+            // is wave (2 sub + j) mod 4's.  A main-sequence star's window is one or two sub-chunks wide and alive at the first one
+            // or two mass ratios (a q = 0.5 companion already costs it its chi^2): with wave k taking sub-chunk k whole, one or
+            // two waves walked all of it while the others waited at the closing barrier (tools/gantt_marg.py: walk 13 us against
+            // 2) -- dealt this way, two sub-chunks x two mass ratios are four waves' work.
+            for (int sub = 0; sub < 4; ++sub) {
+            const int u = c * 4 + sub;
             const double nbm = t_nbmin16[u];
             const double *__restrict__ const nbp = t_nb + u * 16;
-            for (int j = 0; j < Q; ++j) {
+            for (int j = (wave - 2 * sub) & 3; j < Q; j += 4) {
                 // level 2: this wave's 16 nodes x one mass ratio
                 const double lb2 = box_bound<NFP>(t_box2 + ((size_t)u * Q + j) * 2 * NFP, so, sw);
                 MSTAT(2, 1);
@@ -445,6 +454,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
                 }
                 xcut = fma(-2.0, tmax[kp], cut2);
             }
+            }
         };
         const int n_words = (n_chunks + 63) >> 6;
         for (int wi = 0; wi < n_words && wi < B9_MARG_MASK_WORDS; ++wi) {
@@ -460,7 +470,9 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     }
     if (SAMPLE) { s_bkey[wave][lane] = best.key; s_bmass[wave][lane] = best.mass; s_bratio[wave][lane] = best.ratio; s_bpop[wave][lane] = best.pop; }
     if (COST && lane == 0) ms.cost[(size_t)sc * 4 + wave] = n_cost;
+    HSTAMP(3);
     __syncthreads();
+    HSTAMP(4);
     if (wave != 0) return;
     // ---- wave 0: merge the four shares, finish the star, sum the chunk
     double ll[NPOPS];
@@ -472,6 +484,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
         double S = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) S += (s_sm[kp][k][lane] > 0.0) ? s_sm[kp][k][lane] * exp_fast(s_ref[kp][k][lane] - r) : 0.0;
+        HSTAMP(5);
         if (SPLIT) {                                    // this workgroup's share of the star's sum: merged by k_marg_merge
             double *sh = shares + ((((size_t)w * st.mg_n_pieces + st.mg_share_base[sc] + split) * NPOPS + kp) * 128);
             sh[lane] = r; sh[64 + lane] = S;

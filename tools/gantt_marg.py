@@ -65,3 +65,10 @@ if eng.lib.b9_debug_read_gantt_heavy(hb.ctypes.data) == 0:
         if r[5] <= 0 or r[0] <= 0:
             continue
         print(f"   wg {k:2d}: row {(r[1]-r[0])/100:5.2f} | header {(r[2]-r[1])/100:5.2f} | tiles {(r[3]-r[2])/100:5.2f} | rows {(r[4]-r[3])/100:5.2f} | nb+box1 {(r[5]-r[4])/100:5.2f} | total {(r[5]-r[0])/100:5.2f}")
+    first_star = min((k for k in range(64) if h[k][0] > 0 and h[k][5] > 0 and h[k][1] > h[k][0] and (h[k][2] - h[k][1]) < (h[k][3] - h[k][2]) * 50), default=None)
+    print("star workgroups among the first 64 ids (the launch's most expensive pieces), wave 0, us: entry -> decision | headers + level 1 + barrier | walk | wait for the other waves | merge")
+    for k in range(64):
+        r = h[k]
+        if r[0] <= 0 or r[4] <= 0 or r[3] < r[2] or (t[order[-2]][k][2] & 0xFF) != 0:
+            continue
+        print(f"   wg {k:2d}: decision {(r[1]-r[0])/100:5.2f} | level 1 {(r[2]-r[1])/100:5.2f} | walk {(r[3]-r[2])/100:5.2f} | barrier {(r[4]-r[3])/100:5.2f} | merge {(r[5]-r[4])/100:5.2f} | total {(r[5]-r[0])/100:5.2f}")
