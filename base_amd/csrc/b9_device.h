@@ -112,10 +112,12 @@ struct DevStars {
 //   nbmin16 [chunk][sub]                              smallest nb of the sub-chunk
 //   box1    [chunk]{lo[f], hi[f]}                     the same over the chunk's 64 nodes and all mass ratios
 //   nbmin64 [chunk]
+//   box2f, box1f                                      the same boxes as FLOATS rounded outward (nfp doubles' worth each: the
+//                                                     packed-fp32 box test, b9_star_marg.hip.h box_bound32)
 // ------------------------------------------------------------------------------------------
 struct MargLayout {
     int npad, n_chunks, nfp, Q;
-    long long o_rows, o_nb, o_box2, o_nbmin16, o_box1, o_nbmin64, total;
+    long long o_rows, o_nb, o_box2, o_nbmin16, o_box1, o_nbmin64, o_box2f, o_box1f, total;
 };
 
 static inline __host__ __device__ MargLayout marg_layout(int nfp, int mass_cap, int K, int Q)
@@ -131,6 +133,8 @@ static inline __host__ __device__ MargLayout marg_layout(int nfp, int mass_cap, 
     L.o_nbmin16 = o; o += (L.n_chunks * 4 + 7) / 8 * 8;
     L.o_box1 = o;    o += (long long)L.n_chunks * 2 * nfp;
     L.o_nbmin64 = o; o += (L.n_chunks + 7) / 8 * 8;
+    L.o_box2f = o;   o += (long long)L.n_chunks * 4 * Q * nfp;
+    L.o_box1f = o;   o += (long long)L.n_chunks * nfp;
     L.total = o;
     return L;
 }

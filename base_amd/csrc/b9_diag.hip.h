@@ -68,6 +68,12 @@ extern "C" int b9_debug_read_gantt_walk(unsigned long long *out)
 #define HS2_LANE 0
 #define HS2(k) do { if (threadIdx.x == HS2_LANE && blockIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_heavy2[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define HSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_heavy[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+__device__ unsigned long long g_gantt_star[64 * 4 * 8];       // phase stamps of the marginalised star role: [role-relative workgroup id < 64][wave][phase]
+extern "C" int b9_debug_read_gantt_star(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_star), sizeof(unsigned long long) * 64 * 4 * 8);
+}
+#define SSTAMP(id, k) do { if ((threadIdx.x & 63) == 0 && (id) < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_star[((id) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define WSTAMP_LANDED(a, b) do { WSTAMP(a); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WSTAMP(b); } while (0)
 // start / end of every workgroup of the fused-step and tree kernels: [t_in, t_out, role | XCC id << 8 | HW_ID << 16, launch index]
 #define B9_GANTT_ENTER() const unsigned long long t_in_ = __builtin_amdgcn_s_memrealtime()
@@ -91,6 +97,7 @@ extern "C" int b9_debug_read_gantt_walk(unsigned long long *out)
 #define WSTAMP_LANDED(a, b) do {} while (0)
 #define HS2(k) do {} while (0)
 #define HSTAMP(k) do {} while (0)
+#define SSTAMP(id, k) do {} while (0)
 #define WSTAMP(k) do {} while (0)
 #define WSTAMP_ON(v) do {} while (0)
 #endif

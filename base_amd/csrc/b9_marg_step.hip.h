@@ -102,9 +102,10 @@ __device__ __forceinline__ void rows_min_max(double &lo, double &hi)
     lo = __builtin_fmin(lo, lane_down<32>(lo)); hi = __builtin_fmax(hi, lane_down<32>(hi));
 }
 
-template <int NFP>
+template <int NFP, int NPOPS>
 __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDev &sd, const MargStep &mx, int w, int cand, int pop, int c, double *smem)
 {
+    constexpr bool box32 = B9_BOX32(NFP, NPOPS);
     if (!sd.derive_next || MSTEP_NO_BUILD) return;
     const int tid = threadIdx.x, lane = tid & 63, jl = tid >> 6, W = sd.n_walkers, n_pops = sd.n_pops, K = mx.K, Q = mx.Q;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mass_cap = sd.mass_cap;
@@ -207,10 +208,7 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
             // boxes: a NaN magnitude stays out of them (fmin / fmax ignore it); its term is dropped by the star loop's X < xcut
             double lo = ok ? C : __builtin_inf(), hi = ok ? C : NEG_INF;
             row_min_max(lo, hi);
-            if (i16 == 0) {
-                double *b2 = out + L.o_box2 + ((size_t)u * Q + j) * 2 * NFP;
-                b2[f] = lo <= hi ? lo : 0.0; b2[NFP + f] = lo <= hi ? hi : 0.0;
-            }
+            if (i16 == 0) box_store<NFP>(box32, out + L.o_box2 + ((size_t)u * Q + j) * 2 * NFP, out + L.o_box2f + ((size_t)u * Q + j) * NFP, f, lo, hi);
             rows_min_max(lo, hi);
             if (lane == 0) { s_box[jl][0][f] = __builtin_fmin(s_box[jl][0][f], lo); s_box[jl][1][f] = __builtin_fmax(s_box[jl][1][f], hi); }
         }
@@ -230,8 +228,7 @@ __device__ __forceinline__ void marg_build_table(const DevPack &pk, const StepDe
     if (tid < NFP) {
         double lo = s_box[0][0][tid], hi = s_box[0][1][tid];
         for (int k = 1; k < 4; ++k) { lo = __builtin_fmin(lo, s_box[k][0][tid]); hi = __builtin_fmax(hi, s_box[k][1][tid]); }
-        double *b1 = out + L.o_box1 + (size_t)c * 2 * NFP;
-        b1[tid] = lo <= hi ? lo : 0.0; b1[NFP + tid] = lo <= hi ? hi : 0.0;
+        box_store<NFP>(box32, out + L.o_box1 + (size_t)c * 2 * NFP, out + L.o_box1f + (size_t)c * NFP, tid, lo, hi);
     }
     HSTAMP(5);
 }
@@ -317,7 +314,7 @@ __device__ __forceinline__ int marg_step_body(const DevPack &pk, const DevStars 
         if (b < n_tab) {        // b = ((w * 2 + cand) * NPOPS + pop) * n_chunks_cap + c
             const int c = b % mx.n_chunks_cap; b /= mx.n_chunks_cap;
             const int pop = b % NPOPS; b /= NPOPS;
-            marg_build_table<NFP>(pk, sd, mx, b >> 1, b & 1, pop, c, smem);
+            marg_build_table<NFP, NPOPS>(pk, sd, mx, b >> 1, b & 1, pop, c, smem);
             return 2;
         }
         b -= n_tab;

@@ -93,7 +93,7 @@ typedef const __attribute__((address_space(4))) double *b9_ctab;
 // lower bound of sum_f w_f (C_f - obs_f)^2 over every row with lo_f <= C_f <= hi_f (box = {lo[NFP], hi[NFP]}, wave-uniform):
 // the scaled distance of obs_f to the interval is max(sw lo - so, so - sw hi, 0)
 template <int NFP>
-__device__ __forceinline__ double box_bound(b9_ctab box, const double (&so)[NFP], const double (&sw)[NFP])
+__device__ __forceinline__ double box_bound64(b9_ctab box, const double (&so)[NFP], const double (&sw)[NFP])
 {
     double lb = 0.0;
 #pragma unroll
@@ -106,6 +106,95 @@ __device__ __forceinline__ double box_bound(b9_ctab box, const double (&so)[NFP]
         lb = fma(m, m, lb);
     }
     return lb;
+}
+
+// The same bound in PACKED fp32 (the BOX32 instances: B9_BOX32): two filters per v_pk_fma_f32 (box words as the SGPR-pair
+// operand), v_max3_f32 for the clamp -- 5 instructions per filter PAIR where the fp64 form takes 5 per filter (62 box tests
+// per workgroup at 50k stars x 8 walkers are 27 % of the star role's VALU instructions).  The bound stays rigorous:
+//   * the table holds the box a second time as floats rounded OUTWARD (box_store: a looser box, still a box);
+//   * the star's fp32 pair (swf, sof) carries a relative error 2^-24 each, the fma rounds once: the computed distance is
+//     within d_f = 2^-22 |so_f| (+ 2^-22 relative) of the true one, so  lb32 <= (1 + eta) lb + (1 + 1 / eta) sum_f d_f^2  for
+//     any eta > 0 (2 m d <= eta m^2 + d^2 / eta) -- with eta = 2^-11 and the roundings of the fp32 sum:
+//     B9_BOX_INV lb32 <= lb + slack,  B9_BOX_INV = 1 - 2^-10,  slack = 2100 x 2^-44 sum_f so_f^2  (0.006 for eight magnitudes of
+//     25 at sigma 0.01);
+//   * a box is skipped only when  B9_BOX_INV lb32 + nbmin > xcut + slack,  which implies lb + nbmin > xcut: no term within the
+//     cut is lost.  What it costs is boxes that pass at 40.04 e-folds instead of 40.
+// The star's fp32 words and its slack live in LDS (`sf`, `s_slack`: the four waves of a workgroup hold the SAME 64 stars),
+// read where a box is tested: 16 more live VGPRs cost the row loop its occupancy.
+typedef float b9_f2 __attribute__((ext_vector_type(2)));
+typedef float b9_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) unsigned long long *b9_cbox;     // {lo pairs[NFP / 2], hi pairs[NFP / 2]}
+#define B9_BOX_INV 0.9990234375f
+template <int NFP>
+__device__ __forceinline__ double box_bound32(b9_cbox box, const b9_f4 *sf, int lane)
+{
+    // the lane's words {sw, sw', so, so'} of a filter pair: one ds_read_b128; up to four pairs requested TOGETHER (left to the
+    // compiler the reads share one register quad: a box is four dependent LDS round trips -- two populations 163 -> 175 us)
+    constexpr int NB = 2;
+    const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) b9_f4 *)sf + (unsigned)lane * 16u;
+    b9_f2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int p0 = 0; p0 < NFP / 2; p0 += NB) {
+        b9_f4 s4[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) asm volatile("ds_read_b128 %0, %1" : "=v"(s4[k]) : "v"(a0 + (unsigned)(p0 + k) * 1024u));
+        if constexpr (NB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s4[0]), "+v"(s4[1]), "+v"(s4[2]), "+v"(s4[3]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s4[0]), "+v"(s4[1]));
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int p = p0 + k;
+            const b9_f2 swp = {s4[k].x, s4[k].y}, sop = {s4[k].z, s4[k].w};
+            b9_f2 a, b, m;
+            asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(a) : "v"(swp), "s"(box[p]), "v"(sop));             // sw lo - so
+            asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(b) : "v"(swp), "s"(box[NFP / 2 + p]), "v"(sop));   // so - sw hi
+            asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m.x) : "v"(a.x), "v"(b.x));
+            asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m.y) : "v"(a.y), "v"(b.y));
+            acc = __builtin_elementwise_fma(m, m, acc);
+        }
+    }
+    return (double)((acc.x + acc.y) * B9_BOX_INV);
+}
+// the star's side of the box test: lane `lane`'s fp32 words into sf[NFP / 2][64]; returns its slack (kept in LDS too: the
+// row loop has no registers to spare -- two more live doubles doubled the fused step's scratch traffic, C2 127 -> 136 us)
+template <int NFP>
+__device__ __forceinline__ double box_stage(b9_f4 *sf, int lane, bool write, const double (&so)[NFP], const double (&sw)[NFP])
+{
+    double s2 = 0.0;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) s2 = fma(so[f], so[f], s2);
+    if (write) {
+#pragma unroll
+        for (int p = 0; p < NFP / 2; ++p) sf[p * 64 + lane] = b9_f4{(float)sw[2 * p], (float)sw[2 * p + 1], (float)so[2 * p], (float)so[2 * p + 1]};
+    }
+    return s2 < 1e30 ? s2 * (2100.0 / 17592186044416.0) : __builtin_inf();         // (2^44; beyond fp32's range of squares: every box passes)
+}
+// does any lane need the box?  (box: the table's boxes -- box2 / box1, or box2f / box1f for BOX32; k: which; nbm: the smallest nb of its rows;
+// xcut: a term counts while X < xcut)
+template <int NFP, bool BOX32>
+__device__ __forceinline__ bool box_pass(b9_ctab boxes, size_t k, double nbm, double xcut, const double (&so)[NFP], const double (&sw)[NFP],
+                                         const b9_f4 *sf, const double *s_slack, int lane)
+{
+    if constexpr (BOX32) {
+        const double lb = box_bound32<NFP>((b9_cbox)boxes + k * NFP, sf, lane);
+        asm volatile("" : "+v"(lane));          // (the slack is read HERE, not hoisted over the row loop)
+        return __ballot(lb + nbm <= xcut + s_slack[lane]) != 0ull;
+    } else {
+        return __ballot(box_bound64<NFP>(boxes + k * 2 * NFP, so, sw) + nbm < xcut) != 0ull;
+    }
+}
+// a box into the table (the builders): floats, rounded outward
+// (outward: the bound is moved by 2^-22 of itself + 1e-30 before the conversion rounds it by at most 2^-24 -- two instructions;
+// the box grows by 6e-6 mag at magnitude 25)
+__device__ __forceinline__ float f32_below(double x) { return (float)(fma(-__builtin_fabs(x), 0x1p-22, x) - 1e-30); }
+__device__ __forceinline__ float f32_above(double x) { return (float)(fma(__builtin_fabs(x), 0x1p-22, x) + 1e-30); }
+// (the fp64 box is always written, the float copy for the instances that test in fp32.  Measured: leaving the fp64 stores out
+// of those instances' builders moves the fused step's register allocation -- C2 121 -> 125 us -- for four stores saved)
+template <int NFP>
+__device__ __forceinline__ void box_store(bool box32, double *box, double *box_f, int f, double lo, double hi)      // (an empty box -- lo > hi: no finite row -- is stored as [0, 0])
+{
+    const bool any = lo <= hi;
+    box[f] = any ? lo : 0.0; box[NFP + f] = any ? hi : 0.0;
+    if (box32) { float *b = reinterpret_cast<float *>(box_f); b[f] = any ? f32_below(lo) : 0.0f; b[NFP + f] = any ? f32_above(hi) : 0.0f; }
 }
 
 // X = nb + chi^2 of one table row (wave-uniform row, per-lane star)
@@ -252,11 +341,17 @@ struct MargSelPlain {
 // B9_TILE_OCC waves per SIMD with B9_TILE_UNROLL rows in flight (sweep: 8 filters occupancy 4 / 5 / 6 / 7: 146 / 137 / 134 /
 // 138 us; two populations 186 / 175 / 184 / 192; 16 filters at 6: 418, the rows spill).
 #define B9_TILE_DOUBLES(NFP) (16 * (NFP) + 16)
+// which instances test their boxes in packed fp32 (box_bound32)
+#define B9_BOX32(NFP, NPOPS) ((NPOPS) == 1)
 // TILE = 2, the SPARSE setting (launches that leave the chip nearly empty: one chain on a split catalogue): four rows in flight
 // at occupancy 4 -- 20k stars, one chain, 8 x 8 grid: 62.0 -> 55.9 us per step; with 8 walkers on the same catalogue it
 // loses (91 -> 99.7), so the launch picks by its own size (b9_kernels.hip: marg_sparse).
-#define B9_TILE_OCC(NFP, NPOPS, TILE) (((NFP) >= 16 || (TILE) == 2) ? 4 : ((NPOPS) == 2 ? 5 : 6))
-#define B9_TILE_UNROLL(NFP, NPOPS, TILE) (((NFP) >= 16 || (NPOPS) == 2 || (TILE) == 2) ? 4 : 2)
+#ifndef B9_TILE_OCC_DENSE            // (tools/build_variant.py -DB9_TILE_OCC_DENSE=7 -DB9_TILE_UNROLL_DENSE=1: the sweep's variants)
+#define B9_TILE_OCC_DENSE 6
+#define B9_TILE_UNROLL_DENSE 2
+#endif
+#define B9_TILE_OCC(NFP, NPOPS, TILE) (((NFP) >= 16 || (TILE) == 2) ? 4 : ((NPOPS) == 2 ? 5 : B9_TILE_OCC_DENSE))
+#define B9_TILE_UNROLL(NFP, NPOPS, TILE) (((NFP) >= 16 || (NPOPS) == 2 || (TILE) == 2) ? 4 : B9_TILE_UNROLL_DENSE)
 template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, bool COST, int TILE, class Select>
 __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars &st, int block_id, double *tile_lds,
                  const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
@@ -266,6 +361,9 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
 {
     __shared__ double s_tmax[NPOPS][4][64], s_ref[NPOPS][4][64], s_sm[NPOPS][4][64];
     __shared__ unsigned long long s_mask[NPOPS][B9_MARG_MASK_WORDS];
+    constexpr bool BOX32 = B9_BOX32(NFP, NPOPS);
+    __shared__ b9_f4 s_sf[BOX32 ? (NFP / 2) * 64 : 1];                   // the 64 stars in fp32 for the box tests (box_bound32)
+    __shared__ double s_slack[BOX32 ? 64 : 1];
     __shared__ double s_bkey[SAMPLE ? 4 : 1][64], s_bmass[SAMPLE ? 4 : 1][64], s_bratio[SAMPLE ? 4 : 1][64];
     __shared__ int s_bpop[SAMPLE ? 4 : 1][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -290,7 +388,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     if (SPLIT ? pos >= st.mg_n_pieces : pos * 64 >= st.mg_pad) return;
     const int piece = SPLIT ? st.mg_piece[pos] : 0;
     const int split = SPLIT ? (piece >> 20) & 31 : 0, n_split = SPLIT ? (piece >> 25) & 63 : 1;      // (at most 32 pieces)
-    HSTAMP(0);
+    SSTAMP(block_id, 0);
     select.issue(w);
     const int sc = SPLIT ? piece & 0xFFFFF : st.marg_order[pos];
     const int slot = sc * 64 + lane;                                // (slot of the marginalised mode's own copy: DevStars::mg_*)
@@ -300,8 +398,9 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
 #pragma unroll
     for (int f = 0; f < NFP; ++f) { so[f] = st.mg_so[B9_SIDX(NFP, f, slot)]; sw[f] = st.mg_sw[B9_SIDX(NFP, f, slot)]; }
     const double c0m = st.mg_c0m[slot], la = st.mg_la[slot];
+    if constexpr (BOX32) { const double sl = box_stage<NFP>(s_sf, lane, wave == 0, so, sw); if (wave == 0) s_slack[lane] = sl; }      // (visible behind the barrier that closes the seed pass)
     const MargSel sel = select.finish(w);
-    HSTAMP(1);
+    SSTAMP(block_id, 1);
     const IsoHdr *__restrict__ const hdr = sel.hdr;
     const double *__restrict__ const tab = sel.tab;
     const double *par = sel.params + (size_t)w * B9_NPARAM;
@@ -348,14 +447,14 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
         const double xcut = fma(-2.0, tmax[kp], cut2);
         const int c_end = n_chunks < 64 * B9_MARG_MASK_WORDS ? n_chunks : 64 * B9_MARG_MASK_WORDS;
         for (int c = split + n_split * wave; c < c_end; c += 4 * n_split) {          // (this workgroup's node chunks, dealt over its waves)
-            const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, so, sw);
             MSTAT(0, 1);
-            if (__ballot(lb1 + t_wp[L.o_nbmin64 + c] < xcut) != 0ull && lane == 0) atomicOr(&s_mask[kp][c >> 6], 1ull << (c & 63));
+            if (box_pass<NFP, BOX32>(t_wp + (BOX32 ? L.o_box1f : L.o_box1), (size_t)c, t_wp[L.o_nbmin64 + c], xcut, so, sw, s_sf, s_slack, lane) && lane == 0)
+                atomicOr(&s_mask[kp][c >> 6], 1ull << (c & 63));
         }
     }
     __syncthreads();
 
-    HSTAMP(2);
+    SSTAMP(block_id, 2);
     Best best; best.key = NEG_INF; best.mass = 0.0; best.ratio = 0.0; best.pop = 0;
     const unsigned long long g_row = SAMPLE ? (unsigned long long)(ms.row0 + w) : 0ull;
     unsigned n_cost = 0;                                 // COST: (16 nodes x one mass ratio) units this wave evaluates
@@ -367,7 +466,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
         const double *__restrict__ const t_g = tab + (size_t)(w * NPOPS + kp) * L.total;      // (generic: the asynchronous row loads take addresses)
         const b9_ctab t_wp = (b9_ctab)t_g;
         const double *__restrict__ const t_rows = t_g + L.o_rows, *__restrict__ const t_nb = t_g + L.o_nb;
-        const b9_ctab t_box2 = t_wp + L.o_box2, t_nbmin16 = t_wp + L.o_nbmin16;
+        const b9_ctab t_box2 = t_wp + (BOX32 ? L.o_box2f : L.o_box2), t_nbmin16 = t_wp + L.o_nbmin16;
         const int n_chunks = ((iso_g[kp].n - 1) * K + 63) >> 6;
         // one chunk that passed level 1: this wave's sub-chunk, mass ratio by mass ratio
         auto chunk = [&](int c) {
@@ -384,9 +483,13 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
             const double *__restrict__ const nbp = t_nb + u * 16;
             for (int j = (wave - 2 * sub) & 3; j < Q; j += 4) {
                 // level 2: this wave's 16 nodes x one mass ratio
-                const double lb2 = box_bound<NFP>(t_box2 + ((size_t)u * Q + j) * 2 * NFP, so, sw);
                 MSTAT(2, 1);
-                if (__ballot(lb2 + nbm < xcut) == 0ull) continue;
+                if constexpr (BOX32) {
+                    if (!box_pass<NFP, true>(t_box2, (size_t)u * Q + j, nbm, xcut, so, sw, s_sf, s_slack, lane)) continue;
+                } else {
+                    const double lb2 = box_bound64<NFP>(t_box2 + ((size_t)u * Q + j) * 2 * NFP, so, sw);
+                    if (__ballot(lb2 + nbm < xcut) == 0ull) continue;
+                }
                 MSTAT(3, 1);
                 MLIFE_UNIT();
                 if (COST) ++n_cost;
@@ -463,16 +566,15 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
             while (m) { const int c = wi * 64 + __builtin_ctzll(m); m &= m - 1; chunk(c); }
         }
         for (int c = 64 * B9_MARG_MASK_WORDS + split; c < n_chunks; c += n_split) {      // (tables longer than the mask: every wave tests)
-            const double lb1 = box_bound<NFP>(t_wp + L.o_box1 + (size_t)c * 2 * NFP, so, sw);
-            if (__ballot(lb1 + t_wp[L.o_nbmin64 + c] < fma(-2.0, tmax[kp], cut2)) != 0ull) chunk(c);
+            if (box_pass<NFP, BOX32>(t_wp + (BOX32 ? L.o_box1f : L.o_box1), (size_t)c, t_wp[L.o_nbmin64 + c], fma(-2.0, tmax[kp], cut2), so, sw, s_sf, s_slack, lane)) chunk(c);
         }
         s_ref[kp][wave][lane] = ref[kp]; s_sm[kp][wave][lane] = sm[kp];
     }
     if (SAMPLE) { s_bkey[wave][lane] = best.key; s_bmass[wave][lane] = best.mass; s_bratio[wave][lane] = best.ratio; s_bpop[wave][lane] = best.pop; }
     if (COST && lane == 0) ms.cost[(size_t)sc * 4 + wave] = n_cost;
-    HSTAMP(3);
+    SSTAMP(block_id, 3);
     __syncthreads();
-    HSTAMP(4);
+    SSTAMP(block_id, 4);
     if (wave != 0) return;
     // ---- wave 0: merge the four shares, finish the star, sum the chunk
     double ll[NPOPS];
@@ -484,7 +586,7 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
         double S = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) S += (s_sm[kp][k][lane] > 0.0) ? s_sm[kp][k][lane] * exp_fast(s_ref[kp][k][lane] - r) : 0.0;
-        HSTAMP(5);
+        SSTAMP(block_id, 5);
         if (SPLIT) {                                    // this workgroup's share of the star's sum: merged by k_marg_merge
             double *sh = shares + ((((size_t)w * st.mg_n_pieces + st.mg_share_base[sc] + split) * NPOPS + kp) * 128);
             sh[lane] = r; sh[64 + lane] = S;
@@ -598,6 +700,7 @@ __global__ __launch_bounds__(256) void k_marg_table(DevPack pk, const IsoHdr *__
 {
     extern __shared__ __attribute__((aligned(16))) double s_mass[];
     const int wp = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, jl = tid >> 6;
+    const bool box32 = B9_BOX32(NFP, n_pops);               // (the box format the star kernel's instance reads)
     const IsoHdr h = hdr[wp];
     if (!h.valid) return;
     const int n_nodes = (h.n - 1) * K;
@@ -658,10 +761,7 @@ __global__ __launch_bounds__(256) void k_marg_table(DevPack pk, const IsoHdr *__
             double lo = ok ? C[f] : __builtin_inf(), hi = ok ? C[f] : NEG_INF;
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { lo = __builtin_fmin(lo, __shfl_xor(lo, o, 64)); hi = __builtin_fmax(hi, __shfl_xor(hi, o, 64)); }
-            if (i16 == 0) {
-                double *b2 = out + L.o_box2 + ((size_t)u * Q + j) * 2 * NFP;
-                b2[f] = lo <= hi ? lo : 0.0; b2[NFP + f] = lo <= hi ? hi : 0.0;
-            }
+            if (i16 == 0) box_store<NFP>(box32, out + L.o_box2 + ((size_t)u * Q + j) * 2 * NFP, out + L.o_box2f + ((size_t)u * Q + j) * NFP, f, lo, hi);
             lo64[f] = __builtin_fmin(lo64[f], lo); hi64[f] = __builtin_fmax(hi64[f], hi);
         }
     }
@@ -686,8 +786,7 @@ __global__ __launch_bounds__(256) void k_marg_table(DevPack pk, const IsoHdr *__
     if (tid < NFP) {
         double lo = s_box[tid], hi = s_box[NFP + tid];
         for (int k = 1; k < 4; ++k) { lo = __builtin_fmin(lo, s_box[(k * 2) * NFP + tid]); hi = __builtin_fmax(hi, s_box[(k * 2 + 1) * NFP + tid]); }
-        double *b1 = out + L.o_box1 + (size_t)c * 2 * NFP;
-        b1[tid] = lo <= hi ? lo : 0.0; b1[NFP + tid] = lo <= hi ? hi : 0.0;
+        box_store<NFP>(box32, out + L.o_box1 + (size_t)c * 2 * NFP, out + L.o_box1f + (size_t)c * NFP, tid, lo, hi);
     }
 }
 

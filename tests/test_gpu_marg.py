@@ -104,6 +104,12 @@ def test_pruning_is_rigorous(n_pops, wd_frac, K, Q):
                                                        n_pops=n_pops, small=False, seed=77)
     cl["clust_prior"][:200] = 1.0
     cl["clust_prior"][200:260] = 1e-200
+    # photometry 50 x sharper than the grid resolves (scaled observations of ~1e5: the packed-fp32 box test of the one-population
+    # instances runs on its rounding slack there), with and without a field floor
+    sg = np.asarray(cl["sigma"]).reshape(len(cl["clust_prior"]), -1)
+    sg[260:420] = np.where(sg[260:420] > 0, sg[260:420] * 0.02, sg[260:420])
+    cl["sigma"] = sg.reshape(np.asarray(cl["sigma"]).shape)
+    cl["clust_prior"][260:330] = 1.0
     stars = abi.make_stars(cl)
     opt = abi.make_options(abi.MODE_MARGINALISED, n_pops, K, Q)
     eng = engine.Engine(pack, stars, priors, opt)

@@ -65,10 +65,16 @@ if eng.lib.b9_debug_read_gantt_heavy(hb.ctypes.data) == 0:
         if r[5] <= 0 or r[0] <= 0:
             continue
         print(f"   wg {k:2d}: row {(r[1]-r[0])/100:5.2f} | header {(r[2]-r[1])/100:5.2f} | tiles {(r[3]-r[2])/100:5.2f} | rows {(r[4]-r[3])/100:5.2f} | nb+box1 {(r[5]-r[4])/100:5.2f} | total {(r[5]-r[0])/100:5.2f}")
-    first_star = min((k for k in range(64) if h[k][0] > 0 and h[k][5] > 0 and h[k][1] > h[k][0] and (h[k][2] - h[k][1]) < (h[k][3] - h[k][2]) * 50), default=None)
-    print("star workgroups among the first 64 ids (the launch's most expensive pieces), wave 0, us: entry -> decision | headers + level 1 + barrier | walk | wait for the other waves | merge")
-    for k in range(64):
-        r = h[k]
-        if r[0] <= 0 or r[4] <= 0 or r[3] < r[2] or (t[order[-2]][k][2] & 0xFF) != 0:
-            continue
-        print(f"   wg {k:2d}: decision {(r[1]-r[0])/100:5.2f} | level 1 {(r[2]-r[1])/100:5.2f} | walk {(r[3]-r[2])/100:5.2f} | barrier {(r[4]-r[3])/100:5.2f} | merge {(r[5]-r[4])/100:5.2f} | total {(r[5]-r[0])/100:5.2f}")
+sb = np.zeros((64, 4, 8), dtype=np.uint64)
+if hasattr(eng.lib, "b9_debug_read_gantt_star"):
+    eng.lib.b9_debug_read_gantt_star.argtypes = [C.c_void_p]
+    if eng.lib.b9_debug_read_gantt_star(sb.ctypes.data) == 0:
+        h = sb.astype(np.int64)
+        print("star workgroups, dispatch positions 0-63 (the launch's most expensive pieces), last launch, us: entry -> decision | headers + level 1 + barrier | "
+              "walk of waves 0-3 | wave 0's wait for the others | merge")
+        for k in range(64):
+            r = h[k][0]
+            if r[0] <= 0 or r[4] <= 0 or r[3] < r[2]:
+                continue
+            walks = " ".join(f"{(h[k][v][3]-h[k][v][2])/100:5.2f}" for v in range(4))
+            print(f"   wg {k:2d}: decision {(r[1]-r[0])/100:5.2f} | level 1 {(r[2]-r[1])/100:5.2f} | walk {walks} | barrier {(r[4]-r[3])/100:5.2f} | merge {(r[5]-r[4])/100:5.2f} | total {(r[5]-r[0])/100:5.2f}")
