@@ -301,8 +301,9 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
 // Waves per SIMD the instances are built for (tools/kernel_resources.py)
 #define B9_MARG_WAVES(NFP, NPOPS, SAMPLE) (((NFP) >= 16 || (SAMPLE)) ? 4 : ((NPOPS) == 2 ? 6 : 7))
 
-// A workgroup = FOUR waves holding the SAME 64 stars; wave k takes sub-chunk k of every 64-node chunk (a quarter of every
-// star's window, wherever it lies) and the four partial log-sum-exps are merged through LDS at the end.  (With one wave
+// A workgroup = FOUR waves holding the SAME 64 stars; a chunk's units (sub-chunk of 16 nodes x one mass ratio) are dealt over
+// them diagonally -- unit (sub, j) is wave (2 sub + j) mod 4's: a quarter of every star's window, wherever it lies -- and the
+// four partial log-sum-exps are merged through LDS at the end.  (With one wave
 // per 64 stars the launch lasted as long as its heaviest wave -- a chunk of giants whose windows barely overlap walks
 // 2000 terms against an average of 240; the mean wave lived a quarter of the launch.)  A wave prunes against the maxima
 // the four waves' seed passes merged BEHIND A BARRIER and, from there on, its OWN running maximum only: which terms enter a

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""ISA check of the ASYNCHRONOUS scalar row loads of the marginalised kernels (SRow, b9_star_marg.hip.h).
+"""ISA check of the ASYNCHRONOUS loads of the marginalised kernels: the scalar row loads (SRow, b9_star_marg.hip.h) and the
+packed-fp32 box test's LDS reads (box_bound32: ds_read_b128 from inline assembly, one wait for the batch -- the same hazard with
+VGPR destinations).
 
 SRow::load issues s_load_dwordx8 / x16 / x2 from inline assembly and defers the s_waitcnt to SRow::wait.  To the compiler
 the destination SGPRs are defined at the load's ISSUE; nothing tells its register allocator or its waitcnt insertion that
@@ -33,14 +35,19 @@ def device_asm(force=False):
     return ASM
 
 
-def sgprs(operand):
-    """SGPR numbers an operand names: s12, s[12:27]."""
+def sgprs(operand, bank="s"):
+    """Register numbers of one bank ("s" / "v") an operand names: s12, s[12:27]."""
     out = set()
-    for m in re.finditer(r"\bs\[(\d+):(\d+)\]", operand):
+    for m in re.finditer(r"\b%s\[(\d+):(\d+)\]" % bank, operand):
         out.update(range(int(m.group(1)), int(m.group(2)) + 1))
-    for m in re.finditer(r"\bs(\d+)\b", operand):
+    for m in re.finditer(r"\b%s(\d+)\b" % bank, operand):
         out.add(int(m.group(1)))
     return out
+
+
+def regs(operand):
+    """Registers an operand names, as ("s", n) / ("v", n)."""
+    return {("s", n) for n in sgprs(operand, "s")} | {("v", n) for n in sgprs(operand, "v")}
 
 
 def parse_kernels(path):
@@ -122,18 +129,22 @@ def check_kernel(instrs):
                 if "lgkmcnt(0)" in t:
                     infl = {}
                 continue
-            if a and op.startswith("s_load_dword"):
+            if a and (op.startswith("s_load_dword") or op.startswith("ds_read")):
                 if ln not in counted:
                     counted.add(ln)
                     n_loads += 1
-                for r in sgprs(t.split(",")[0]):
+                if op.startswith("ds_read"):          # (its address register is read at issue: only a destination may not be named)
+                    hit = sorted(regs(t[len(op):]) & set(infl))
+                    if hit:
+                        findings[ln] = (ln, t, [b_ + str(n) for b_, n in hit], infl[hit[0]])
+                for r in regs(t.split(",")[0]):
                     infl[r] = ln
                 continue
             if not infl or op in ("s_endpgm", "s_branch", "s_barrier", "s_nop") or op.startswith("s_cbranch") or op.startswith("s_sleep"):
                 continue
-            hit = sorted(sgprs(t[len(op):]) & set(infl))
+            hit = sorted(regs(t[len(op):]) & set(infl))
             if hit:
-                findings[ln] = (ln, t, hit, infl[hit[0]])
+                findings[ln] = (ln, t, [b_ + str(n) for b_, n in hit], infl[hit[0]])
         for j in succ[i]:
             merged = dict(state_in[j])
             merged.update({r: l for r, l in infl.items() if r not in merged})
@@ -155,9 +166,9 @@ def check(path):
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else device_asm()
     findings, n_loads, n_kernels = check(path)
-    print(f"{n_kernels} marginalised kernel instances, {n_loads} asynchronous scalar loads followed to their waits: {len(findings)} finding(s)")
+    print(f"{n_kernels} marginalised kernel instances, {n_loads} asynchronous loads (scalar rows, LDS box words) followed to their waits: {len(findings)} finding(s)")
     for fn, ln, text, regs, at in findings[:40]:
-        print(f"  {fn[:60]} line {ln}: `{text[:90]}` names s{regs} while the load of line {at} is in flight")
+        print(f"  {fn[:60]} line {ln}: `{text[:90]}` names {regs} while the load of line {at} is in flight")
     return 1 if findings else 0
 
 
