@@ -42,7 +42,7 @@ extern "C" int b9_debug_clear_stamps(void)
 #endif
 
 #ifdef B9_GANTT      // diagnostic build only: per-workgroup start / end times (s_memrealtime, 100 MHz) of 8 consecutive launches
-#define B9_GANTT_WG 4096
+#define B9_GANTT_WG 8192
 __device__ unsigned long long g_gantt[8 * B9_GANTT_WG * 4];
 __device__ unsigned long long g_gantt_heavy[64 * 8];          // phase stamps of the heavy role (one slot per workgroup id < 64)
 extern "C" int b9_debug_read_gantt(unsigned long long *out)

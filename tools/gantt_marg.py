@@ -28,7 +28,7 @@ chol = np.diag([mcmc.DEFAULT_STEP[int(k)] for k in free]) * 0.3
 ids = np.arange(W, dtype=np.int32)
 for _ in range(3):
     eng.mcmc_run_block(start, lp, ids, free, chol, 7, 0, 200, record=False)
-NWG = 4096
+NWG = 8192
 buf = np.zeros((8, NWG, 4), dtype=np.uint64)
 eng.lib.b9_debug_read_gantt.argtypes = [C.c_void_p]
 assert eng.lib.b9_debug_read_gantt(buf.ctypes.data) == 0
@@ -47,6 +47,10 @@ for s in steps[1:-1]:
         line += f"  gap after the previous launch's last end {(t0 - prev_end) / 100:.2f}"
     print(line)
     prev_end = b.max()
+    # workgroups in flight over the launch (tenths of its span)
+    edges = np.linspace(t0, b.max(), 11)
+    busy = [float(np.clip(np.minimum(b, edges[k + 1]) - np.maximum(a, edges[k]), 0, None).sum() / (edges[k + 1] - edges[k])) for k in range(10)]
+    print("   workgroups in flight, by tenth of the span: " + " ".join(f"{x:5.0f}" for x in busy) + f"   (mean {np.sum(b - a) / (b.max() - t0):.0f})")
     for r in (4, 2, 5, 0, 1):
         m = role == r
         if not m.any():
