@@ -26,11 +26,11 @@ echo "config sweep done"
   python3 tools/time_marg.py 20000 4 4 8 --wd 0.05; python3 tools/time_marg.py 20000 4 4 1; python3 tools/time_marg.py 10000 4 4 1; python3 tools/time_marg.py 10000 8 8 1; python3 tools/time_marg.py 200 4 4 1 --filters 4
   python3 tools/time_marg.py 50000 4 4 8 --sample; python3 tools/time_marg.py 30000 4 4 8 --pops 2 --sample; python3 tools/time_marg.py 50000 4 4 8 --filters 16 --sample
 } > $O/${TAG}_marg_instances.txt 2>&1 || echo "(marg instances failed)"
-{ python3 tools/time_step.py C0 C1 C2 C3 C4 F16 F16P2 F4; python3 tools/time_step.py C0 C1 C2 C3 C4 --marg 4 4; python3 tools/time_step.py C1 C3 --marg 8 8;
+{ python3 tools/time_step.py C0 C1 C2 C3 C4 F16 F16P2 F4; python3 tools/time_step.py C0 C1 C2 C3 C4 F16 F16P2 F4 --marg 4 4; python3 tools/time_step.py C1 C3 --marg 8 8;
   echo "# the two-launch marginalised step (b9_tuning.two_launch_steps), for comparison"; B9_TWO_LAUNCH_STEPS=1 python3 tools/time_step.py C1 C2 C3 --marg 4 4; } > $O/${TAG}_time_step.txt 2>&1 || echo "(time_step failed)"
 { python3 tools/time_logpost.py; python3 tools/time_logpost.py --marg 4 4; } > $O/${TAG}_time_logpost.txt 2>&1 || echo "(time_logpost failed)"
 { for s in C1 C2 C3 C4; do python3 tools/soak_determinism.py 50 $s --marg 4 4; done; python3 tools/soak_determinism.py 100 C2; python3 tools/soak_determinism.py 100 C3; } > $O/${TAG}_soak.txt 2>&1 || echo "(soak failed)"
 if [ -f build/variants/lib_gantt.so ]; then
-  { for s in C1 C2 C3; do B9_HIP_LIB=build/variants/lib_gantt.so python3 tools/gantt_marg.py $s | head -8; B9_HIP_LIB=build/variants/lib_gantt.so python3 tools/gantt_marg.py $s | grep -A4 "table builders"; done; } > $O/${TAG}_gantt_marg.txt 2>&1 || echo "(gantt failed)"
+  { for s in C1 C2 C3 C4; do B9_HIP_LIB=build/variants/lib_gantt.so python3 tools/gantt_marg.py $s > $O/gantt_tmp.txt; head -6 $O/gantt_tmp.txt; grep -A4 "table builders" $O/gantt_tmp.txt; grep -A8 "star workgroups, dispatch" $O/gantt_tmp.txt; done; rm -f $O/gantt_tmp.txt; } > $O/${TAG}_gantt_marg.txt 2>&1 || echo "(gantt failed)"
 fi
 echo "all done"
