@@ -130,7 +130,10 @@ __device__ __forceinline__ double box_bound32(b9_cbox box, const b9_f4 *sf, int 
 {
     // the lane's words {sw, sw', so, so'} of a filter pair: one ds_read_b128; up to four pairs requested TOGETHER (left to the
     // compiler the reads share one register quad: a box is four dependent LDS round trips -- two populations 163 -> 175 us)
-    constexpr int NB = 2;
+#ifndef B9_BOX_NB
+#define B9_BOX_NB 2
+#endif
+    constexpr int NB = B9_BOX_NB;
     const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) b9_f4 *)sf + (unsigned)lane * 16u;
     b9_f2 acc = {0.0f, 0.0f};
 #pragma unroll
@@ -343,7 +346,10 @@ struct MargSelPlain {
 // 138 us; two populations 186 / 175 / 184 / 192; 16 filters at 6: 418, the rows spill).
 #define B9_TILE_DOUBLES(NFP) (16 * (NFP) + 16)
 // which instances test their boxes in packed fp32 (box_bound32)
-#define B9_BOX32(NFP, NPOPS) ((NPOPS) == 1)
+#ifndef B9_BOX32_P2
+#define B9_BOX32_P2 0
+#endif
+#define B9_BOX32(NFP, NPOPS) ((NPOPS) == 1 || B9_BOX32_P2)
 // TILE = 2, the SPARSE setting (launches that leave the chip nearly empty: one chain on a split catalogue): four rows in flight
 // at occupancy 4 -- 20k stars, one chain, 8 x 8 grid: 62.0 -> 55.9 us per step; with 8 walkers on the same catalogue it
 // loses (91 -> 99.7), so the launch picks by its own size (b9_kernels.hip: marg_sparse).
@@ -351,8 +357,12 @@ struct MargSelPlain {
 #define B9_TILE_OCC_DENSE 6
 #define B9_TILE_UNROLL_DENSE 2
 #endif
-#define B9_TILE_OCC(NFP, NPOPS, TILE) (((NFP) >= 16 || (TILE) == 2) ? 4 : ((NPOPS) == 2 ? 5 : B9_TILE_OCC_DENSE))
-#define B9_TILE_UNROLL(NFP, NPOPS, TILE) (((NFP) >= 16 || (NPOPS) == 2 || (TILE) == 2) ? 4 : B9_TILE_UNROLL_DENSE)
+#ifndef B9_TILE_OCC_P2
+#define B9_TILE_OCC_P2 5
+#define B9_TILE_UNROLL_P2 4
+#endif
+#define B9_TILE_OCC(NFP, NPOPS, TILE) (((NFP) >= 16 || (TILE) == 2) ? 4 : ((NPOPS) == 2 ? B9_TILE_OCC_P2 : B9_TILE_OCC_DENSE))
+#define B9_TILE_UNROLL(NFP, NPOPS, TILE) (((NFP) >= 16 || (TILE) == 2) ? 4 : ((NPOPS) == 2 ? B9_TILE_UNROLL_P2 : B9_TILE_UNROLL_DENSE))
 template <int NFP, int NPOPS, bool SAMPLE, bool SPLIT, bool COST, int TILE, class Select>
 __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars &st, int block_id, double *tile_lds,
                  const double *__restrict__ iso_data, long long iso_stride, int mass_cap,
