@@ -152,6 +152,9 @@ int ensure_marg_plan(b9_ctx *ctx)
             fprintf(stderr, "[marg plan] %d chunks, cost min %.0f p50 %.0f p90 %.0f max %.0f total %.0f; P %.2f; %d pieces (max per chunk %d)\n", n_mc, cs.front(), cs[cs.size() / 2],
                     cs[cs.size() * 9 / 10], cs.back(), total, P, (int)pieces.size(), *std::max_element(n_piece.begin(), n_piece.end()));
         }
+        if (ctx->plan_debug > 1)
+            for (size_t k = 0; k < pieces.size(); ++k)
+                fprintf(stderr, "[marg plan] position %zu: chunk %d piece %d of %d, chunk cost %.0f\n", k, pieces[k] & 0xFFFFF, (pieces[k] >> 20) & 31, (pieces[k] >> 25) & 63, cost[pieces[k] & 0xFFFFF]);
         if ((rc = upload_ints(ctx, pieces, &ctx->st.mg_piece))) return rc;
         if ((rc = upload_ints(ctx, base, &ctx->st.mg_share_base))) return rc;
     }

@@ -110,7 +110,7 @@ void apply_tuning(b9_ctx *ctx, const b9_tuning &t)
     ctx->two_launch_steps = t.two_launch_steps != 0;
     ctx->marg_prune = t.marg_no_pruning == 0;
     ctx->timing_group = t.timing_group > 0 ? t.timing_group : 8;
-    ctx->plan_debug = t.plan_debug != 0;
+    ctx->plan_debug = t.plan_debug;
     ctx->tree_depth = std::max(0, std::min(B9_TREE_MAX_DEPTH, t.tree_depth));
     if (ctx->marg_piece_units != std::max(0, t.marg_piece_units)) ctx->marg_plan_ok = false;
     ctx->marg_piece_units = std::max(0, t.marg_piece_units);

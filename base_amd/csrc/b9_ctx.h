@@ -101,7 +101,7 @@ struct b9_ctx {
     int derive_order = 1;      // fused sampler step: 1 writers + derivation lead the grid and the heavy-star workgroups follow them (default),
                                // 0 heavy-star workgroups first, < 0 derivation workgroups trail the hot ones (B9_DERIVE_ORDER)
     bool two_launch_steps = false;   // b9_tuning.two_launch_steps: the derive + star launch pair per step also in given-mass mode
-    bool plan_debug = false;         // b9_tuning.plan_debug: print the fused step's launch plan to stderr when it changes
+    int plan_debug = 0;              // b9_tuning.plan_debug: print the fused step's launch plan to stderr when it changes (2: the marginalised catalogue's pieces too)
     bool marg_prune = true;          // marginalised kernel: field floor + box pruning (b9_tuning.marg_no_pruning turns both off)
     int heavy_parts_fixed = 0;       // b9_tuning.heavy_parts: 0 = sized from the catalogue (check_ready)
     int tree_depth = 0;              // b9_tuning.tree_depth: 0 = automatic

@@ -73,7 +73,10 @@ extern "C" int b9_debug_read_gantt_star(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gantt_star), sizeof(unsigned long long) * 64 * 4 * 8);
 }
-#define SSTAMP(id, k) do { if ((threadIdx.x & 63) == 0 && (id) < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_star[((id) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#ifndef B9_SSTAMP_BASE          // (-DB9_SSTAMP_BASE=n: the window of 64 dispatch positions that is recorded)
+#define B9_SSTAMP_BASE 0
+#endif
+#define SSTAMP(id, k) do { if ((threadIdx.x & 63) == 0 && (unsigned)((id) - B9_SSTAMP_BASE) < 64u) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g_gantt_star[(((id) - B9_SSTAMP_BASE) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define WSTAMP_LANDED(a, b) do { WSTAMP(a); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WSTAMP(b); } while (0)
 // start / end of every workgroup of the fused-step and tree kernels: [t_in, t_out, role | XCC id << 8 | HW_ID << 16, launch index]
 #define B9_GANTT_ENTER() const unsigned long long t_in_ = __builtin_amdgcn_s_memrealtime()

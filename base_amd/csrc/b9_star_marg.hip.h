@@ -391,7 +391,10 @@ __device__ __forceinline__ void star_marg_body(const DevPack &pk, const DevStars
     const int a = xcd % wsplit, b = xcd / wsplit;
     // SPLIT (small catalogues; DevStars::mg_piece): the dispatch position names a PIECE -- workgroup `split` of the n_split that
     // share one (star chunk, walker) takes the node chunks c = split, split + n_split, ... of every star's window and leaves
-    // its per-star share (ref, sum) in `shares` for k_marg_merge.  (n_split is a compile-time 1 in the unsplit instance: its
+    // its per-star share (ref, sum) in `shares` for k_marg_merge.  (A window is one to three chunks wide, so of two pieces one
+    // often walks most of it -- 16 us against 5, tools/probes/gantt_top.py.  Dealing the 16-node SUB-chunks over the pieces
+    // instead evens that out but makes every piece test every level-1 box: one chain on 10k stars 24.2 -> 23.4 us per step, on
+    // 20k stars 26.6 -> 28.4, 8 x 8 grid 43.0 / 53.5 -> 38.6 / 57.9, 8 walkers 43.6 / 76.9 -> 44.4 / 84.0 -- not adopted.)  (n_split is a compile-time 1 in the unsplit instance: its
     // code is the one-workgroup kernel's.)
     const int p_local = i_x / wg_n, wl = i_x - p_local * wg_n;
     const int w = wl * wsplit + a;
