@@ -278,14 +278,7 @@ __device__ __forceinline__ void marg_build_wd_table(const DevPack &pk, const Ste
 // candidates as the launch's own `const __restrict__` kernel arguments -- read through the StepDev / MargStep pointers
 // (which the builders of the same launch write through, for the other parity) the compiler cannot prove the tables
 // unclobbered and turns every scalar load of a box or an nb word into a vector load + v_readfirstlane: +18 % launch time.
-// WARM (split catalogues -- one chain, a few hundred workgroups, every one resident): while the decision is awaited, the star
-// workgroups of an XCD read BOTH candidates' node tables of their walker through once, a slice each (256 lanes x one 128-byte
-// line per round, at most B9_WARM_ROUNDS rounds).  The tables were written by the previous launch's builders on whatever XCD
-// they ran; a lone wave's walk otherwise pays a miss in its XCD's L2 for every box and every unit it touches, one after
-// the other (~3 us per unit against ~1 of arithmetic: tools/gantt_marg.py) -- the warm-up takes the misses all at once,
-// inside the wait.
-#define B9_WARM_ROUNDS 4
-#define B9_WARM_MAX_BYTES (3u << 19)
+// WARM: L2Warm (b9_star_marg.hip.h) -- both candidates' tables of the walker, read through inside the wait for the decision.
 template <bool WARM>
 struct MargStepSel {
     const StepDev &sd;
@@ -295,31 +288,18 @@ struct MargStepSel {
     const IsoHdr *__restrict__ hdr;
     const double *__restrict__ par, *__restrict__ tab, *__restrict__ wdt;
     int rank, count;         // WARM: this workgroup among the star workgroups of its XCD
-    unsigned warm[B9_WARM_ROUNDS];
+    L2Warm warm;
     __device__ __forceinline__ void issue(int w)
     {
         if constexpr (WARM) {
-#pragma unroll
-            for (int k = 0; k < B9_WARM_ROUNDS; ++k) warm[k] = 0u;
-            if (wd) return;
             const size_t rows = (size_t)sd.n_walkers * sd.n_pops, per = (size_t)sd.n_pops * mx.L.total;      // (doubles per candidate of this walker)
-            if (per * 16 > B9_WARM_MAX_BYTES) return;       // (both candidates together would crowd the XCD's 4 MB out: the 8 x 8 grid's tables, 4.4 MB, lost 3 us)
-#pragma unroll
-            for (int k = 0; k < B9_WARM_ROUNDS; ++k) {
-                const size_t line = ((size_t)k * count + rank) * 256 + threadIdx.x;       // (16 doubles a line; both candidates, one after the other)
-                const size_t off = line * 16;
-                if (off < 2 * per) {
-                    const double *a = tab + (off < per ? (size_t)w * per + off : rows * mx.L.total + (size_t)w * per + (off - per));
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(warm[k]) : "v"(a));
-                }
-            }
+            if (wd) warm.issue(tab, nullptr, 0, 0, 1);
+            else warm.issue(tab + (size_t)w * per, tab + rows * mx.L.total + (size_t)w * per, per, rank, count);
         }
     }
     __device__ __forceinline__ MargSel finish(int w)
     {
-        if constexpr (WARM) {          // (the lines have long arrived when the decision has; the registers are free from here on)
-            if (!wd) asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm[0]), "+v"(warm[1]), "+v"(warm[2]), "+v"(warm[3]));
-        }
+        if constexpr (WARM) warm.wait();          // (the lines have long arrived when the decision has)
         if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) {
             const int s0 = (!MSTEP_NO_DECIDE && wait_decision(sd, w)) ? 1 : 0;
             if (threadIdx.x == 0) *s_sel = s0;

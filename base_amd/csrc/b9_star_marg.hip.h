@@ -328,10 +328,47 @@ __device__ __forceinline__ void lse_term(double t, double &ref, double &sm, doub
 // the star's own words are requested: its chain is the longer one), `select.finish(w)` -- called once per workgroup, by
 // all its threads, after the star's words have been requested -- returns the choice.
 struct MargSel { const IsoHdr *hdr; const double *params; const double *tab; };
+
+// WARM (split catalogues -- one chain, a few hundred workgroups, every one resident): the star workgroups of an XCD read their
+// walker's node tables through once, a slice each (256 lanes x one 128-byte line per round, at most B9_WARM_ROUNDS rounds),
+// before any of them walks.  The tables were written by the launch before on whatever XCD its workgroups ran; a lone wave's
+// walk otherwise pays a miss in its XCD's L2 for every box and every unit it touches, one after the other (~3 us per unit
+// against ~1 of arithmetic: tools/gantt_marg.py) -- the warm-up takes the misses all at once (in k_marg_step: inside the wait
+// for the decision, both candidates).  Not for tables that would crowd the XCD's 4 MB (B9_WARM_MAX_BYTES: the 8 x 8 grid's
+// two candidates, 4.4 MB, lost 3 us).
+#define B9_WARM_ROUNDS 4
+#define B9_WARM_MAX_BYTES (3u << 19)
+struct L2Warm {
+    unsigned r[B9_WARM_ROUNDS];
+    // the lines (16 doubles) of [b0, b0 + n) and then [b1, b1 + n) (b1 null: none): workgroup `rank` of `count`
+    __device__ __forceinline__ void issue(const double *b0, const double *b1, size_t n, int rank, int count)
+    {
+#pragma unroll
+        for (int k = 0; k < B9_WARM_ROUNDS; ++k) r[k] = 0u;
+        const size_t total = b1 ? 2 * n : n;
+        if (total * 8 > B9_WARM_MAX_BYTES) return;
+#pragma unroll
+        for (int k = 0; k < B9_WARM_ROUNDS; ++k) {
+            const size_t off = (((size_t)k * count + rank) * 256 + threadIdx.x) * 16;
+            if (off < total) {
+                const double *a = off < n ? b0 + off : b1 + (off - n);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(r[k]) : "v"(a));
+            }
+        }
+    }
+    // (the registers are the loads' until here)
+    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])); }
+};
+static_assert(B9_WARM_ROUNDS == 4, "L2Warm::wait names four registers");
+
+template <bool WARM>
 struct MargSelPlain {
     MargSel s;
-    __device__ __forceinline__ void issue(int) {}
-    __device__ __forceinline__ MargSel finish(int) const { return s; }
+    size_t per;              // WARM: doubles of one walker's tables
+    int rank, count;         //       this workgroup among the launch's workgroups on its XCD
+    L2Warm warm;
+    __device__ __forceinline__ void issue(int w) { if constexpr (WARM) warm.issue(s.tab + (size_t)w * per, nullptr, per, rank, count); }
+    __device__ __forceinline__ MargSel finish(int) { if constexpr (WARM) warm.wait(); return s; }
 };
 
 // TILE: how a unit's 16 rows reach the lanes.  The scalar path (SRow) holds ONE row ahead in scalar registers -- all that
@@ -643,7 +680,8 @@ void k_star_marg(DevPack pk, DevStars st, const IsoHdr *__restrict__ hdr,
 {
     extern __shared__ __attribute__((aligned(16))) double tile_lds[];        // (TILE: 4 x B9_TILE_DOUBLES doubles)
     star_marg_body<NFP, NPOPS, SAMPLE, SPLIT, COST, TILE>(pk, st, (int)blockIdx.x, tile_lds, iso_data, iso_stride, mass_cap, partial, partial_stride, perstar, K, Q, ms, L,
-                                                    n_walkers, cut2, wsplit, shares, MargSelPlain{MargSel{hdr, params, tab}});
+                                                    n_walkers, cut2, wsplit, shares,
+                                                    MargSelPlain<SPLIT && !COST>{MargSel{hdr, params, tab}, (size_t)NPOPS * L.total, (int)blockIdx.x >> 3, ((int)gridDim.x + 7) >> 3, {}});
 }
 
 // k_marg_merge: the stars of a SPLIT launch -- one wave per (star chunk, walker), lane = star: the chunk's shares (ref, sum) of
@@ -975,5 +1013,5 @@ __global__ __launch_bounds__(256) void k_star_marg_wd(DevPack pk, DevStars st, c
                                                       int K, MargSample ms, const double *__restrict__ wtab)
 {
     star_marg_wd_body<NFP, NPOPS, SAMPLE>(pk, st, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, iso_data, iso_stride, mass_cap, partial, partial_stride,
-                                          perstar, K, ms, MargSelPlain{MargSel{hdr, params, wtab}});
+                                          perstar, K, ms, MargSelPlain<false>{MargSel{hdr, params, wtab}, 0, 0, 0, {}});
 }
