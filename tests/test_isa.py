@@ -73,6 +73,23 @@ def test_checker_sees_a_use_before_the_wait_also_across_a_back_edge(tmp_path):
     assert (len(f), n, k) == (0, 2, 1)
     f, n, k = chk.check(_asm(tmp_path, lds.replace("v_mov_b32_e32 v70, v8", "v_mov_b32_e32 v70, v65")))
     assert len(f) == 1 and f[0][3] == ["v65"]
+    # the L2 warm-up's global loads are waited for by vmcnt: an lgkmcnt wait does not release their registers
+    warm = """
+        ;;#ASMSTART
+        global_load_dword v40, v[2:3], off
+        ;;#ASMEND
+        s_waitcnt lgkmcnt(0)
+        v_add_u32_e32 v5, v6, v7
+        ;;#ASMSTART
+        s_waitcnt vmcnt(0)
+        ;;#ASMEND
+        v_mov_b32_e32 v41, v40
+        s_endpgm
+    """
+    f, n, k = chk.check(_asm(tmp_path, warm))
+    assert (len(f), n, k) == (0, 1, 1)
+    f, n, k = chk.check(_asm(tmp_path, warm.replace("v_add_u32_e32 v5, v6, v7", "v_add_u32_e32 v40, v6, v7")))
+    assert len(f) == 1 and f[0][3] == ["v40"]
 
 
 def test_shipped_marginalised_kernels_touch_no_row_register_before_its_wait():

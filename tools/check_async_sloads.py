@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ISA check of the ASYNCHRONOUS loads of the marginalised kernels: the scalar row loads (SRow, b9_star_marg.hip.h) and the
 packed-fp32 box test's LDS reads (box_bound32: ds_read_b128 from inline assembly, one wait for the batch -- the same hazard with
-VGPR destinations).
+VGPR destinations); the L2 warm-up's global loads (L2Warm) likewise, until their s_waitcnt vmcnt(0).
 
 SRow::load issues s_load_dwordx8 / x16 / x2 from inline assembly and defers the s_waitcnt to SRow::wait.  To the compiler
 the destination SGPRs are defined at the load's ISSUE; nothing tells its register allocator or its waitcnt insertion that
@@ -117,6 +117,7 @@ def check_kernel(instrs):
             s_ = [i + 1] if i + 1 < len(blocks) else []
         succ.append(s_)
     state_in = [dict() for _ in blocks]
+    vm = set()            # registers an inline-assembly global load defines (waited for by vmcnt, not lgkmcnt)
     findings, n_loads = {}, 0
     work = list(range(len(blocks)))
     counted = set()
@@ -127,7 +128,17 @@ def check_kernel(instrs):
             op = t.split()[0]
             if op.startswith("s_waitcnt"):
                 if "lgkmcnt(0)" in t:
-                    infl = {}
+                    infl = {r: l for r, l in infl.items() if r in vm}
+                if "vmcnt(0)" in t:
+                    infl = {r: l for r, l in infl.items() if r not in vm}
+                continue
+            if a and op.startswith("global_load"):          # (L2Warm: destinations pending until s_waitcnt vmcnt(0))
+                if ln not in counted:
+                    counted.add(ln)
+                    n_loads += 1
+                for r in regs(t.split(",")[0]):
+                    infl[r] = ln
+                    vm.add(r)
                 continue
             if a and (op.startswith("s_load_dword") or op.startswith("ds_read")):
                 if ln not in counted:
