@@ -180,7 +180,7 @@ typedef struct b9_tuning {
     int32_t marg_no_pruning;   /* 1: marginalised kernel evaluates every node of every star (no floor, no boxes): the      */
                                /* brute-force statement of the same sum on the GPU, for tests                            */
     int32_t timing_group;      /* launches per HIP-event bracket of b9_enable_timing in the fused step (default 8)        */
-    int32_t plan_debug;        /* 1: print the fused step's launch plan to stderr whenever it changes                    */
+    int32_t plan_debug;        /* 1: print the fused step's launch plan to stderr whenever it changes; 2: also the marginalised catalogue's pieces */
     int32_t tree_depth;        /* given-mass sampler blocks: Metropolis steps per launch.  1 = the one-step fused launch;   */
                                /* 2 / 3 = the tree-speculative launch (every proposal of the chain's next 2 / 3 steps --   */
                                /* 3 / 7 of them -- evaluated at once, same chain); default: the deepest tree whose          */
