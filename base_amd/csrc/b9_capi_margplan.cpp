@@ -136,7 +136,8 @@ int ensure_marg_plan(b9_ctx *ctx)
         // the smallest piece worth a workgroup (b9_tuning.marg_piece_units; measured, us per step of one chain at 4 x 4, 10k / 20k
         // stars: 2 units 32.9 / 39.0, 3: 33.1 / 37.5, 4: 31.6 / 36.4, 6: 39.1 / 51.4, 10: 49.2 / 53.5; 8 walkers: 4: 55.8 / 92.9,
         // 10: 56.3 / 79.2 -- a lone wave is latency-bound, one scalar-load round trip per table row: more resident waves hide it)
-        const double piece_min = ctx->marg_piece_units > 0 ? (double)ctx->marg_piece_units : 4.0;
+        // (the 8 x 8 grid, same shapes: 2 units 48.6 / 62.2, 4: 43.0 / 50.6, 6: 41.1 / 47.0, 8: 47.6 / 53.6, 12: 53.2 / 66.5 -- six from eight mass ratios on)
+        const double piece_min = ctx->marg_piece_units > 0 ? (double)ctx->marg_piece_units : (Q >= 8 ? 6.0 : 4.0);
         const double P = measured ? std::max(total / slots, piece_min) : 1.0 / 8.0;      // (unmeasured: 8 pieces each, round 4's split)
         std::vector<int> n_piece(n_mc), base(n_mc + 1, 0), pieces;
         for (int c = 0; c < n_mc; ++c) n_piece[c] = std::min(kMaxPieces, std::max(1, (int)std::ceil(cost[c] / P)));

@@ -188,7 +188,7 @@ typedef struct b9_tuning {
                                /* launch's (few walkers per GPU, catalogues that leave the chip under-filled), else 1.      */
                                /* Env: B9_TREE_DEPTH                                                                        */
     int32_t marg_piece_units;  /* marginalised mode, small catalogues: the smallest share of a star chunk's node window worth a   */
-                               /* workgroup of its own, in (16 nodes x one mass ratio) units per wave (default 4).  Part of what a   */
+                               /* workgroup of its own, in (16 nodes x one mass ratio) units per wave (default 4; 6 from 8 mass ratios on).  Part of what a */
                                /* star's sum rounds like: every rank of a run must use the same value.  Env: B9_MARG_PIECE_UNITS   */
     int32_t reserved[6];
 } b9_tuning;
